@@ -1,0 +1,119 @@
+/* smalltts_hip.h — C ABI of libsmalltts_hip.so (MI355X / gfx950).
+ *
+ * Drop-in boundary for the four opaque onnxruntime graphs the reference drives
+ * (SURVEY.md §8b).  Each entry point cites the reference interface it replaces
+ * (paths relative to the reference repository root):
+ *
+ *   smtts_cond_encode   <- condition_encoder.onnx   src/smalltts/infer/onnx.py:91-96,
+ *                                                   src/server/src/pipeline.rs:122-141  (= DiTModel.encode_conditions,
+ *                                                   src/smalltts/models/backbone/model.py:88-95)
+ *   smtts_denoise_step  <- denoiser.onnx            src/smalltts/infer/onnx.py:107-124,
+ *                                                   src/server/src/pipeline.rs:143-166  (= DiTModel.denoise_step, model.py:97-100)
+ *   smtts_sample        <- the host-side sampler loop src/smalltts/infer/onnx.py:98-125, pipeline.rs:84-93
+ *                          (mode 1: teacher ODE + CFG, built from src/scripts/train/dmd2/distill.py:60-134)
+ *   smtts_codec_decode  <- codec/decoder.onnx       src/smalltts/codec/onnx.py:34-53, infer/onnx.py:127-128
+ *   smtts_codec_encode  <- codec/encoder.onnx       src/smalltts/codec/onnx.py:56-75
+ *
+ * Conventions: plain C types only; every tensor argument is a DEVICE pointer on the handle's GPU
+ * (e.g. torch tensor.data_ptr()); `stream` is a hipStream_t passed as void* (NULL = default stream);
+ * all work is enqueued asynchronously on `stream`.  The caller owns inputs, outputs and workspace
+ * (query the size first); the library owns weights only.  Return 0 = ok, non-zero = error with the
+ * message available from smtts_last_error().  A handle is single-stream and not thread-safe: one
+ * handle per GPU (the reference also allows one inference in flight, src/server/src/main.rs:24,138).
+ * bool tensors are 1 byte per element (numpy/torch bool).
+ */
+#ifndef SMALLTTS_HIP_H
+#define SMALLTTS_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct smtts_engine* smtts_handle;
+
+/* ---- lifecycle ------------------------------------------------------------------------------ */
+int smtts_create(int device_id, smtts_handle* out);
+int smtts_destroy(smtts_handle h);
+const char* smtts_last_error(smtts_handle h); /* h may be NULL: last creation error */
+const char* smtts_version(void);
+
+/* ---- weights (replaces the ONNX initialisers; names/shapes = DiTModel.state_dict(),
+ *      src/scripts/test_checkpoint.py:44-73, plus codec.* names of smalltts_amd/weights.py) ---- */
+int smtts_set_tensor(smtts_handle h, const char* name, const float* data, const int64_t* shape, int ndim,
+                     int data_on_device);
+int smtts_synth_tensor(smtts_handle h, const char* name, const int64_t* shape, int ndim, uint64_t key, float mean,
+                       float half_range);
+int smtts_get_tensor(smtts_handle h, const char* name, float* host_out, int64_t numel);
+/* codec hyper-parameters (decoder order); must precede smtts_finalize when codec tensors are present */
+int smtts_set_codec_spec(smtts_handle h, int latent_dim, int n_filters, int kernel, int ffn_mult, float eps,
+                         const int* ratios, int n_ratios, const int* depths /* n_ratios + 1 */);
+int smtts_finalize(smtts_handle h);
+/* 3 = split-bf16 MFMA (fp32-class accuracy, default) ; 1 = single-pass bf16 MFMA */
+int smtts_set_precision(smtts_handle h, int split);
+int smtts_has_part(smtts_handle h, int part); /* 0 dit, 1 codec decoder, 2 codec encoder */
+
+/* ---- condition encoder ---------------------------------------------------------------------- */
+size_t smtts_cond_workspace_bytes(smtts_handle h, int B, int R, int P);
+/* ref f32 (B,R,64); ref_len i64 (B); phonemes i64 (B,P); ph_mask bool (B,P)
+ * -> k_ref,v_ref f32 (12,B,8,R,120); ref_mask bool (B,R); k_text,v_text f32 (12,B,8,P,120).
+ * ref_seq_out (B,R,960) / mem_out (B,P,960) are optional debug taps (NULL to skip). */
+int smtts_cond_encode(smtts_handle h, void* stream, const float* ref, const int64_t* ref_len, const int64_t* phonemes,
+                      const uint8_t* ph_mask, int B, int R, int P, float* k_ref, float* v_ref, uint8_t* ref_mask,
+                      float* k_text, float* v_text, void* ws, size_t ws_bytes, float* ref_seq_out, float* mem_out);
+
+/* ---- denoiser --------------------------------------------------------------------------------- */
+size_t smtts_denoise_workspace_bytes(smtts_handle h, int B, int N);
+/* x_t f32 (B,N,64); mask bool (B,N); t f32 (B); caches as above; rope f32 (1,N,64) angles or NULL
+ * -> velocity f32 (B,N,64) */
+int smtts_denoise_step(smtts_handle h, void* stream, const float* x_t, const uint8_t* mask, const float* t,
+                       const float* k_ref, const float* v_ref, const uint8_t* ref_mask, const float* k_text,
+                       const float* v_text, const uint8_t* ph_mask, const float* rope, int B, int N, int R, int P,
+                       float* velocity, void* ws, size_t ws_bytes);
+
+/* ---- sampler ---------------------------------------------------------------------------------- */
+size_t smtts_sample_workspace_bytes(smtts_handle h, int B, int N, int n_steps, int cfg);
+/* mode 0: x=0; for t in linspace(1,0,n): x_t = a x + s eps_i; v = denoise; x = a x_t - s v  (DMD student)
+ * mode 1: deterministic ODE from x_1 = s(1) eps (teacher), see DESIGN.md
+ * cfg != 0: mask/caches/cond masks carry 3B rows [cond; text dropped; speaker dropped]; x has B rows;
+ *           v = vc + s_text (vc - vt) + s_spk (vc - vs).
+ * noise: mode 0 (n_steps,B,N,64), mode 1 (B,N,64); NULL -> on-device Philox4x32-10 with `seed`.
+ * x_out (B,N,64); steps_out optional (n_steps,B,N,64) x-hat after every step. */
+int smtts_sample(smtts_handle h, void* stream, int mode, int n_steps, int cfg, float s_text, float s_spk,
+                 const uint8_t* mask, const float* k_ref, const float* v_ref, const uint8_t* ref_mask,
+                 const float* k_text, const float* v_text, const uint8_t* ph_mask, int B, int N, int R, int P,
+                 const float* noise, uint64_t seed, float* x_out, float* steps_out, void* ws, size_t ws_bytes);
+
+/* ---- codec ------------------------------------------------------------------------------------ */
+int smtts_codec_hop(smtts_handle h);
+size_t smtts_decode_workspace_bytes(smtts_handle h, int B, int T);
+/* latents f32 (B,T,64) -> audio f32 (B,1,hop*T) */
+int smtts_codec_decode(smtts_handle h, void* stream, const float* latents, int B, int T, float* audio, void* ws,
+                       size_t ws_bytes);
+size_t smtts_encode_workspace_bytes(smtts_handle h, int B, int S);
+/* audio f32 (B,1,S) -> latents f32 (B, S/hop, 64) */
+int smtts_codec_encode(smtts_handle h, void* stream, const float* audio, int B, int S, float* latents, void* ws,
+                       size_t ws_bytes);
+
+/* ---- utilities -------------------------------------------------------------------------------- */
+/* standard normals, same generator the sampler uses: element i <- Philox4x32-10(counter=(i/4, stream_id), key=seed) */
+int smtts_randn(smtts_handle h, void* stream, float* out, int64_t n, uint64_t seed, uint64_t stream_id);
+/* (alpha, sigma) of the reference schedule for t (infer/onnx.py:31-39); host-side, float64 math */
+void smtts_alpha_sigma(float t, float* alpha, float* sigma);
+
+/* ---- single-kernel test hooks (used by tests/ to check kernels in isolation) -------------------- */
+/* C[M,N] = A[M,K] (f32, lda) * W[N,K]^T (f32 host-layout on device, split internally) + bias ; act as ACT_* */
+int smtts_test_gemm(smtts_handle h, void* stream, const float* A, int lda, const float* W, const float* bias, int M,
+                    int N, int K, int act, int split, int cfg, float* C, int ldc);
+int smtts_test_swiglu(smtts_handle h, void* stream, const float* A, const float* W1, const float* W3, const float* b1,
+                      const float* b3, int M, int F, int K, int split, float* out);
+int smtts_test_attention(smtts_handle h, void* stream, const float* qkvg, const float* qw, const float* kw, float eps,
+                         const float* rope, int rot_dim, const float* k_ref, const float* v_ref, int R,
+                         const float* k_text, const float* v_text, int P, const uint8_t* mask_self,
+                         const uint8_t* mask_ref, const uint8_t* mask_text, int B, int N, int H, int dh, float* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,234 @@
+// Fused joint attention for the smalltts DiT and the two condition encoders (gfx950).
+//
+// Reference semantics (dit.py:95-135, style.py:48-68):
+//   q = RoPE(RMSNorm_head(q_raw) ), k_self = RoPE(RMSNorm_head(k_raw)), keys = [k_self | k_ref | k_text]
+//   o = softmax(q keys^T / sqrt(dh) + keymask) [v_self | v_ref | v_text] ;  out = o * sigmoid(gate)
+// Cross keys arrive already normalised from the KV cache and carry no RoPE (dit.py:83-86).
+//
+// Work decomposition: one workgroup per (16-query tile, head, batch row) -> >=300 workgroups at the
+// bench shape; K/V are staged through LDS in 64-key chunks with an online softmax, so Ktot is
+// unbounded.  Inside a chunk: lane = key for q.k^T (ds_read_b128 rows, padded stride -> no bank
+// conflicts), wave-wide max/sum by cross-lane shuffles, then lane = head-dim for P.V with P
+// broadcast from LDS.  All math fp32: attention is 0.16 % of the model FLOPs and
+// its scores need fp32 to hold the 1e-3 latent parity.
+#include "kernels.hpp"
+
+template <int DH>
+__global__ __launch_bounds__(256) void attention_kernel(AttnArgs a) {
+    constexpr int KC = 64, QW = 4, QT = 16;
+    constexpr int KS = DH + 4;             // K row stride in LDS (floats)
+    constexpr int DPL = (DH + 63) / 64;    // head dims per lane in the P.V phase
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* K_s = smem;                     // [KC][KS]
+    float* V_s = K_s + KC * KS;            // [KC][DH]
+    float* q_s = V_s + KC * DH;            // [QT][DH]
+    float* p_s = q_s + QT * DH;            // [4 waves][KC][QW]
+    float* m_s = p_s + 4 * KC * QW;        // [KC] key validity
+
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int qt = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+    const int N = a.N, R = a.k_ref ? a.R : 0, P = a.k_text ? a.P : 0;
+    const int Ktot = N + R + P;
+    const float inv_dh = 1.0f / (float)DH;
+    const float sm_scale = 1.0f / sqrtf((float)DH);
+
+    // RMSNorm (per-head weight) + RoPE on interleaved pairs for one row held as DPL regs per lane
+    auto norm_rope = [&](const float* src, const float* wgt, int pos, float out[DPL]) {
+        float x[DPL];
+        float ss = 0.f;
+#pragma unroll
+        for (int i = 0; i < DPL; ++i) {
+            int d = lane + 64 * i;
+            x[i] = d < DH ? src[d] : 0.f;
+            ss += x[i] * x[i];
+        }
+        ss = wave_sum(ss);
+        const float rstd = 1.0f / sqrtf(ss * inv_dh + a.eps);
+#pragma unroll
+        for (int i = 0; i < DPL; ++i) {
+            int d = lane + 64 * i;
+            float y = d < DH ? x[i] * rstd * wgt[d] : 0.f;
+            float partner = __shfl_xor(y, 1, 64);
+            if (d < a.rot_dim) {
+                float ang = a.rope[(long)pos * a.rot_dim + d];
+                float c = cosf(ang), s = sinf(ang);
+                y = (d & 1) ? (y * c + partner * s) : (y * c - partner * s);
+            }
+            out[i] = y;
+        }
+    };
+
+    // ---- queries of this wave -> LDS (pre-scaled by 1/sqrt(dh)) ------------------------------
+    const int q0 = qt * QT + w * QW;
+#pragma unroll
+    for (int qi = 0; qi < QW; ++qi) {
+        const int n = q0 + qi;
+        float qv[DPL];
+        if (n < N) {
+            norm_rope(a.q + (long)b * a.bs + (long)n * a.rs + h * DH, a.qw + h * DH, n, qv);
+        } else {
+#pragma unroll
+            for (int i = 0; i < DPL; ++i) qv[i] = 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < DPL; ++i) {
+            int d = lane + 64 * i;
+            if (d < DH) q_s[(w * QW + qi) * DH + d] = qv[i] * sm_scale;
+        }
+    }
+
+    float m_run[QW], l_run[QW], o[QW][DPL];
+#pragma unroll
+    for (int qi = 0; qi < QW; ++qi) {
+        m_run[qi] = -INFINITY;
+        l_run[qi] = 0.f;
+#pragma unroll
+        for (int i = 0; i < DPL; ++i) o[qi][i] = 0.f;
+    }
+
+    for (int c0 = 0; c0 < Ktot; c0 += KC) {
+        __syncthreads();  // previous chunk fully consumed (also orders the q_s writes on entry)
+        // ---- stage K/V chunk: each wave fills rows w, w+4, ... ------------------------------
+        for (int jj = w; jj < KC; jj += 4) {
+            const int gk = c0 + jj;
+            float kv[DPL], vv[DPL];
+            float valid = 0.f;
+            if (gk < N) {
+                const long base = (long)b * a.bs + (long)gk * a.rs + h * DH;
+                norm_rope(a.k + base, a.kw + h * DH, gk, kv);
+#pragma unroll
+                for (int i = 0; i < DPL; ++i) {
+                    int d = lane + 64 * i;
+                    vv[i] = d < DH ? a.v[base + d] : 0.f;
+                }
+                valid = (!a.mask_self || a.mask_self[b * N + gk]) ? 1.f : 0.f;
+            } else if (gk < Ktot) {
+                const bool isref = gk < N + R;
+                const int j = isref ? gk - N : gk - N - R;
+                const int S = isref ? R : P;
+                const long base = (((long)b * a.H + h) * S + j) * DH;
+                const float* kp = (isref ? a.k_ref : a.k_text) + base;
+                const float* vp = (isref ? a.v_ref : a.v_text) + base;
+#pragma unroll
+                for (int i = 0; i < DPL; ++i) {
+                    int d = lane + 64 * i;
+                    kv[i] = d < DH ? kp[d] : 0.f;
+                    vv[i] = d < DH ? vp[d] : 0.f;
+                }
+                const uint8_t* mk = isref ? a.mask_ref : a.mask_text;
+                valid = (!mk || mk[b * S + j]) ? 1.f : 0.f;
+            } else {
+#pragma unroll
+                for (int i = 0; i < DPL; ++i) { kv[i] = 0.f; vv[i] = 0.f; }
+            }
+#pragma unroll
+            for (int i = 0; i < DPL; ++i) {
+                int d = lane + 64 * i;
+                if (d < DH) {
+                    K_s[jj * KS + d] = kv[i];
+                    V_s[jj * DH + d] = vv[i];
+                }
+            }
+            if (lane == 0) m_s[jj] = valid;
+        }
+        __syncthreads();
+
+        // ---- scores: lane = key --------------------------------------------------------------
+        float s[QW];
+#pragma unroll
+        for (int qi = 0; qi < QW; ++qi) s[qi] = 0.f;
+        const float4* kr = reinterpret_cast<const float4*>(K_s + lane * KS);
+#pragma unroll 6
+        for (int d4 = 0; d4 < DH / 4; ++d4) {
+            const float4 kk = kr[d4];
+#pragma unroll
+            for (int qi = 0; qi < QW; ++qi) {
+                const float4 qq = reinterpret_cast<const float4*>(q_s + (w * QW + qi) * DH)[d4];
+                s[qi] += qq.x * kk.x + qq.y * kk.y + qq.z * kk.z + qq.w * kk.w;
+            }
+        }
+        const bool kvalid = m_s[lane] != 0.f;
+        float p4[QW];
+#pragma unroll
+        for (int qi = 0; qi < QW; ++qi) {
+            const float sv = kvalid ? s[qi] : -INFINITY;
+            const float cm = wave_max(sv);
+            const float m_new = fmaxf(m_run[qi], cm);
+            float alpha = 1.f, p = 0.f;
+            if (m_new != -INFINITY) {
+                alpha = (m_run[qi] == -INFINITY) ? 0.f : expf(m_run[qi] - m_new);
+                p = kvalid ? expf(sv - m_new) : 0.f;
+            }
+            const float cs = wave_sum(p);
+            l_run[qi] = l_run[qi] * alpha + cs;
+#pragma unroll
+            for (int i = 0; i < DPL; ++i) o[qi][i] *= alpha;
+            m_run[qi] = m_new;
+            p4[qi] = p;
+        }
+        float* pw = p_s + w * KC * QW;
+        *reinterpret_cast<float4*>(pw + lane * QW) = make_float4(p4[0], p4[1], p4[2], p4[3]);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+        // ---- P.V: lane = head dim ------------------------------------------------------------
+        const int kc = (Ktot - c0) < KC ? (Ktot - c0) : KC;
+        for (int jj = 0; jj < kc; ++jj) {
+            const float4 pp = *reinterpret_cast<const float4*>(pw + jj * QW);
+            float vv[DPL];
+#pragma unroll
+            for (int i = 0; i < DPL; ++i) {
+                int d = lane + 64 * i;
+                vv[i] = d < DH ? V_s[jj * DH + d] : 0.f;
+            }
+#pragma unroll
+            for (int i = 0; i < DPL; ++i) {
+                o[0][i] += pp.x * vv[i];
+                o[1][i] += pp.y * vv[i];
+                o[2][i] += pp.z * vv[i];
+                o[3][i] += pp.w * vv[i];
+            }
+        }
+    }
+
+    // ---- normalise, gate, store ----------------------------------------------------------------
+#pragma unroll
+    for (int qi = 0; qi < QW; ++qi) {
+        const int n = q0 + qi;
+        if (n >= N) continue;
+        const float inv = l_run[qi] > 0.f ? 1.0f / l_run[qi] : 0.f;
+#pragma unroll
+        for (int i = 0; i < DPL; ++i) {
+            int d = lane + 64 * i;
+            if (d < DH) {
+                float g = a.gate[(long)b * a.bs + (long)n * a.rs + h * DH + d];
+                a.out[(long)b * a.obs + (long)n * a.ors + h * DH + d] = o[qi][i] * inv / (1.0f + expf(-g));
+            }
+        }
+    }
+}
+
+template <int DH>
+static hipError_t attention_go(const AttnArgs& a, hipStream_t st) {
+    constexpr int KC = 64, QW = 4, QT = 16, KS = DH + 4;
+    size_t lds = sizeof(float) * (KC * KS + KC * DH + QT * DH + 4 * KC * QW + KC);
+    auto kern = attention_kernel<DH>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)lds);
+    if (e != hipSuccess) return e;
+    dim3 grid((a.N + QT - 1) / QT, a.H, a.B);
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_attention(const AttnArgs& a, hipStream_t st) {
+    if (a.N <= 0 || a.B <= 0) return hipSuccess;
+    if (a.rot_dim & 1 || a.rot_dim > a.dh) return hipErrorInvalidValue;
+    switch (a.dh) {
+        case 64: return attention_go<64>(a, st);
+        case 120: return attention_go<120>(a, st);
+        case 128: return attention_go<128>(a, st);
+    }
+    return hipErrorInvalidValue;
+}

@@ -1,0 +1,1043 @@
+// Engine: weight registry, GEMM packing, and the kernel sequences of the hot-path operators.
+#include "engine.hpp"
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+
+#define HIPC(x)                                          \
+    do {                                                 \
+        hipError_t e__ = (x);                            \
+        if (e__ != hipSuccess) return fail_hip(e__, #x); \
+    } while (0)
+
+namespace {
+struct Bump {  // bump allocator over a caller-owned workspace (also used, with p == null, to size it)
+    char* p;
+    size_t off = 0;
+    explicit Bump(void* base) : p(static_cast<char*>(base)) {}
+    template <class T>
+    T* take(size_t n) {
+        off = (off + 255) & ~size_t(255);
+        T* r = reinterpret_cast<T*>(p + off);
+        off += n * sizeof(T);
+        return r;
+    }
+};
+inline std::string sidx(const std::string& a, int i, const std::string& b) { return a + std::to_string(i) + b; }
+}  // namespace
+
+Engine::Engine(int device) : device_(device) {}
+
+Engine::~Engine() {
+    (void)hipSetDevice(device_);
+    for (void* p : allocs_) (void)hipFree(p);
+}
+
+int Engine::fail_hip(hipError_t e, const char* what) {
+    err_ = std::string(what) + ": " + hipGetErrorString(e);
+    return 1;
+}
+
+void* Engine::dalloc(size_t bytes) {
+    void* p = nullptr;
+    if (hipMalloc(&p, bytes ? bytes : 16) != hipSuccess) return nullptr;
+    allocs_.push_back(p);
+    return p;
+}
+
+const RawTensor* Engine::raw(const std::string& n) const {
+    auto it = raw_.find(n);
+    return it == raw_.end() ? nullptr : &it->second;
+}
+const float* Engine::rawp(const std::string& n) const {
+    const RawTensor* t = raw(n);
+    return t ? t->d : nullptr;
+}
+
+// ---------------------------------------------------------------------------------------------
+// weights in
+// ---------------------------------------------------------------------------------------------
+int Engine::set_tensor(const char* name, const float* data, const long* shape, int ndim, bool src_on_device) {
+    HIPC(hipSetDevice(device_));
+    RawTensor t;
+    t.numel = 1;
+    for (int i = 0; i < ndim; ++i) { t.shape.push_back(shape[i]); t.numel *= shape[i]; }
+    auto it = raw_.find(name);
+    if (it != raw_.end() && it->second.numel == t.numel) {
+        t.d = it->second.d;
+    } else {
+        t.d = static_cast<float*>(dalloc(t.numel * sizeof(float)));
+        if (!t.d) return fail("out of device memory for tensor " + std::string(name));
+    }
+    HIPC(hipMemcpy(t.d, data, t.numel * sizeof(float), src_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice));
+    raw_[name] = t;
+    finalized_ = false;
+    return 0;
+}
+
+int Engine::synth_tensor(const char* name, const long* shape, int ndim, uint64_t key, float mean, float half_range) {
+    HIPC(hipSetDevice(device_));
+    RawTensor t;
+    t.numel = 1;
+    for (int i = 0; i < ndim; ++i) { t.shape.push_back(shape[i]); t.numel *= shape[i]; }
+    t.d = static_cast<float*>(dalloc(t.numel * sizeof(float)));
+    if (!t.d) return fail("out of device memory for tensor " + std::string(name));
+    HIPC(launch_synth(t.d, t.numel, key, mean, half_range, 0));
+    raw_[name] = t;
+    finalized_ = false;
+    return 0;
+}
+
+int Engine::get_tensor(const char* name, float* host_out, long numel) {
+    const RawTensor* t = raw(name);
+    if (!t) return fail("unknown tensor " + std::string(name));
+    if (numel != t->numel) return fail("size mismatch reading tensor " + std::string(name));
+    HIPC(hipSetDevice(device_));
+    HIPC(hipMemcpy(host_out, t->d, numel * sizeof(float), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int Engine::set_codec_spec(const CodecSpecC& s) {
+    if (s.n_ratios < 1 || s.n_ratios > 7) return fail("codec spec: 1..7 ratios supported");
+    cspec_ = s;
+    finalized_ = false;
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// packing helpers
+// ---------------------------------------------------------------------------------------------
+PW Engine::pack_from_f32(const float* src, int N, int K) {
+    PW w;
+    w.N = N;
+    w.K = K;
+    w.hi = static_cast<bf16_t*>(dalloc((size_t)N * K * 2));
+    w.lo = static_cast<bf16_t*>(dalloc((size_t)N * K * 2));
+    if (!w.hi || !w.lo) { w.N = 0; return w; }
+    if (launch_split_rows(src, K, w.hi, w.lo, K, N, K, nullptr, 0) != hipSuccess) w.N = 0;
+    return w;
+}
+
+PW Engine::pack_rows(const std::vector<std::string>& names, const std::vector<int>* perm) {
+    PW w;
+    int K = -1, Ntot = 0;
+    for (auto& n : names) {
+        const RawTensor* t = raw(n);
+        if (!t || t->shape.size() != 2) { err_ = "pack: missing/non-2D tensor " + n; return w; }
+        if (K < 0) K = (int)t->shape[1];
+        if (K != t->shape[1]) { err_ = "pack: K mismatch at " + n; return w; }
+        Ntot += (int)t->shape[0];
+    }
+    if (names.size() == 1 && !perm) return pack_from_f32(raw(names[0])->d, Ntot, K);
+    float* tmp = nullptr;
+    if (hipMalloc(&tmp, (size_t)Ntot * K * 4) != hipSuccess) { err_ = "pack: temp alloc failed"; return w; }
+    long off = 0;
+    for (auto& n : names) {
+        const RawTensor* t = raw(n);
+        (void)hipMemcpyAsync(tmp + off, t->d, t->numel * 4, hipMemcpyDeviceToDevice, 0);
+        off += t->numel;
+    }
+    int* dperm = nullptr;
+    if (perm) {
+        if (hipMalloc(&dperm, perm->size() * sizeof(int)) != hipSuccess) { (void)hipFree(tmp); return w; }
+        (void)hipMemcpyAsync(dperm, perm->data(), perm->size() * sizeof(int), hipMemcpyHostToDevice, 0);
+    }
+    w.N = Ntot;
+    w.K = K;
+    w.hi = static_cast<bf16_t*>(dalloc((size_t)Ntot * K * 2));
+    w.lo = static_cast<bf16_t*>(dalloc((size_t)Ntot * K * 2));
+    if (!w.hi || !w.lo || launch_split_rows(tmp, K, w.hi, w.lo, K, Ntot, K, dperm, 0) != hipSuccess) w.N = 0;
+    (void)hipStreamSynchronize(0);
+    (void)hipFree(tmp);
+    if (dperm) (void)hipFree(dperm);
+    return w;
+}
+
+// concatenate 1-D tensors; a name "" inserts zero_len[k] zeros (k-th empty name)
+float* Engine::concat_vec(const std::vector<std::string>& names, const std::vector<int>& zero_len) {
+    long tot = 0;
+    size_t zi = 0;
+    for (auto& n : names) {
+        if (n.empty()) { tot += zero_len[zi++]; continue; }
+        const RawTensor* t = raw(n);
+        if (!t) { err_ = "concat: missing tensor " + n; return nullptr; }
+        tot += t->numel;
+    }
+    float* d = static_cast<float*>(dalloc(tot * 4));
+    if (!d) return nullptr;
+    (void)hipMemsetAsync(d, 0, tot * 4, 0);
+    long off = 0;
+    zi = 0;
+    for (auto& n : names) {
+        if (n.empty()) { off += zero_len[zi++]; continue; }
+        const RawTensor* t = raw(n);
+        (void)hipMemcpyAsync(d + off, t->d, t->numel * 4, hipMemcpyDeviceToDevice, 0);
+        off += t->numel;
+    }
+    return d;
+}
+
+static std::vector<int> swiglu_perm(int F) {
+    std::vector<int> p(2 * F);
+    for (int i = 0; i < 2 * F; ++i) {
+        int blk = i / 64, within = i % 64;
+        p[i] = within < 32 ? blk * 32 + within : F + blk * 32 + (within - 32);
+    }
+    return p;
+}
+
+int Engine::build_encoder(EncoderW& e, const std::string& prefix, int dim, int heads, int ff, int layers, float eps) {
+    e.dim = dim; e.heads = heads; e.dh = dim / heads; e.ff = ff; e.layers = layers; e.eps = eps;
+    if (ff % 32) return fail("encoder ff must be a multiple of 32");
+    std::vector<int> perm = swiglu_perm(ff);
+    e.blocks.clear();
+    for (int i = 0; i < layers; ++i) {
+        std::string p = sidx(prefix + ".blocks.", i, "");
+        EncBlockW b;
+        b.qkvg = pack_rows({p + ".attention.wq.weight", p + ".attention.wk.weight", p + ".attention.wv.weight",
+                            p + ".attention.gate.weight"});
+        b.wo = pack_rows({p + ".attention.wo.weight"});
+        b.ff13 = pack_rows({p + ".mlp.w1.weight", p + ".mlp.w3.weight"}, &perm);
+        b.w2 = pack_rows({p + ".mlp.w2.weight"});
+        b.qn = rawp(p + ".attention.q_norm.weight");
+        b.kn = rawp(p + ".attention.k_norm.weight");
+        b.an = rawp(p + ".attention_norm.weight");
+        b.mn = rawp(p + ".mlp_norm.weight");
+        if (!b.qkvg.N || !b.wo.N || !b.ff13.N || !b.w2.N || !b.qn || !b.kn || !b.an || !b.mn)
+            return fail("encoder block incomplete: " + p + " (" + err_ + ")");
+        e.blocks.push_back(b);
+    }
+    e.final_norm = rawp(prefix + ".norm.weight");
+    if (!e.final_norm) return fail("missing " + prefix + ".norm.weight");
+    e.rope = static_cast<float*>(dalloc((size_t)kMaxPos * e.dh * 4));
+    if (!e.rope) return fail("rope table alloc failed");
+    HIPC(launch_rope_table(e.rope, kMaxPos, e.dh, 0));
+    return 0;
+}
+
+int Engine::finalize_dit() {
+    const std::string T = "dit.transformer_blocks.";
+    time0_ = pack_rows({"time_embedding.mlp.0.weight"});
+    time2_ = pack_rows({"time_embedding.mlp.2.weight"});
+    emb0_ = pack_rows({"dit.emb_proj.0.weight"});
+    emb2_ = pack_rows({"dit.emb_proj.2.weight"});
+    inproj_ = pack_rows({"dit.input_embed.proj.weight"});
+    velocity_ = pack_rows({"velocity.weight"});
+    phproj_ = pack_rows({"dit.phoneme_proj.weight"});
+    style_in_ = pack_rows({"style_encoder.in_proj.weight"});
+    style_out_ = pack_rows({"style_encoder.out_proj.weight"});
+    if (!time0_.N || !time2_.N || !emb0_.N || !emb2_.N || !inproj_.N || !velocity_.N || !phproj_.N || !style_in_.N ||
+        !style_out_.N)
+        return fail("DiT pack failed: " + err_);
+
+    std::vector<std::string> modw, modb, kvr, kvrb, kvt, kvtb, knc;
+    for (int i = 0; i < kBlocks; ++i) {
+        std::string p = sidx(T, i, "");
+        modw.push_back(p + ".attn_norm.linear.weight");
+        modb.push_back(p + ".attn_norm.linear.bias");
+        kvr.push_back(p + ".attn.to_k_ref.weight"); kvr.push_back(p + ".attn.to_v_ref.weight");
+        kvrb.push_back(p + ".attn.to_k_ref.bias"); kvrb.push_back(p + ".attn.to_v_ref.bias");
+        kvt.push_back(p + ".attn.to_k_text.weight"); kvt.push_back(p + ".attn.to_v_text.weight");
+        kvtb.push_back(p + ".attn.to_k_text.bias"); kvtb.push_back(p + ".attn.to_v_text.bias");
+        knc.push_back(p + ".attn.k_norm_cross.weight");
+    }
+    modw.push_back("dit.norm_out.linear.weight");
+    modb.push_back("dit.norm_out.linear.bias");
+    modall_ = pack_rows(modw);
+    modall_b_ = concat_vec(modb);
+    kvref_ = pack_rows(kvr);
+    kvref_b_ = concat_vec(kvrb);
+    kvtext_ = pack_rows(kvt);
+    kvtext_b_ = concat_vec(kvtb);
+    knc_ = concat_vec(knc);
+    if (!modall_.N || !modall_b_ || !kvref_.N || !kvref_b_ || !kvtext_.N || !kvtext_b_ || !knc_)
+        return fail("DiT modulation/KV pack failed: " + err_);
+    if (modall_.N != kModLd) return fail("modulation table width mismatch");
+
+    // grouped conv (dit.py:218-220) -> per-group GEMM weights [G*cpg][K*64] (ic padded 60 -> 64)
+    for (int c = 0; c < 2; ++c) {
+        const RawTensor* w = raw(sidx("dit.input_embed.conv_pos_embed.conv", c + 1, ".weight"));
+        if (!w || w->shape.size() != 3 || w->shape[0] != kHidden || w->shape[1] != kConvCpg || w->shape[2] != kConvK)
+            return fail("conv_pos_embed weight missing or wrong shape");
+        float* tmp = nullptr;
+        const int Kp = kConvK * kConvGs;
+        HIPC(hipMalloc(&tmp, (size_t)kHidden * Kp * 4));
+        GatherSpec g{0, 0, (long)kConvCpg * kConvK, 1, kConvK, kHidden, kConvGs, kConvCpg};
+        HIPC(launch_gather_pack(w->d, tmp, kHidden, Kp, g, 0));
+        (c ? conv2_ : conv1_) = pack_from_f32(tmp, kHidden, Kp);
+        HIPC(hipStreamSynchronize(0));
+        HIPC(hipFree(tmp));
+        if (!(c ? conv2_ : conv1_).N) return fail("conv pack failed");
+    }
+
+    std::vector<int> perm = swiglu_perm(kFF);
+    blocks_.clear();
+    for (int i = 0; i < kBlocks; ++i) {
+        std::string p = sidx(T, i, "");
+        DitBlockW b;
+        b.qkvg = pack_rows({p + ".attn.to_q.weight", p + ".attn.to_k_self.weight", p + ".attn.to_v_self.weight",
+                            p + ".attn.gate.weight"});
+        b.b_qkvg = concat_vec({p + ".attn.to_q.bias", p + ".attn.to_k_self.bias", p + ".attn.to_v_self.bias", ""},
+                              {kHidden});
+        b.out = pack_rows({p + ".attn.to_out.0.weight"});
+        b.ff13 = pack_rows({p + ".ff.w1.weight", p + ".ff.w3.weight"}, &perm);
+        b.ff2 = pack_rows({p + ".ff.w2.weight"});
+        b.b1 = rawp(p + ".ff.w1.bias"); b.b3 = rawp(p + ".ff.w3.bias"); b.b2 = rawp(p + ".ff.w2.bias");
+        b.qn = rawp(p + ".attn.q_norm.weight"); b.kn = rawp(p + ".attn.k_norm.weight");
+        if (!b.qkvg.N || !b.b_qkvg || !b.out.N || !b.ff13.N || !b.ff2.N || !b.b1 || !b.b3 || !b.b2 || !b.qn || !b.kn)
+            return fail("DiT block incomplete: " + p + " (" + err_ + ")");
+        blocks_.push_back(b);
+    }
+    if (build_encoder(style_, "style_encoder", 512, 8, 1536, 12, 1e-5f)) return 1;
+    if (build_encoder(text_, "phoneme_embedding", 512, 4, 1024, 8, 1e-6f)) return 1;
+    float ls = 0.f;
+    if (!raw("style_encoder.log_scale")) return fail("missing style_encoder.log_scale");
+    HIPC(hipMemcpy(&ls, rawp("style_encoder.log_scale"), 4, hipMemcpyDeviceToHost));
+    style_scale_ = expf(ls);
+    rope_dit_ = static_cast<float*>(dalloc((size_t)kMaxPos * 64 * 4));
+    if (!rope_dit_) return fail("rope alloc failed");
+    HIPC(launch_rope_table(rope_dit_, kMaxPos, 64, 0));
+    for (const char* n : {"time_embedding.mlp.0.bias", "time_embedding.mlp.2.bias", "dit.emb_proj.0.bias",
+                          "dit.emb_proj.2.bias", "dit.input_embed.proj.bias", "velocity.bias", "dit.phoneme_proj.bias",
+                          "style_encoder.in_proj.bias", "style_encoder.out_proj.bias",
+                          "dit.input_embed.conv_pos_embed.conv1.bias", "dit.input_embed.conv_pos_embed.conv2.bias",
+                          "phoneme_embedding.text_embedding.weight"})
+        if (!raw(n)) return fail(std::string("missing tensor ") + n);
+    dit_ready_ = true;
+    return 0;
+}
+
+int Engine::finalize_codec(bool decoder) {
+    const CodecSpecC& s = cspec_;
+    CodecHalfW& h = decoder ? dec_ : enc_;
+    const std::string P = decoder ? "codec.decoder" : "codec.encoder";
+    const int S = s.n_ratios + 1, Kc = s.kernel;
+    if (Kc - 1 > kCodecPad) return fail("codec kernel too large for the frame padding");
+    h = CodecHalfW();
+    auto gather_to_pw = [&](const float* src, int N, int K, GatherSpec g, PW& out, float** f32_out) -> int {
+        float* tmp = nullptr;
+        if (f32_out) {
+            tmp = static_cast<float*>(dalloc((size_t)N * K * 4));
+            if (!tmp) return fail("codec pack alloc failed");
+        } else {
+            HIPC(hipMalloc(&tmp, (size_t)N * K * 4));
+        }
+        HIPC(launch_gather_pack(src, tmp, N, K, g, 0));
+        if (f32_out) { *f32_out = tmp; return 0; }
+        out = pack_from_f32(tmp, N, K);
+        HIPC(hipStreamSynchronize(0));
+        HIPC(hipFree(tmp));
+        return out.N ? 0 : fail("codec pack failed");
+    };
+    for (int i = 0; i < S; ++i) {
+        CodecStageW st;
+        const int C = decoder ? s.n_filters << (S - 1 - i) : s.n_filters << i;
+        st.C = C;
+        if (i > 0) {
+            const int r = decoder ? s.ratios[i - 1] : s.ratios[s.n_ratios - i];
+            if (r > kCodecPad) return fail("codec ratio exceeds frame padding");
+            st.r = r;
+            if (decoder) {
+                const int Cin = 2 * C;
+                const RawTensor* w = raw(sidx(P + ".up.", i, ".weight"));
+                if (!w || w->numel != (long)Cin * C * 2 * r) return fail("missing/mis-shaped " + sidx(P + ".up.", i, ".weight"));
+                GatherSpec g{r, 1, 2L * r, -(long)r, (long)C * 2 * r, C, Cin, Cin};
+                if (gather_to_pw(w->d, r * C, 2 * Cin, g, st.resample, nullptr)) return 1;
+                const float* b = rawp(sidx(P + ".up.", i, ".bias"));
+                if (!b) return fail("missing up bias");
+                GatherSpec gb{0, 0, 0, 0, 1, 1, C, C};
+                PW dummy;
+                if (gather_to_pw(b, 1, r * C, gb, dummy, &st.resample_bias)) return 1;
+            } else {
+                const int Cin = C / 2;
+                const RawTensor* w = raw(sidx(P + ".down.", i, ".weight"));
+                if (!w || w->numel != (long)C * Cin * 2 * r) return fail("missing/mis-shaped " + sidx(P + ".down.", i, ".weight"));
+                GatherSpec g{0, 0, (long)Cin * 2 * r, 1, 2L * r, C, Cin, Cin};
+                if (gather_to_pw(w->d, C, 2 * r * Cin, g, st.resample, nullptr)) return 1;
+                st.resample_bias = const_cast<float*>(rawp(sidx(P + ".down.", i, ".bias")));
+                if (!st.resample_bias) return fail("missing down bias");
+            }
+        }
+        const int depth = decoder ? s.depths[i] : s.depths[S - 1 - i];
+        for (int j = 0; j < depth; ++j) {
+            std::string p = P + ".stages." + std::to_string(i) + "." + std::to_string(j);
+            CodecBlockW b;
+            b.norm_w = rawp(p + ".norm.weight"); b.dw_b = rawp(p + ".mixer.bias"); b.gamma = rawp(p + ".gamma");
+            b.ffn_norm_w = rawp(p + ".ffn_norm.weight"); b.b1 = rawp(p + ".ffn.w1.bias");
+            b.b2 = rawp(p + ".ffn.w2.bias"); b.ffn_gamma = rawp(p + ".ffn_gamma");
+            const float* mw = rawp(p + ".mixer.weight");
+            if (!b.norm_w || !b.dw_b || !b.gamma || !b.ffn_norm_w || !b.b1 || !b.b2 || !b.ffn_gamma || !mw)
+                return fail("codec block incomplete: " + p);
+            GatherSpec g{0, 0, 1, 0, Kc, Kc, C, C};
+            PW dummy;
+            if (gather_to_pw(mw, Kc, C, g, dummy, &b.dw_w)) return 1;
+            b.w1 = pack_rows({p + ".ffn.w1.weight"});
+            b.w2 = pack_rows({p + ".ffn.w2.weight"});
+            if (!b.w1.N || !b.w2.N) return fail("codec ffn pack failed: " + p + " " + err_);
+            st.blocks.push_back(b);
+        }
+        h.stages.push_back(st);
+    }
+    const int C0 = h.stages[0].C, Cl = h.stages[S - 1].C;
+    if (decoder) {
+        const RawTensor* w = raw(P + ".stem.weight");
+        if (!w || w->numel != (long)C0 * s.latent_dim * Kc) return fail("missing decoder stem");
+        GatherSpec g{0, 0, (long)s.latent_dim * Kc, 1, Kc, C0, s.latent_dim, s.latent_dim};
+        if (gather_to_pw(w->d, C0, Kc * s.latent_dim, g, h.stem, nullptr)) return 1;
+        h.stem_b = rawp(P + ".stem.bias");
+        const float* hw = rawp(P + ".head.weight");
+        const float* hb = rawp(P + ".head.bias");
+        if (!h.stem_b || !hw || !hb) return fail("missing decoder stem bias / head");
+        GatherSpec gh{0, 0, 1, 0, Kc, Kc, Cl, Cl};
+        PW dummy;
+        if (gather_to_pw(hw, Kc, Cl, gh, dummy, &h.head_w)) return 1;
+        HIPC(hipMemcpy(&h.head_b_host, hb, 4, hipMemcpyDeviceToHost));
+    } else {
+        h.stem_w_raw = rawp(P + ".stem.weight");
+        h.stem_b = rawp(P + ".stem.bias");
+        const RawTensor* w = raw(P + ".head.weight");
+        h.head_b = rawp(P + ".head.bias");
+        if (!h.stem_w_raw || !h.stem_b || !w || !h.head_b) return fail("missing encoder stem/head");
+        GatherSpec g{0, 0, (long)Cl * Kc, 1, Kc, s.latent_dim, Cl, Cl};
+        if (gather_to_pw(w->d, s.latent_dim, Kc * Cl, g, h.head, nullptr)) return 1;
+    }
+    h.ready = true;
+    return 0;
+}
+
+int Engine::finalize() {
+    HIPC(hipSetDevice(device_));
+    if (raw("velocity.weight")) {
+        if (finalize_dit()) return 1;
+    }
+    if (raw("codec.decoder.stem.weight")) {
+        if (finalize_codec(true)) return 1;
+    }
+    if (raw("codec.encoder.stem.weight")) {
+        if (finalize_codec(false)) return 1;
+    }
+    HIPC(hipDeviceSynchronize());
+    finalized_ = true;
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// small helpers to build GEMM calls
+// ---------------------------------------------------------------------------------------------
+static inline GemmOperands ops(const float* A, RowMap amap, const PW& w, int M, int row0 = 0, int nrows = -1) {
+    GemmOperands g;
+    g.A = A;
+    g.amap = amap;
+    g.Whi = w.hi + (long)row0 * w.K;
+    g.Wlo = w.lo + (long)row0 * w.K;
+    g.ldw = w.K;
+    g.M = M;
+    g.N = nrows < 0 ? w.N : nrows;
+    g.K = w.K;
+    g.a_z = 0;
+    g.w_z = 0;
+    g.w_zmod = 0;
+    return g;
+}
+static inline EpiStore<ACT_NONE> store_to(float* out, RowMap omap, const float* bias, float scale = 1.f,
+                                          const uint8_t* rowmask = nullptr) {
+    return EpiStore<ACT_NONE>{out, omap, 0, bias, 0, scale, rowmask};
+}
+
+// ---------------------------------------------------------------------------------------------
+// K10: encoder stack (style.py:70-105 / phonemes.py:131-167), x updated in place
+// ---------------------------------------------------------------------------------------------
+int Engine::run_encoder(hipStream_t st, const EncoderW& e, float* x, float* y, float* qkvg, float* o, float* ffh,
+                        int B, int S, const uint8_t* key_mask) {
+    const int M = B * S, D = e.dim;
+    for (const EncBlockW& b : e.blocks) {
+        HIPC(launch_rmsnorm(x, rowmap_plain(D), y, rowmap_plain(D), M, D, e.eps, b.an, st));
+        HIPC(gemm_store(ops(y, rowmap_plain(D), b.qkvg, M), ACT_NONE, store_to(qkvg, rowmap_plain(4 * D), nullptr), 1,
+                        split_, st));
+        AttnArgs a{};
+        a.q = qkvg; a.k = qkvg + D; a.v = qkvg + 2 * D; a.gate = qkvg + 3 * D;
+        a.bs = (long)S * 4 * D; a.rs = 4 * D;
+        a.qw = b.qn; a.kw = b.kn; a.eps = e.eps;
+        a.rope = e.rope; a.rot_dim = e.dh;
+        a.mask_self = key_mask;
+        a.out = o; a.obs = (long)S * D; a.ors = D;
+        a.B = B; a.N = S; a.H = e.heads; a.dh = e.dh;
+        HIPC(launch_attention(a, st));
+        EpiResid<0> r1{x, rowmap_plain(D), nullptr, nullptr, 0, 0, 0, 1, nullptr};
+        HIPC(gemm_resid(ops(o, rowmap_plain(D), b.wo, M), 0, r1, split_, st));
+        HIPC(launch_rmsnorm(x, rowmap_plain(D), y, rowmap_plain(D), M, D, e.eps, b.mn, st));
+        EpiSwiGLU sw{ffh, e.ff, nullptr, nullptr};
+        HIPC(gemm_swiglu(ops(y, rowmap_plain(D), b.ff13, M), sw, split_, st));
+        HIPC(gemm_resid(ops(ffh, rowmap_plain(e.ff), b.w2, M), 0, r1, split_, st));
+    }
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// E0: condition encoder (model.py:88-95)
+// ---------------------------------------------------------------------------------------------
+namespace {
+struct CondWs {
+    float *x, *y, *qkvg, *o, *ffh, *seq;
+    size_t plan(Bump& b, int Mx) {
+        x = b.take<float>((size_t)Mx * 512);
+        y = b.take<float>((size_t)Mx * 512);
+        qkvg = b.take<float>((size_t)Mx * 2048);
+        o = b.take<float>((size_t)Mx * 512);
+        ffh = b.take<float>((size_t)Mx * 1536);
+        seq = b.take<float>((size_t)Mx * kHidden);
+        return b.off;
+    }
+};
+}  // namespace
+
+size_t Engine::cond_ws_bytes(int B, int R, int P) const {
+    Bump b(nullptr);
+    CondWs w;
+    int Mx = B * (R > P ? R : P);
+    return w.plan(b, Mx > 0 ? Mx : 1) + 256;
+}
+
+int Engine::cond_encode(hipStream_t st, const float* ref, const int64_t* ref_len, const int64_t* ids,
+                        const uint8_t* ph_mask, int B, int R, int P, float* k_ref, float* v_ref, uint8_t* ref_mask,
+                        float* k_text, float* v_text, void* ws, size_t ws_bytes, float* ref_seq_out, float* mem_out) {
+    if (!dit_ready_) return fail("cond_encode: DiT weights not finalized");
+    if (R > kMaxPos || P > kMaxPos) return fail("cond_encode: sequence longer than the rope table (4096)");
+    if (ws_bytes < cond_ws_bytes(B, R, P)) return fail("cond_encode: workspace too small");
+    HIPC(hipSetDevice(device_));
+    Bump bump(ws);
+    CondWs w;
+    w.plan(bump, B * (R > P ? R : P) > 0 ? B * (R > P ? R : P) : 1);
+
+    // ---- E1 style encoder (style.py:144-174) -------------------------------------------------
+    if (R > 0) {
+        const int M = B * R;
+        HIPC(launch_len_mask(ref_len, ref_mask, B, R, st));
+        HIPC(gemm_store(ops(ref, rowmap_plain(kLatent), style_in_, M), ACT_NONE,
+                        store_to(w.x, rowmap_plain(512), rawp("style_encoder.in_proj.bias"), style_scale_), 1, split_, st));
+        if (run_encoder(st, style_, w.x, w.y, w.qkvg, w.o, w.ffh, B, R, ref_mask)) return 1;
+        HIPC(launch_rmsnorm(w.x, rowmap_plain(512), w.y, rowmap_plain(512), M, 512, style_.eps, style_.final_norm, st));
+        float* seq = ref_seq_out ? ref_seq_out : w.seq;
+        HIPC(gemm_store(ops(w.y, rowmap_plain(512), style_out_, M), ACT_NONE,
+                        store_to(seq, rowmap_plain(kHidden), rawp("style_encoder.out_proj.bias"), 1.f, ref_mask), 1,
+                        split_, st));
+        // ---- E3 cross KV for the reference tokens (dit.py:80-93) -------------------------------
+        EpiKV kv{k_ref, v_ref, kvref_b_, B, kHeads, kDh, R};
+        HIPC(gemm_kv(ops(seq, rowmap_plain(kHidden), kvref_, M), kv, split_, st));
+        HIPC(launch_headnorm(k_ref, kBlocks, B, kHeads, R, kDh, 1e-6f, knc_, st));
+    }
+    // ---- E2 text encoder (phonemes.py:200-207) + phoneme_proj (dit.py:293-298) ---------------
+    if (P > 0) {
+        const int M = B * P;
+        HIPC(launch_embedding(ids, rawp("phoneme_embedding.text_embedding.weight"), w.x, M, 512, 198, st));
+        if (run_encoder(st, text_, w.x, w.y, w.qkvg, w.o, w.ffh, B, P, ph_mask)) return 1;
+        HIPC(launch_rmsnorm(w.x, rowmap_plain(512), w.y, rowmap_plain(512), M, 512, text_.eps, text_.final_norm, st));
+        float* mem = mem_out ? mem_out : w.seq;
+        HIPC(gemm_store(ops(w.y, rowmap_plain(512), phproj_, M), ACT_NONE,
+                        store_to(mem, rowmap_plain(kHidden), rawp("dit.phoneme_proj.bias"), 1.f, ph_mask), 1, split_, st));
+        EpiKV kv{k_text, v_text, kvtext_b_, B, kHeads, kDh, P};
+        HIPC(gemm_kv(ops(mem, rowmap_plain(kHidden), kvtext_, M), kv, split_, st));
+        HIPC(launch_headnorm(k_text, kBlocks, B, kHeads, P, kDh, 1e-6f, knc_, st));
+    }
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// D1/D3/D5/D8 modulation table: all AdaLN vectors for `rows` distinct timesteps in one pass
+//   mod[r] = [ blk0: shift_msa scale_msa gate_msa shift_mlp scale_mlp gate_mlp | ... | final: scale shift ]
+// ---------------------------------------------------------------------------------------------
+int Engine::modulation(hipStream_t st, const float* t_dev, int rows, float* sinb, float* t1, float* temb, float* e1,
+                       float* semb, float* mod) {
+    HIPC(launch_time_sinusoid(t_dev, sinb, rows, st));
+    HIPC(gemm_store(ops(sinb, rowmap_plain(256), time0_, rows), ACT_SILU,
+                    store_to(t1, rowmap_plain(kHidden), rawp("time_embedding.mlp.0.bias")), 1, split_, st));
+    HIPC(gemm_store(ops(t1, rowmap_plain(kHidden), time2_, rows), ACT_NONE,
+                    store_to(temb, rowmap_plain(kHidden), rawp("time_embedding.mlp.2.bias")), 1, split_, st));
+    HIPC(gemm_store(ops(temb, rowmap_plain(kHidden), emb0_, rows), ACT_SILU,
+                    store_to(e1, rowmap_plain(2 * kHidden), rawp("dit.emb_proj.0.bias")), 1, split_, st));
+    // AdaLN consumes silu(emb) only (dit.py:20,36), so the SiLU is fused into this epilogue
+    HIPC(gemm_store(ops(e1, rowmap_plain(2 * kHidden), emb2_, rows), ACT_SILU,
+                    store_to(semb, rowmap_plain(kHidden), rawp("dit.emb_proj.2.bias")), 1, split_, st));
+    HIPC(gemm_store(ops(semb, rowmap_plain(kHidden), modall_, rows), ACT_NONE,
+                    store_to(mod, rowmap_plain(kModLd), modall_b_), 1, split_, st));
+    return 0;
+}
+
+namespace {
+struct ModWs {
+    float *sinb, *t1, *temb, *e1, *semb, *mod;
+    void plan(Bump& b, int rows) {
+        sinb = b.take<float>((size_t)rows * 256);
+        t1 = b.take<float>((size_t)rows * kHidden);
+        temb = b.take<float>((size_t)rows * kHidden);
+        e1 = b.take<float>((size_t)rows * 2 * kHidden);
+        semb = b.take<float>((size_t)rows * kHidden);
+        mod = b.take<float>((size_t)rows * kModLd);
+    }
+};
+struct CoreWs {
+    float *h, *gm1, *gm2, *x, *y, *qkvg, *o, *ffh;
+    size_t gm_elems;
+    void plan(Bump& b, int B, int N) {
+        const size_t M = (size_t)B * N;
+        gm_elems = (size_t)B * kConvG * (N + 2 * kConvPad) * kConvGs;
+        h = b.take<float>(M * kHidden);
+        gm1 = b.take<float>(gm_elems);
+        gm2 = b.take<float>(gm_elems);
+        x = b.take<float>(M * kHidden);
+        y = b.take<float>(M * kHidden);
+        qkvg = b.take<float>(M * 4 * kHidden);
+        o = b.take<float>(M * kHidden);
+        ffh = b.take<float>(M * kFF);
+    }
+};
+}  // namespace
+
+size_t Engine::denoise_core_bytes(int B, int N) const {
+    Bump b(nullptr);
+    CoreWs w;
+    w.plan(b, B, N);
+    return b.off + 256;
+}
+
+// ---------------------------------------------------------------------------------------------
+// D0: one denoiser evaluation given a ready modulation table (model.py:97-100, dit.py:316-327)
+// ---------------------------------------------------------------------------------------------
+int Engine::denoise_core(hipStream_t st, const float* x_t, const uint8_t* mask, const float* mod, int mod_row0,
+                         int mod_rstride, const float* k_ref, const float* v_ref, const uint8_t* ref_mask,
+                         const float* k_text, const float* v_text, const uint8_t* ph_mask, const float* rope, int B,
+                         int N, int R, int P, float* velocity, char* wsp) {
+    Bump bump(wsp);
+    CoreWs w;
+    w.plan(bump, B, N);
+    const int M = B * N;
+    const RowMap rh = rowmap_plain(kHidden);
+    // D2 input embedding (dit.py:246-253): h = proj(x); x = mask*mish(conv2(mask*mish(conv1(mask*h)))) + h
+    HIPC(gemm_store(ops(x_t, rowmap_plain(kLatent), inproj_, M), ACT_NONE,
+                    store_to(w.h, rh, rawp("dit.input_embed.proj.bias")), 1, split_, st));
+    HIPC(launch_convpos_pack(w.h, mask, w.gm1, B, N, kConvG, kConvCpg, kConvPad, kConvGs, st));
+    HIPC(hipMemsetAsync(w.gm2, 0, w.gm_elems * 4, st));
+    {
+        // grouped conv k=31 as B*G small GEMMs: z = b*G + g, rows = frames, K = 31 taps x 64 (padded) channels
+        const long zs = (long)(N + 2 * kConvPad) * kConvGs;
+        GemmOperands g = ops(w.gm1, rowmap_plain(kConvGs), conv1_, N, 0, kConvCpg);
+        g.a_z = zs;
+        g.w_z = (long)kConvCpg * conv1_.K;
+        g.w_zmod = kConvG;
+        EpiConvPos<0> e1{w.gm2, nullptr, rawp("dit.input_embed.conv_pos_embed.conv1.bias"), mask, kConvG, kConvCpg, N,
+                         kConvPad, kConvGs};
+        HIPC(gemm_convpos(g, false, e1, B * kConvG, split_, st));
+        g = ops(w.gm2, rowmap_plain(kConvGs), conv2_, N, 0, kConvCpg);
+        g.a_z = zs;
+        g.w_z = (long)kConvCpg * conv2_.K;
+        g.w_zmod = kConvG;
+        EpiConvPos<0> e2{w.x, w.h, rawp("dit.input_embed.conv_pos_embed.conv2.bias"), mask, kConvG, kConvCpg, N,
+                         kConvPad, kConvGs};
+        HIPC(gemm_convpos(g, true, e2, B * kConvG, split_, st));
+    }
+    const float* rp = rope ? rope : rope_dit_;
+    for (int l = 0; l < kBlocks; ++l) {
+        const DitBlockW& b = blocks_[l];
+        const float* m = mod + (long)l * kModPerBlock;
+        // D5 AdaLN-Zero (dit.py:19-25)
+        HIPC(launch_ln_modulate(w.x, w.y, M, kHidden, 1e-6f, m + 0 * kHidden, m + 1 * kHidden, kModLd, mod_row0,
+                                mod_rstride, N, st));
+        // D6 joint attention (dit.py:95-135)
+        HIPC(gemm_store(ops(w.y, rh, b.qkvg, M), ACT_NONE, store_to(w.qkvg, rowmap_plain(4 * kHidden), b.b_qkvg), 1,
+                        split_, st));
+        AttnArgs a{};
+        a.q = w.qkvg; a.k = w.qkvg + kHidden; a.v = w.qkvg + 2 * kHidden; a.gate = w.qkvg + 3 * kHidden;
+        a.bs = (long)N * 4 * kHidden; a.rs = 4 * kHidden;
+        a.qw = b.qn; a.kw = b.kn; a.eps = 1e-6f;
+        a.rope = rp; a.rot_dim = 64;
+        const long lr = (long)l * B * kHeads * R * kDh, lp = (long)l * B * kHeads * P * kDh;
+        a.k_ref = R > 0 ? k_ref + lr : nullptr; a.v_ref = R > 0 ? v_ref + lr : nullptr; a.R = R;
+        a.k_text = P > 0 ? k_text + lp : nullptr; a.v_text = P > 0 ? v_text + lp : nullptr; a.P = P;
+        a.mask_self = mask; a.mask_ref = ref_mask; a.mask_text = ph_mask;
+        a.out = w.o; a.obs = (long)N * kHidden; a.ors = kHidden;
+        a.B = B; a.N = N; a.H = kHeads; a.dh = kDh;
+        HIPC(launch_attention(a, st));
+        // to_out + mask + gated residual (dit.py:117-118,198)
+        EpiResid<0> r1{w.x, rh, nullptr, m + 2 * kHidden, kModLd, mod_row0, mod_rstride, N, mask};
+        HIPC(gemm_resid(ops(w.o, rh, b.out, M), 1, r1, split_, st));
+        // D7 feed-forward (dit.py:199-201)
+        HIPC(launch_ln_modulate(w.x, w.y, M, kHidden, 1e-6f, m + 3 * kHidden, m + 4 * kHidden, kModLd, mod_row0,
+                                mod_rstride, N, st));
+        EpiSwiGLU sw{w.ffh, kFF, b.b1, b.b3};
+        HIPC(gemm_swiglu(ops(w.y, rh, b.ff13, M), sw, split_, st));
+        EpiResid<0> r2{w.x, rh, b.b2, m + 5 * kHidden, kModLd, mod_row0, mod_rstride, N, nullptr};
+        HIPC(gemm_resid(ops(w.ffh, rowmap_plain(kFF), b.ff2, M), 1, r2, split_, st));
+    }
+    // D8 final AdaLN (chunk order scale, shift: dit.py:37) + velocity head (model.py:100)
+    const float* mf = mod + (long)kBlocks * kModPerBlock;
+    HIPC(launch_ln_modulate(w.x, w.y, M, kHidden, 1e-6f, mf + kHidden, mf, kModLd, mod_row0, mod_rstride, N, st));
+    HIPC(gemm_store(ops(w.y, rh, velocity_, M), ACT_NONE, store_to(velocity, rowmap_plain(kLatent), rawp("velocity.bias")),
+                    1, split_, st));
+    return 0;
+}
+
+size_t Engine::denoise_ws_bytes(int B, int N, int rows) const {
+    Bump b(nullptr);
+    ModWs m;
+    m.plan(b, rows);
+    return b.off + 256 + denoise_core_bytes(B, N);
+}
+
+int Engine::denoise_step(hipStream_t st, const float* x_t, const uint8_t* mask, const float* t, const float* k_ref,
+                         const float* v_ref, const uint8_t* ref_mask, const float* k_text, const float* v_text,
+                         const uint8_t* ph_mask, const float* rope, int B, int N, int R, int P, float* velocity,
+                         void* ws, size_t ws_bytes) {
+    if (!dit_ready_) return fail("denoise_step: DiT weights not finalized");
+    if (N > kMaxPos) return fail("denoise_step: sequence longer than the rope table (4096)");
+    if (ws_bytes < denoise_ws_bytes(B, N, B)) return fail("denoise_step: workspace too small");
+    HIPC(hipSetDevice(device_));
+    Bump bump(ws);
+    ModWs m;
+    m.plan(bump, B);
+    if (modulation(st, t, B, m.sinb, m.t1, m.temb, m.e1, m.semb, m.mod)) return 1;
+    char* core = static_cast<char*>(ws) + ((bump.off + 255) & ~size_t(255));
+    return denoise_core(st, x_t, mask, m.mod, 0, 1, k_ref, v_ref, ref_mask, k_text, v_text, ph_mask, rope, B, N, R, P,
+                        velocity, core);
+}
+
+// ---------------------------------------------------------------------------------------------
+// S1 / S2 samplers
+// ---------------------------------------------------------------------------------------------
+void alpha_sigma_host(float t, float& a, float& s) {
+    // reference infer/onnx.py:31-39 : float64 math on the float32 t, cast to float32 at the end
+    double td = (double)t;
+    const double eps = 1e-5;
+    td = td < eps ? eps : (td > 1.0 - eps ? 1.0 - eps : td);
+    double c = std::cos(M_PI / 2.0 * td);
+    double a2 = c * c;
+    double lsnr = std::log(a2 / (1.0 - a2)) + 2.0 * std::log(0.5);
+    double asq = 1.0 / (1.0 + std::exp(-lsnr));
+    a = (float)std::sqrt(asq);
+    s = (float)std::sqrt(1.0 - asq);
+}
+static float linspace10(int i, int n) {
+    // np.linspace(1, 0, n, dtype=float32): float64 arithmetic, endpoint exact, cast to float32
+    if (n <= 1) return 1.0f;
+    if (i == n - 1) return 0.0f;
+    double step = -1.0 / (double)(n - 1);
+    return (float)(1.0 + step * (double)i);
+}
+
+namespace {
+struct SampleWs {
+    float *ts, *xt, *v, *x, *nz, *xt3, *v3;
+    void plan(Bump& b, int B, int N, int n_steps, int cfg) {
+        const size_t e = (size_t)B * N * kLatent;
+        ts = b.take<float>(n_steps);
+        xt = b.take<float>(e);
+        v = b.take<float>(e);
+        x = b.take<float>(e);
+        nz = b.take<float>(e);
+        xt3 = b.take<float>(cfg ? 3 * e : 1);
+        v3 = b.take<float>(cfg ? 3 * e : 1);
+    }
+};
+}  // namespace
+
+size_t Engine::sample_ws_bytes(int B, int N, int n_steps, int cfg) const {
+    Bump b(nullptr);
+    SampleWs s;
+    s.plan(b, B, N, n_steps, cfg);
+    ModWs m;
+    m.plan(b, n_steps);
+    return b.off + 256 + denoise_core_bytes(cfg ? 3 * B : B, N);
+}
+
+int Engine::sample(hipStream_t st, int mode, int n_steps, int cfg, float s_text, float s_spk, const uint8_t* mask,
+                   const float* k_ref, const float* v_ref, const uint8_t* ref_mask, const float* k_text,
+                   const float* v_text, const uint8_t* ph_mask, int B, int N, int R, int P, const float* noise,
+                   uint64_t seed, float* x_out, float* steps_out, void* ws, size_t ws_bytes) {
+    if (!dit_ready_) return fail("sample: DiT weights not finalized");
+    if (n_steps < 1) return fail("sample: n_steps must be >= 1");
+    if (N > kMaxPos) return fail("sample: sequence longer than the rope table (4096)");
+    if (ws_bytes < sample_ws_bytes(B, N, n_steps, cfg)) return fail("sample: workspace too small");
+    HIPC(hipSetDevice(device_));
+    Bump bump(ws);
+    SampleWs s;
+    s.plan(bump, B, N, n_steps, cfg);
+    ModWs m;
+    m.plan(bump, n_steps);
+    char* core = static_cast<char*>(ws) + ((bump.off + 255) & ~size_t(255));
+    const long e = (long)B * N * kLatent;
+
+    std::vector<float> ts(n_steps), al(n_steps), sg(n_steps);
+    for (int i = 0; i < n_steps; ++i) {
+        ts[i] = linspace10(i, n_steps);
+        alpha_sigma_host(ts[i], al[i], sg[i]);
+    }
+    HIPC(hipMemcpyAsync(s.ts, ts.data(), n_steps * sizeof(float), hipMemcpyHostToDevice, st));
+    HIPC(hipStreamSynchronize(st));  // ts lives on the host stack
+    // t is shared by the whole batch -> every AdaLN vector of every step in one pass (SURVEY §7 hard part 3)
+    if (modulation(st, s.ts, n_steps, m.sinb, m.t1, m.temb, m.e1, m.semb, m.mod)) return 1;
+
+    const int Bd = cfg ? 3 * B : B;
+    // mask for 3B rows when cfg: caller passes mask with B rows; replicate by pointer arithmetic is impossible,
+    // so the cfg path expects `mask` to already hold 3B rows (documented in the header).
+    auto eval_velocity = [&](int step) -> int {
+        if (!cfg)
+            return denoise_core(st, s.xt, mask, m.mod, step, 0, k_ref, v_ref, ref_mask, k_text, v_text, ph_mask, nullptr,
+                                B, N, R, P, s.v, core);
+        for (int r = 0; r < 3; ++r)
+            HIPC(hipMemcpyAsync(s.xt3 + r * e, s.xt, e * sizeof(float), hipMemcpyDeviceToDevice, st));
+        if (denoise_core(st, s.xt3, mask, m.mod, step, 0, k_ref, v_ref, ref_mask, k_text, v_text, ph_mask, nullptr, Bd,
+                         N, R, P, s.v3, core))
+            return 1;
+        HIPC(launch_cfg_combine(s.v3, s.v, s_text, s_spk, e, st));
+        return 0;
+    };
+
+    if (mode == 0) {
+        HIPC(hipMemsetAsync(s.x, 0, e * sizeof(float), st));
+        for (int i = 0; i < n_steps; ++i) {
+            const float* nz = noise ? noise + (long)i * e : s.nz;
+            if (!noise) HIPC(launch_randn(s.nz, e, seed, (uint64_t)i, st));
+            HIPC(launch_axpby(s.xt, s.x, nz, al[i], sg[i], e, st));       // x_t = a x + s eps
+            if (eval_velocity(i)) return 1;
+            HIPC(launch_axpby(s.x, s.xt, s.v, al[i], -sg[i], e, st));     // x = a x_t - s v
+            if (steps_out) HIPC(hipMemcpyAsync(steps_out + (long)i * e, s.x, e * sizeof(float), hipMemcpyDeviceToDevice, st));
+        }
+    } else {
+        const float* nz = noise ? noise : s.nz;
+        if (!noise) HIPC(launch_randn(s.nz, e, seed, 0, st));
+        HIPC(hipMemsetAsync(s.x, 0, e * sizeof(float), st));
+        HIPC(launch_axpby(s.xt, s.x, nz, 0.f, sg[0], e, st));             // x_1 = sigma(1) eps
+        for (int i = 0; i < n_steps; ++i) {
+            if (eval_velocity(i)) return 1;
+            const bool last = i + 1 == n_steps;
+            HIPC(launch_ode_step(s.xt, s.v, s.x, al[i], sg[i], last ? al[i] : al[i + 1], last ? sg[i] : sg[i + 1], e, st));
+            if (steps_out) HIPC(hipMemcpyAsync(steps_out + (long)i * e, s.x, e * sizeof(float), hipMemcpyDeviceToDevice, st));
+        }
+    }
+    HIPC(hipMemcpyAsync(x_out, s.x, e * sizeof(float), hipMemcpyDeviceToDevice, st));
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Codec (V1 decode / V0 encode).  Channels-last images [B][kCodecPad + T][C]; the zero pad frames in
+// front of each batch item implement the causal left padding of every conv, so strided / transposed /
+// k-tap convs all become plain GEMMs over overlapping rows.
+// ---------------------------------------------------------------------------------------------
+int Engine::codec_block(hipStream_t st, const CodecBlockW& w, float* x, float* nbuf, float* hidden, int B, int T,
+                        int C) {
+    const int M = B * T, pad = kCodecPad;
+    const RowMap img = rowmap_batched(C, T, (long)(pad + T) * C, (long)pad * C);
+    HIPC(launch_rmsnorm(x, img, nbuf, img, M, C, cspec_.eps, w.norm_w, st));
+    HIPC(launch_dwconv_resid(x, nbuf, w.dw_w, w.dw_b, w.gamma, B, T, C, cspec_.kernel, pad, st));
+    HIPC(launch_rmsnorm(x, img, nbuf, img, M, C, cspec_.eps, w.ffn_norm_w, st));
+    const int F = cspec_.ffn_mult * C;
+    HIPC(gemm_store(ops(nbuf, img, w.w1, M), ACT_GELU, store_to(hidden, rowmap_plain(F), w.b1), 1, split_, st));
+    EpiResid<0> r{x, img, w.b2, w.ffn_gamma, 0, 0, 0, 1, nullptr};
+    HIPC(gemm_resid(ops(hidden, rowmap_plain(F), w.w2, M), 2, r, split_, st));
+    return 0;
+}
+
+namespace {
+struct CodecWs {
+    float *xa, *xb, *nb, *hid, *lat;
+    void plan(Bump& b, size_t max_img, size_t max_hidden, size_t lat_elems) {
+        xa = b.take<float>(max_img);
+        xb = b.take<float>(max_img);
+        nb = b.take<float>(max_img);
+        hid = b.take<float>(max_hidden);
+        lat = b.take<float>(lat_elems);
+    }
+};
+}  // namespace
+
+size_t Engine::decode_ws_bytes(int B, int T) const {
+    const CodecSpecC& s = cspec_;
+    const int S = s.n_ratios + 1;
+    size_t max_img = 0, max_hid = 0;
+    long Ti = T;
+    for (int i = 0; i < S; ++i) {
+        if (i > 0) Ti *= s.ratios[i - 1];
+        size_t C = (size_t)s.n_filters << (S - 1 - i);
+        size_t img = (size_t)B * (kCodecPad + Ti) * C;
+        max_img = img > max_img ? img : max_img;
+        size_t hid = (size_t)B * Ti * C * s.ffn_mult;
+        max_hid = hid > max_hid ? hid : max_hid;
+    }
+    Bump b(nullptr);
+    CodecWs w;
+    w.plan(b, max_img, max_hid, (size_t)B * (kCodecPad + T) * s.latent_dim);
+    return b.off + 256;
+}
+
+int Engine::codec_decode(hipStream_t st, const float* latents, int B, int T, float* audio, void* ws, size_t ws_bytes) {
+    if (!dec_.ready) return fail("codec_decode: decoder weights not finalized");
+    if (ws_bytes < decode_ws_bytes(B, T)) return fail("codec_decode: workspace too small");
+    HIPC(hipSetDevice(device_));
+    const CodecSpecC& s = cspec_;
+    const int S = s.n_ratios + 1, pad = kCodecPad, Kc = s.kernel, L = s.latent_dim;
+    // re-derive the plan
+    size_t max_img = 0, max_hid = 0;
+    {
+        long Ti = T;
+        for (int i = 0; i < S; ++i) {
+            if (i > 0) Ti *= s.ratios[i - 1];
+            size_t C = (size_t)s.n_filters << (S - 1 - i);
+            size_t img = (size_t)B * (pad + Ti) * C;
+            max_img = img > max_img ? img : max_img;
+            size_t hid = (size_t)B * Ti * C * s.ffn_mult;
+            max_hid = hid > max_hid ? hid : max_hid;
+        }
+    }
+    Bump bump(ws);
+    CodecWs w;
+    w.plan(bump, max_img, max_hid, (size_t)B * (pad + T) * L);
+
+    // latent image with causal zero pad, then stem conv k (as GEMM over K*latent contiguous floats)
+    HIPC(launch_zero_pad_frames(w.lat, B, T, L, pad, st));
+    HIPC(hipMemcpy2DAsync(w.lat + (long)pad * L, (size_t)(pad + T) * L * 4, latents, (size_t)T * L * 4, (size_t)T * L * 4, B,
+                          hipMemcpyDeviceToDevice, st));
+    float* x = w.xa;
+    float* xn = w.xb;
+    int Ti = T;
+    int C = dec_.stages[0].C;
+    HIPC(launch_zero_pad_frames(x, B, Ti, C, pad, st));
+    HIPC(launch_zero_pad_frames(w.nb, B, Ti, C, pad, st));
+    {
+        RowMap am = rowmap_batched(L, Ti, (long)(pad + Ti) * L, (long)(pad - (Kc - 1)) * L);
+        RowMap om = rowmap_batched(C, Ti, (long)(pad + Ti) * C, (long)pad * C);
+        HIPC(gemm_store(ops(w.lat, am, dec_.stem, B * Ti), ACT_NONE, store_to(x, om, dec_.stem_b), 1, split_, st));
+    }
+    for (int i = 0; i < S; ++i) {
+        const CodecStageW& sg = dec_.stages[i];
+        if (i > 0) {
+            // ConvTranspose1d(k = 2r, stride r), causal trim: rows (x[t-1], x[t]) -> r output frames
+            const int r = sg.r, Cn = sg.C, Tn = Ti * r;
+            HIPC(launch_zero_pad_frames(xn, B, Tn, Cn, pad, st));
+            HIPC(launch_zero_pad_frames(w.nb, B, Tn, Cn, pad, st));
+            RowMap am = rowmap_batched(C, Ti, (long)(pad + Ti) * C, (long)(pad - 1) * C);
+            RowMap om = rowmap_batched((long)r * Cn, Ti, (long)(pad + Tn) * Cn, (long)pad * Cn);
+            HIPC(gemm_store(ops(x, am, sg.resample, B * Ti), ACT_NONE, store_to(xn, om, sg.resample_bias), 1, split_, st));
+            float* t = x; x = xn; xn = t;
+            Ti = Tn;
+            C = Cn;
+        }
+        for (const CodecBlockW& b : sg.blocks)
+            if (codec_block(st, b, x, w.nb, w.hid, B, Ti, C)) return 1;
+    }
+    HIPC(launch_head_conv(x, dec_.head_w, dec_.head_b_host, audio, B, Ti, C, Kc, pad, st));
+    return 0;
+}
+
+size_t Engine::encode_ws_bytes(int B, int S_) const {
+    const CodecSpecC& s = cspec_;
+    const int S = s.n_ratios + 1;
+    size_t max_img = 0, max_hid = 0;
+    long Ti = S_;
+    for (int i = 0; i < S; ++i) {
+        if (i > 0) Ti /= s.ratios[s.n_ratios - i];
+        size_t C = (size_t)s.n_filters << i;
+        size_t img = (size_t)B * (kCodecPad + Ti) * C;
+        max_img = img > max_img ? img : max_img;
+        size_t hid = (size_t)B * Ti * C * s.ffn_mult;
+        max_hid = hid > max_hid ? hid : max_hid;
+    }
+    Bump b(nullptr);
+    CodecWs w;
+    w.plan(b, max_img, max_hid, 1);
+    return b.off + 256;
+}
+
+int Engine::codec_encode(hipStream_t st, const float* audio, int B, int S_, float* latents, void* ws, size_t ws_bytes) {
+    if (!enc_.ready) return fail("codec_encode: encoder weights not finalized");
+    if (ws_bytes < encode_ws_bytes(B, S_)) return fail("codec_encode: workspace too small");
+    HIPC(hipSetDevice(device_));
+    const CodecSpecC& s = cspec_;
+    const int S = s.n_ratios + 1, pad = kCodecPad, Kc = s.kernel;
+    size_t max_img = 0, max_hid = 0;
+    {
+        long Ti = S_;
+        for (int i = 0; i < S; ++i) {
+            if (i > 0) Ti /= s.ratios[s.n_ratios - i];
+            size_t C = (size_t)s.n_filters << i;
+            size_t img = (size_t)B * (pad + Ti) * C;
+            max_img = img > max_img ? img : max_img;
+            size_t hid = (size_t)B * Ti * C * s.ffn_mult;
+            max_hid = hid > max_hid ? hid : max_hid;
+        }
+    }
+    Bump bump(ws);
+    CodecWs w;
+    w.plan(bump, max_img, max_hid, 1);
+    float* x = w.xa;
+    float* xn = w.xb;
+    int Ti = S_;
+    int C = enc_.stages[0].C;
+    HIPC(launch_zero_pad_frames(x, B, Ti, C, pad, st));
+    HIPC(launch_zero_pad_frames(w.nb, B, Ti, C, pad, st));
+    HIPC(launch_stem_conv1(audio, enc_.stem_w_raw, enc_.stem_b, x, B, Ti, C, Kc, pad, st));
+    for (int i = 0; i < S; ++i) {
+        const CodecStageW& sg = enc_.stages[i];
+        if (i > 0) {
+            // Conv1d(k = 2r, stride r), causal left pad r: out[t] reads frames [(t-1) r, (t+1) r)
+            const int r = sg.r, Cn = sg.C, Tn = Ti / r;
+            HIPC(launch_zero_pad_frames(xn, B, Tn, Cn, pad, st));
+            HIPC(launch_zero_pad_frames(w.nb, B, Tn, Cn, pad, st));
+            RowMap am = rowmap_batched((long)r * C, Tn, (long)(pad + Ti) * C, (long)(pad - r) * C);
+            RowMap om = rowmap_batched(Cn, Tn, (long)(pad + Tn) * Cn, (long)pad * Cn);
+            HIPC(gemm_store(ops(x, am, sg.resample, B * Tn), ACT_NONE, store_to(xn, om, sg.resample_bias), 1, split_, st));
+            float* t = x; x = xn; xn = t;
+            Ti = Tn;
+            C = Cn;
+        }
+        for (const CodecBlockW& b : sg.blocks)
+            if (codec_block(st, b, x, w.nb, w.hid, B, Ti, C)) return 1;
+    }
+    RowMap am = rowmap_batched(C, Ti, (long)(pad + Ti) * C, (long)(pad - (Kc - 1)) * C);
+    HIPC(gemm_store(ops(x, am, enc_.head, B * Ti), ACT_NONE, store_to(latents, rowmap_plain(s.latent_dim), enc_.head_b), 1,
+                    split_, st));
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// test hooks
+// ---------------------------------------------------------------------------------------------
+int Engine::test_gemm(hipStream_t st, const float* A, int lda, const float* W, const float* bias, int M, int N, int K,
+                      int act, int split, int cfg, float* C, int ldc) {
+    HIPC(hipSetDevice(device_));
+    bf16_t *hi = nullptr, *lo = nullptr;
+    HIPC(hipMalloc(&hi, (size_t)N * K * 2));
+    HIPC(hipMalloc(&lo, (size_t)N * K * 2));
+    HIPC(launch_split_rows(W, K, hi, lo, K, N, K, nullptr, st));
+    PW w;
+    w.hi = hi; w.lo = lo; w.N = N; w.K = K;
+    hipError_t e = gemm_store(ops(A, rowmap_plain(lda), w, M), act, store_to(C, rowmap_plain(ldc), bias), 1, split, st, cfg);
+    (void)hipStreamSynchronize(st);
+    (void)hipFree(hi);
+    (void)hipFree(lo);
+    return e == hipSuccess ? 0 : fail_hip(e, "test_gemm");
+}
+
+int Engine::test_swiglu(hipStream_t st, const float* A, const float* W1, const float* W3, const float* b1,
+                        const float* b3, int M, int F, int K, int split, float* out) {
+    HIPC(hipSetDevice(device_));
+    if (F % 32) return fail("test_swiglu: F must be a multiple of 32");
+    float* cat = nullptr;
+    int* dperm = nullptr;
+    bf16_t *hi = nullptr, *lo = nullptr;
+    std::vector<int> perm = swiglu_perm(F);
+    HIPC(hipMalloc(&cat, (size_t)2 * F * K * 4));
+    HIPC(hipMalloc(&dperm, perm.size() * sizeof(int)));
+    HIPC(hipMalloc(&hi, (size_t)2 * F * K * 2));
+    HIPC(hipMalloc(&lo, (size_t)2 * F * K * 2));
+    HIPC(hipMemcpyAsync(cat, W1, (size_t)F * K * 4, hipMemcpyDeviceToDevice, st));
+    HIPC(hipMemcpyAsync(cat + (size_t)F * K, W3, (size_t)F * K * 4, hipMemcpyDeviceToDevice, st));
+    HIPC(hipMemcpyAsync(dperm, perm.data(), perm.size() * sizeof(int), hipMemcpyHostToDevice, st));
+    HIPC(launch_split_rows(cat, K, hi, lo, K, 2 * F, K, dperm, st));
+    PW w;
+    w.hi = hi; w.lo = lo; w.N = 2 * F; w.K = K;
+    EpiSwiGLU sw{out, F, b1, b3};
+    hipError_t e = gemm_swiglu(ops(A, rowmap_plain(K), w, M), sw, split, st);
+    (void)hipStreamSynchronize(st);
+    (void)hipFree(cat); (void)hipFree(dperm); (void)hipFree(hi); (void)hipFree(lo);
+    return e == hipSuccess ? 0 : fail_hip(e, "test_swiglu");
+}

@@ -1,0 +1,178 @@
+// smalltts gfx950 engine: owns the weights (fp32 originals + bf16 hi/lo GEMM packs) for one GPU and
+// sequences the kernels of the three boundary operators the reference runs through onnxruntime
+// (condition_encoder / denoiser / codec, reference infer/onnx.py:91-128) plus the fused sampler.
+// Single-stream, not thread-safe: one Engine per GPU (mirrors the reference's one-Session-per-
+// pipeline model, src/server/src/main.rs:24).
+#pragma once
+#include <map>
+#include <string>
+#include <vector>
+
+#include "gemm_ops.hpp"
+#include "kernels.hpp"
+
+struct RawTensor {
+    float* d = nullptr;
+    std::vector<long> shape;
+    long numel = 0;
+};
+
+struct PW {  // packed GEMM weight [N][K], bf16 hi + lo
+    bf16_t* hi = nullptr;
+    bf16_t* lo = nullptr;
+    int N = 0, K = 0;
+};
+
+struct EncBlockW {
+    PW qkvg, wo, ff13, w2;
+    const float *qn, *kn, *an, *mn;
+};
+struct EncoderW {
+    int dim, heads, dh, ff, layers;
+    float eps;
+    std::vector<EncBlockW> blocks;
+    const float* final_norm;
+    float* rope;  // [MAXPOS][dh]
+};
+struct DitBlockW {
+    PW qkvg, out, ff13, ff2;
+    float* b_qkvg;
+    const float *b1, *b3, *b2, *qn, *kn;
+};
+struct CodecBlockW {
+    const float *norm_w, *dw_b, *gamma, *ffn_norm_w, *b1, *b2, *ffn_gamma;
+    float* dw_w;  // [K][C]
+    PW w1, w2;
+};
+struct CodecStageW {
+    int C = 0, r = 0;  // r: resample ratio entering this stage (0 for stage 0)
+    PW resample;       // decoder: ConvTranspose as GEMM [r*C][2*Cprev]; encoder: strided conv [C][2r*Cprev]
+    float* resample_bias = nullptr;
+    std::vector<CodecBlockW> blocks;
+};
+struct CodecHalfW {
+    bool ready = false;
+    std::vector<CodecStageW> stages;
+    PW stem;                 // decoder: [C0][K*latent]   (encoder stem is a direct 1-channel conv)
+    const float* stem_b = nullptr;
+    const float* stem_w_raw = nullptr;  // encoder
+    PW head;                 // encoder: [latent][K*Clast]
+    float* head_w = nullptr; // decoder: [K][Clast] fp32
+    float head_b_host = 0.f;
+    const float* head_b = nullptr;
+};
+
+struct CodecSpecC {
+    int latent_dim = 64, n_filters = 32, kernel = 7, ffn_mult = 4, n_ratios = 6;
+    int ratios[8] = {8, 5, 5, 4, 2, 2, 0, 0};   // decoder order
+    int depths[9] = {8, 3, 3, 3, 3, 3, 3, 0, 0};  // decoder order, n_ratios + 1 entries
+    float eps = 1e-5f;
+    int hop() const { int h = 1; for (int i = 0; i < n_ratios; ++i) h *= ratios[i]; return h; }
+};
+
+class Engine {
+  public:
+    explicit Engine(int device);
+    ~Engine();
+    int device() const { return device_; }
+    const std::string& last_error() const { return err_; }
+
+    // ---- weights ---------------------------------------------------------------------------
+    int set_tensor(const char* name, const float* data, const long* shape, int ndim, bool src_on_device);
+    int synth_tensor(const char* name, const long* shape, int ndim, uint64_t key, float mean, float half_range);
+    int get_tensor(const char* name, float* host_out, long numel);
+    int set_codec_spec(const CodecSpecC& s);
+    int finalize();  // build GEMM packs for whatever model parts are present
+    bool has_dit() const { return dit_ready_; }
+    bool has_decoder() const { return dec_.ready; }
+    bool has_encoder() const { return enc_.ready; }
+    void set_precision(int split) { split_ = split == 1 ? 1 : 3; }
+    int precision() const { return split_; }
+
+    // ---- operators (device pointers, async on `st`) ------------------------------------------
+    size_t cond_ws_bytes(int B, int R, int P) const;
+    int cond_encode(hipStream_t st, const float* ref, const int64_t* ref_len, const int64_t* ids,
+                    const uint8_t* ph_mask, int B, int R, int P, float* k_ref, float* v_ref, uint8_t* ref_mask,
+                    float* k_text, float* v_text, void* ws, size_t ws_bytes, float* ref_seq_out, float* mem_out);
+
+    size_t denoise_ws_bytes(int B, int N, int rows) const;
+    int denoise_step(hipStream_t st, const float* x_t, const uint8_t* mask, const float* t, const float* k_ref,
+                     const float* v_ref, const uint8_t* ref_mask, const float* k_text, const float* v_text,
+                     const uint8_t* ph_mask, const float* rope, int B, int N, int R, int P, float* velocity,
+                     void* ws, size_t ws_bytes);
+
+    // mode 0: DMD re-noising loop (infer/onnx.py:98-125); mode 1: teacher ODE (build-defined).
+    // cfg != 0: caches/masks hold 3B rows [cond; no-text; no-speaker], x has B rows.
+    // noise: mode 0 -> (n_steps, B, N, 64); mode 1 -> (B, N, 64); null -> Philox(seed).
+    size_t sample_ws_bytes(int B, int N, int n_steps, int cfg) const;
+    int sample(hipStream_t st, int mode, int n_steps, int cfg, float s_text, float s_spk, const uint8_t* mask,
+               const float* k_ref, const float* v_ref, const uint8_t* ref_mask, const float* k_text,
+               const float* v_text, const uint8_t* ph_mask, int B, int N, int R, int P, const float* noise,
+               uint64_t seed, float* x_out, float* steps_out, void* ws, size_t ws_bytes);
+
+    size_t decode_ws_bytes(int B, int T) const;
+    int codec_decode(hipStream_t st, const float* latents, int B, int T, float* audio, void* ws, size_t ws_bytes);
+    size_t encode_ws_bytes(int B, int S) const;
+    int codec_encode(hipStream_t st, const float* audio, int B, int S, float* latents, void* ws, size_t ws_bytes);
+
+    const CodecSpecC& codec_spec() const { return cspec_; }
+    // single-kernel hooks for tests (W* are fp32 [N][K] on the device; split here, freed after the call)
+    int test_gemm(hipStream_t st, const float* A, int lda, const float* W, const float* bias, int M, int N, int K,
+                  int act, int split, int cfg, float* C, int ldc);
+    int test_swiglu(hipStream_t st, const float* A, const float* W1, const float* W3, const float* b1, const float* b3,
+                    int M, int F, int K, int split, float* out);
+
+    int fail(const std::string& m) { err_ = m; return 1; }
+    int fail_hip(hipError_t e, const char* what);
+
+  private:
+    void* dalloc(size_t bytes);
+    const RawTensor* raw(const std::string& n) const;
+    const float* rawp(const std::string& n) const;
+    PW pack_rows(const std::vector<std::string>& names, const std::vector<int>* perm = nullptr);
+    PW pack_from_f32(const float* src, int N, int K);
+    float* concat_vec(const std::vector<std::string>& names, const std::vector<int>& zero_len = {});
+    int finalize_dit();
+    int finalize_codec(bool decoder);
+    int build_encoder(EncoderW& e, const std::string& prefix, int dim, int heads, int ff, int layers, float eps);
+    int run_encoder(hipStream_t st, const EncoderW& e, float* x, float* y, float* qkvg, float* o, float* ffh, int B,
+                    int S, const uint8_t* key_mask);
+    int modulation(hipStream_t st, const float* t_dev, int rows, float* sinb, float* t1, float* temb, float* e1,
+                   float* semb, float* mod);
+    struct DenoiseWs;
+    int denoise_core(hipStream_t st, const float* x_t, const uint8_t* mask, const float* mod, int mod_row0,
+                     int mod_rstride, const float* k_ref, const float* v_ref, const uint8_t* ref_mask,
+                     const float* k_text, const float* v_text, const uint8_t* ph_mask, const float* rope, int B,
+                     int N, int R, int P, float* velocity, char* ws);
+    size_t denoise_core_bytes(int B, int N) const;
+    int codec_block(hipStream_t st, const CodecBlockW& w, float* x, float* nbuf, float* hidden, int B, int T, int C);
+
+    int device_;
+    std::string err_;
+    std::map<std::string, RawTensor> raw_;
+    std::vector<void*> allocs_;
+    int split_ = 3;
+    bool finalized_ = false;
+
+    // DiT packs
+    bool dit_ready_ = false;
+    PW time0_, time2_, emb0_, emb2_, modall_, inproj_, conv1_, conv2_, velocity_, phproj_, kvref_, kvtext_, style_in_,
+        style_out_;
+    float *modall_b_ = nullptr, *kvref_b_ = nullptr, *kvtext_b_ = nullptr, *knc_ = nullptr;
+    std::vector<DitBlockW> blocks_;
+    EncoderW style_, text_;
+    float style_scale_ = 1.f;
+    float* rope_dit_ = nullptr;  // [MAXPOS][64]
+
+    CodecSpecC cspec_;
+    CodecHalfW dec_, enc_;
+};
+
+void alpha_sigma_host(float t, float& a, float& s);
+
+static constexpr int kMaxPos = 4096;   // reference rope tables (dit.py:139, style.py:140)
+static constexpr int kHidden = 960, kHeads = 8, kDh = 120, kBlocks = 12, kFF = 2400, kLatent = 64;
+static constexpr int kModPerBlock = 6 * kHidden;
+static constexpr long kModLd = (long)kBlocks * kModPerBlock + 2 * kHidden;  // 71040
+static constexpr int kConvK = 31, kConvG = 16, kConvCpg = 60, kConvPad = 15, kConvGs = 64;
+static constexpr int kCodecPad = 8;

@@ -1,0 +1,388 @@
+// LDS-tiled MFMA GEMM for gfx950:  C[M,N] (+)= A[M,K] (fp32, row-mapped) x W[N,K]^T (bf16 hi/lo)
+//
+// * A is fp32 in HBM (residual stream / activations stay fp32); it is split on the fly into
+//   bf16 hi + bf16 lo while being staged into LDS.  W is pre-split offline (hi, lo arrays).
+// * SPLIT==3: acc += Ahi*Bhi + Ahi*Blo + Alo*Bhi  (3 bf16 MFMAs, fp32 accumulate) -> ~2^-17
+//   relative operand error, i.e. fp32-class results on the bf16 matrix cores.
+//   SPLIT==1: plain bf16 MFMA (fast mode; error reported, not hidden).
+// * v_mfma_f32_32x32x16_bf16; a wave owns TM x TN tiles of 32x32; 64-wide wavefronts, WM x WN
+//   waves per workgroup.  LDS rows are padded by 16 B so ds_read_b128 fragment reads are
+//   bank-conflict free (row stride 80 B / 144 B -> 16 distinct 16-B slots per 16-lane group).
+// * Register-prefetched single LDS buffer: global loads of tile t+1 are issued before the MFMAs
+//   of tile t.
+// * Epilogues are functors fused into the accumulator write-out (bias, activation, SwiGLU,
+//   gated residual, KV-cache scatter, conv-pos scatter ...).
+#pragma once
+#include "common.hpp"
+
+struct GemmOperands {
+    const float* A;
+    RowMap amap;
+    const bf16_t* Whi;
+    const bf16_t* Wlo;
+    long ldw;
+    int M, N, K;
+    long a_z, w_z;  // per-blockIdx.z element strides
+    int w_zmod;     // weights use (z % w_zmod) * w_z when non-zero (grouped conv: z = batch*G + group)
+};
+
+__device__ __forceinline__ void split4(const float4& v, uint2& hi, uint2& lo) {
+    bf16x4 h, l;
+    h[0] = (bf16_t)v.x; h[1] = (bf16_t)v.y; h[2] = (bf16_t)v.z; h[3] = (bf16_t)v.w;
+    l[0] = (bf16_t)(v.x - (float)h[0]);
+    l[1] = (bf16_t)(v.y - (float)h[1]);
+    l[2] = (bf16_t)(v.z - (float)h[2]);
+    l[3] = (bf16_t)(v.w - (float)h[3]);
+    hi = *reinterpret_cast<uint2*>(&h);
+    lo = *reinterpret_cast<uint2*>(&l);
+}
+
+template <int BM, int BN, int BK, int WM, int WN, int SPLIT, class Epi>
+__global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(GemmOperands g, Epi epi) {
+    constexpr int NT = WM * WN * 64;
+    constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
+    constexpr int LROW = BK + 8;  // bf16 elements per LDS row (16 B pad)
+    constexpr int A_CH = (BM * BK / 4) / NT;
+    constexpr int W_CH = (BN * BK / 8) / NT;
+    static_assert(A_CH * NT * 4 == BM * BK && W_CH * NT * 8 == BN * BK, "tile/threads mismatch");
+    static_assert(!Epi::PAIRED || TN == 2, "paired epilogue needs a 32x64 wave tile");
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    bf16_t* sAhi = reinterpret_cast<bf16_t*>(smem);
+    bf16_t* sAlo = sAhi + BM * LROW;
+    bf16_t* sWhi = sAlo + (SPLIT == 3 ? BM * LROW : 0);
+    bf16_t* sWlo = sWhi + BN * LROW;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN, z = blockIdx.z;
+    const float* A = g.A + (long)z * g.a_z;
+    const long wz = (long)(g.w_zmod ? z % g.w_zmod : z) * g.w_z;
+    const bf16_t* Whi = g.Whi + wz;
+    const bf16_t* Wlo = (SPLIT == 3) ? g.Wlo + wz : nullptr;
+
+    // per-thread staging coordinates (fixed across k-tiles)
+    long a_off[A_CH];
+    int a_k[A_CH], a_lds[A_CH];
+#pragma unroll
+    for (int c = 0; c < A_CH; ++c) {
+        int idx = c * NT + tid;
+        int row = idx / (BK / 4), c4 = idx % (BK / 4);
+        int m = m0 + row;
+        m = m < g.M ? m : g.M - 1;
+        a_off[c] = g.amap.at(m) + c4 * 4;
+        a_k[c] = c4 * 4;
+        a_lds[c] = row * LROW + c4 * 4;
+    }
+    long w_off[W_CH];
+    int w_k[W_CH], w_lds[W_CH];
+#pragma unroll
+    for (int c = 0; c < W_CH; ++c) {
+        int idx = c * NT + tid;
+        int row = idx / (BK / 8), c8 = idx % (BK / 8);
+        int n = n0 + row;
+        n = n < g.N ? n : g.N - 1;
+        w_off[c] = (long)n * g.ldw + c8 * 8;
+        w_k[c] = c8 * 8;
+        w_lds[c] = row * LROW + c8 * 8;
+    }
+
+    float4 ra[A_CH];
+    uint4 rwh[W_CH], rwl[W_CH];
+    auto load_tile = [&](int k0) {
+#pragma unroll
+        for (int c = 0; c < A_CH; ++c) {
+            if (k0 + a_k[c] < g.K)
+                ra[c] = *reinterpret_cast<const float4*>(A + a_off[c] + k0);
+            else
+                ra[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int c = 0; c < W_CH; ++c) {
+            if (k0 + w_k[c] < g.K) {
+                rwh[c] = *reinterpret_cast<const uint4*>(Whi + w_off[c] + k0);
+                if (SPLIT == 3) rwl[c] = *reinterpret_cast<const uint4*>(Wlo + w_off[c] + k0);
+            } else {
+                rwh[c] = make_uint4(0, 0, 0, 0);
+                if (SPLIT == 3) rwl[c] = make_uint4(0, 0, 0, 0);
+            }
+        }
+    };
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int c = 0; c < A_CH; ++c) {
+            uint2 hi, lo;
+            split4(ra[c], hi, lo);
+            *reinterpret_cast<uint2*>(sAhi + a_lds[c]) = hi;
+            if (SPLIT == 3) *reinterpret_cast<uint2*>(sAlo + a_lds[c]) = lo;
+        }
+#pragma unroll
+        for (int c = 0; c < W_CH; ++c) {
+            *reinterpret_cast<uint4*>(sWhi + w_lds[c]) = rwh[c];
+            if (SPLIT == 3) *reinterpret_cast<uint4*>(sWlo + w_lds[c]) = rwl[c];
+        }
+    };
+
+    floatx16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int fr = lane & 31, fk = (lane >> 5) * 8;
+    const int a_frag = (wm * TM * 32 + fr) * LROW + fk;
+    const int w_frag = (wn * TN * 32 + fr) * LROW + fk;
+
+    const int nk = (g.K + BK - 1) / BK;
+    load_tile(0);
+    store_tile();
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        if (kt + 1 < nk) load_tile((kt + 1) * BK);
+#pragma unroll
+        for (int kk = 0; kk < BK / 16; ++kk) {
+            bf16x8 ah[TM], al[TM], bh[TN], bl[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                ah[i] = *reinterpret_cast<const bf16x8*>(sAhi + a_frag + i * 32 * LROW + kk * 16);
+                if (SPLIT == 3) al[i] = *reinterpret_cast<const bf16x8*>(sAlo + a_frag + i * 32 * LROW + kk * 16);
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                bh[j] = *reinterpret_cast<const bf16x8*>(sWhi + w_frag + j * 32 * LROW + kk * 16);
+                if (SPLIT == 3) bl[j] = *reinterpret_cast<const bf16x8*>(sWlo + w_frag + j * 32 * LROW + kk * 16);
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    if (SPLIT == 3) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+                    }
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+                }
+        }
+        __syncthreads();
+        if (kt + 1 < nk) {
+            store_tile();
+            __syncthreads();
+        }
+    }
+
+    // epilogue: C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    const int cn = lane & 31, rm = 4 * (lane >> 5);
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int mb = m0 + (wm * TM + i) * 32 + rm;
+        if (Epi::PAIRED) {
+            const int nb = n0 + wn * 64;  // packed column base (64 packed = 32 outputs)
+            const int nh = nb / 2 + cn;
+            if (nb + cn < g.N) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    int m = mb + (r & 3) + 8 * (r >> 2);
+                    if (m < g.M) epi.pair(z, m, nh, acc[i][0][r], acc[i][TN - 1][r]);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int n = n0 + (wn * TN + j) * 32 + cn;
+                if (n < g.N) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        int m = mb + (r & 3) + 8 * (r >> 2);
+                        if (m < g.M) epi.one(z, m, n, acc[i][j][r]);
+                    }
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Epilogues
+// ------------------------------------------------------------------------------------------
+// out[omap(m) + n] = mask(m) * act((acc + bias[n]) * scale)
+template <int ACT>
+struct EpiStore {
+    static constexpr bool PAIRED = false;
+    float* out;
+    RowMap omap;
+    long o_z;
+    const float* bias;     // may be null; indexed [n] (+ z*bias_z)
+    long bias_z;
+    float scale;
+    const uint8_t* rowmask;  // may be null; [m]
+    __device__ __forceinline__ void one(int z, int m, int n, float v) const {
+        if (bias) v += bias[(long)z * bias_z + n];
+        v = apply_act<ACT>(v * scale);
+        if (rowmask && !rowmask[m]) v = 0.f;
+        out[(long)z * o_z + omap.at(m) + n] = v;
+    }
+    __device__ __forceinline__ void pair(int, int, int, float, float) const {}
+};
+
+// SwiGLU on interleaved [w1 | w3] 32-column groups: out[m][nh] = silu(a + b1[nh]) * (b + b3[nh])
+struct EpiSwiGLU {
+    static constexpr bool PAIRED = true;
+    float* out;
+    long ldo;
+    const float* b1;  // may be null
+    const float* b3;
+    __device__ __forceinline__ void one(int, int, int, float) const {}
+    __device__ __forceinline__ void pair(int, int m, int nh, float a, float b) const {
+        if (b1) { a += b1[nh]; b += b3[nh]; }
+        out[(long)m * ldo + nh] = (a / (1.0f + expf(-a))) * b;
+    }
+};
+
+// x[xmap(m) + n] += mask(m) * g(batch(m), n) * (acc + bias[n])
+//   GATE 0: g = 1      GATE 1: g = tanh(gate[(grow0 + batch*grstride) * gld + n])     GATE 2: g = gate[n]
+template <int GATE>
+struct EpiResid {
+    static constexpr bool PAIRED = false;
+    float* x;
+    RowMap xmap;
+    const float* bias;       // may be null
+    const float* gate;       // table (GATE 1: rows selected by grow[], GATE 2: vector)
+    long gld;
+    int grow0, grstride;     // gate-table row of batch b = grow0 + b*grstride (GATE 1)
+    int rows_per_batch;      // batch(m) = m / rows_per_batch (GATE 1)
+    const uint8_t* rowmask;  // may be null
+    __device__ __forceinline__ void one(int, int m, int n, float v) const {
+        if (rowmask && !rowmask[m]) return;
+        if (bias) v += bias[n];
+        if (GATE == 1) {
+            int b = m / rows_per_batch;
+            v *= tanhf(gate[(long)(grow0 + b * grstride) * gld + n]);
+        } else if (GATE == 2) {
+            v *= gate[n];
+        }
+        long o = xmap.at(m) + n;
+        x[o] += v;
+    }
+    __device__ __forceinline__ void pair(int, int, int, float, float) const {}
+};
+
+// Cross-KV scatter (reference dit.py:80-93): rows m = (b, j), columns n = ((layer*2 + kv)*H + h)*dh + d
+// -> dst_kv[layer][b][h][j][d]  (+bias).  K is RMS-normalised afterwards by headnorm_kernel.
+struct EpiKV {
+    static constexpr bool PAIRED = false;
+    float* kdst;
+    float* vdst;
+    const float* bias;  // [n]
+    int B, H, dh, S;    // S = keys per batch row (R or P)
+    __device__ __forceinline__ void one(int, int m, int n, float v) const {
+        v += bias[n];
+        int d = n % dh, t = n / dh;
+        int h = t % H; t /= H;
+        int kv = t & 1, layer = t >> 1;
+        int b = m / S, j = m % S;
+        long o = ((((long)layer * B + b) * H + h) * S + j) * dh + d;
+        (kv ? vdst : kdst)[o] = v;
+    }
+    __device__ __forceinline__ void pair(int, int, int, float, float) const {}
+};
+
+// Grouped conv position embedding (reference dit.py:215-236) as per-(batch, group) GEMMs.
+// z = b*G + g, m = t, n = oc (< cpg).  v = mish(acc + bias) * mask[b][t].
+// FINAL == 0: write the group-major padded image  gm[z][pad + t][n]   (input of conv2)
+// FINAL == 1: x[b][t][g*cpg + n] = v + h[b][t][g*cpg + n]              (dit.py:252)
+template <int FINAL>
+struct EpiConvPos {
+    static constexpr bool PAIRED = false;
+    float* out;
+    const float* h;       // FINAL only
+    const float* bias;    // [G*cpg]
+    const uint8_t* mask;  // [B][T]
+    int G, cpg, T, pad, gstride;  // gstride = padded channels per group in gm image
+    __device__ __forceinline__ void one(int z, int m, int n, float v) const {
+        int b = z / G, g = z % G;
+        int ch = g * cpg + n;
+        v = mish_f(v + bias[ch]);
+        if (!mask[b * T + m]) v = 0.f;
+        if (FINAL) {
+            long o = ((long)b * T + m) * (G * cpg) + ch;
+            out[o] = v + h[o];
+        } else {
+            out[((long)z * (T + 2 * pad) + pad + m) * gstride + n] = v;
+        }
+    }
+    __device__ __forceinline__ void pair(int, int, int, float, float) const {}
+};
+
+// ------------------------------------------------------------------------------------------
+// Launcher
+// ------------------------------------------------------------------------------------------
+enum GemmCfg {
+    CFG_64x128 = 0,   // general (wave tile 32x64) — also the SwiGLU config
+    CFG_64x64 = 1,    // small N / under-filled grids
+    CFG_128x128 = 2,  // large M and N
+    CFG_128x32 = 3,   // tall-skinny, N <= 32
+    CFG_128x64 = 4,   // tall-skinny, N <= 64
+};
+
+template <int BM, int BN, int BK, int WM, int WN, int SPLIT, class Epi>
+static inline hipError_t gemm_launch_cfg(const GemmOperands& g, const Epi& epi, int Z, hipStream_t st) {
+    constexpr int LROW = BK + 8;
+    size_t lds = (size_t)(BM + BN) * LROW * 2 * (SPLIT == 3 ? 2 : 1);
+    dim3 grid((g.N + BN - 1) / BN, (g.M + BM - 1) / BM, Z);
+    auto kern = gemm_kernel<BM, BN, BK, WM, WN, SPLIT, Epi>;
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(kern, grid, dim3(WM * WN * 64), lds, st, g, epi);
+    return hipGetLastError();
+}
+
+static inline int gemm_pick_cfg(int M, int N, int K, bool paired) {
+    if (paired) return CFG_64x128;
+    if (N <= 32) return CFG_128x32;
+    if (N <= 64) return M >= 4096 ? CFG_128x64 : CFG_64x64;
+    long tiles128 = (long)((M + 127) / 128) * ((N + 127) / 128);
+    if (tiles128 >= 1024) return CFG_128x128;
+    long tilesL = (long)((M + 63) / 64) * ((N + 127) / 128);
+    if (tilesL >= 256 || N % 128 == 0) return CFG_64x128;
+    return CFG_64x64;
+}
+
+template <int SPLIT, class Epi>
+static inline hipError_t gemm_launch_split(const GemmOperands& g, const Epi& epi, int Z, int cfg, hipStream_t st) {
+    const bool k32 = g.K <= 32;
+    switch (cfg) {
+        case CFG_64x128:
+            return gemm_launch_cfg<64, 128, 64, 2, 2, SPLIT, Epi>(g, epi, Z, st);
+        case CFG_128x128:
+            if constexpr (!Epi::PAIRED) return gemm_launch_cfg<128, 128, 64, 2, 2, SPLIT, Epi>(g, epi, Z, st);
+            break;
+        case CFG_64x64:
+            if constexpr (!Epi::PAIRED) return gemm_launch_cfg<64, 64, 64, 2, 2, SPLIT, Epi>(g, epi, Z, st);
+            break;
+        case CFG_128x32:
+            if constexpr (!Epi::PAIRED) return gemm_launch_cfg<128, 32, 64, 4, 1, SPLIT, Epi>(g, epi, Z, st);
+            break;
+        case CFG_128x64:
+            if constexpr (!Epi::PAIRED) {
+                if (k32) return gemm_launch_cfg<128, 64, 32, 4, 1, SPLIT, Epi>(g, epi, Z, st);
+                return gemm_launch_cfg<128, 64, 64, 4, 1, SPLIT, Epi>(g, epi, Z, st);
+            }
+            break;
+    }
+    return hipErrorInvalidValue;
+}
+
+// split: 1 = plain bf16, 3 = split-bf16 (fp32-class)
+template <class Epi>
+static inline hipError_t gemm_launch(const GemmOperands& g, const Epi& epi, int Z, int split, hipStream_t st,
+                                     int cfg = -1) {
+    if (g.M <= 0 || g.N <= 0) return hipSuccess;
+    if (cfg < 0) cfg = gemm_pick_cfg(g.M, g.N, g.K, Epi::PAIRED);
+    if (split == 3) return gemm_launch_split<3, Epi>(g, epi, Z, cfg, st);
+    return gemm_launch_split<1, Epi>(g, epi, Z, cfg, st);
+}

@@ -1,0 +1,14 @@
+#include "gemm_ops.hpp"
+template <int ACT>
+static EpiStore<ACT> conv(const EpiStore<ACT_NONE>& p) {
+    return EpiStore<ACT>{p.out, p.omap, p.o_z, p.bias, p.bias_z, p.scale, p.rowmask};
+}
+hipError_t gemm_store(const GemmOperands& g, int act, const EpiStore<ACT_NONE>& p, int Z, int split, hipStream_t st, int cfg) {
+    switch (act) {
+        case ACT_NONE: return gemm_launch(g, p, Z, split, st, cfg);
+        case ACT_SILU: return gemm_launch(g, conv<ACT_SILU>(p), Z, split, st, cfg);
+        case ACT_GELU: return gemm_launch(g, conv<ACT_GELU>(p), Z, split, st, cfg);
+        case ACT_MISH: return gemm_launch(g, conv<ACT_MISH>(p), Z, split, st, cfg);
+    }
+    return hipErrorInvalidValue;
+}

@@ -1,0 +1,497 @@
+// Non-GEMM kernels: norms, element-wise sampler steps, RNG, weight synthesis/packing helpers.
+// HBM-bound streaming kernels: one wave (or sub-wave group) per row, float4 accesses where the
+// layout permits, grid sized to cover the chip (>= 256 CUs x several waves).
+#include "kernels.hpp"
+
+#define LAUNCH_CHECK() return hipGetLastError()
+
+// ------------------------------------------------------------------------------------------
+// AdaLN:  y = LN(x) * (1 + scale) + shift       one wave per row, row kept in registers
+// ------------------------------------------------------------------------------------------
+template <int MAXV>
+__global__ __launch_bounds__(256) void ln_modulate_kernel(const float* __restrict__ x, float* __restrict__ y, int M,
+                                                          int C, float eps, const float* __restrict__ shift,
+                                                          const float* __restrict__ scale, long mod_ld,
+                                                          int mod_row0, int mod_rstride, int rpb) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const float* xr = x + (long)row * C;
+    float v[MAXV];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        int c = lane + 64 * i;
+        v[i] = c < C ? xr[c] : 0.f;
+        s += v[i];
+    }
+    const float mean = wave_sum(s) / (float)C;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        int c = lane + 64 * i;
+        float d = c < C ? v[i] - mean : 0.f;
+        q += d * d;
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)C + eps);
+    const int b = row / rpb;
+    const long r = (long)(mod_row0 + b * mod_rstride) * mod_ld;
+    float* yr = y + (long)row * C;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        int c = lane + 64 * i;
+        if (c < C) yr[c] = (v[i] - mean) * rstd * (1.0f + scale[r + c]) + shift[r + c];
+    }
+}
+
+hipError_t launch_ln_modulate(const float* x, float* y, int M, int C, float eps, const float* shift,
+                              const float* scale, long mod_ld, int mod_row0, int mod_rstride, int rows_per_batch,
+                              hipStream_t st) {
+    if (C > 1024) return hipErrorInvalidValue;
+    dim3 grid((M + 3) / 4), block(256);
+    hipLaunchKernelGGL(ln_modulate_kernel<16>, grid, block, 0, st, x, y, M, C, eps, shift, scale, mod_ld,
+                       mod_row0, mod_rstride, rows_per_batch);
+    LAUNCH_CHECK();
+}
+
+// ------------------------------------------------------------------------------------------
+// RMSNorm with 1-D weight; LPR lanes cooperate on one row (float4 per lane per step)
+// ------------------------------------------------------------------------------------------
+template <int LPR, int NV4>
+__global__ __launch_bounds__(256) void rmsnorm_kernel(const float* __restrict__ x, RowMap xmap, float* __restrict__ y,
+                                                      RowMap ymap, int M, int C, float eps,
+                                                      const float* __restrict__ w) {
+    constexpr int RPB = 256 / LPR;  // rows per block
+    const int sub = threadIdx.x % LPR;
+    const int row = blockIdx.x * RPB + threadIdx.x / LPR;
+    const bool live = row < M;
+    const int c4n = C >> 2;
+    const float4* xr = reinterpret_cast<const float4*>(x + xmap.at(live ? row : 0));
+    float4 v[NV4];
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV4; ++i) {
+        int c = sub + LPR * i;
+        v[i] = (live && c < c4n) ? xr[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+        ss += v[i].x * v[i].x + v[i].y * v[i].y + v[i].z * v[i].z + v[i].w * v[i].w;
+    }
+    ss = group_sum<LPR>(ss);
+    const float rstd = 1.0f / sqrtf(ss / (float)C + eps);
+    if (!live) return;
+    float4* yr = reinterpret_cast<float4*>(y + ymap.at(row));
+    const float4* w4 = reinterpret_cast<const float4*>(w);
+#pragma unroll
+    for (int i = 0; i < NV4; ++i) {
+        int c = sub + LPR * i;
+        if (c < c4n) {
+            float4 g = w4[c];
+            yr[c] = make_float4(v[i].x * rstd * g.x, v[i].y * rstd * g.y, v[i].z * rstd * g.z, v[i].w * rstd * g.w);
+        }
+    }
+}
+
+template <int LPR, int NV4>
+static hipError_t rmsnorm_go(const float* x, RowMap xmap, float* y, RowMap ymap, int M, int C, float eps,
+                             const float* w, hipStream_t st) {
+    constexpr int RPB = 256 / LPR;
+    hipLaunchKernelGGL((rmsnorm_kernel<LPR, NV4>), dim3((M + RPB - 1) / RPB), dim3(256), 0, st, x, xmap, y, ymap, M,
+                       C, eps, w);
+    LAUNCH_CHECK();
+}
+
+hipError_t launch_rmsnorm(const float* x, RowMap xmap, float* y, RowMap ymap, int M, int C, float eps,
+                          const float* w, hipStream_t st) {
+    if (C % 4) return hipErrorInvalidValue;
+    int c4 = C / 4;
+    if (c4 <= 8) return rmsnorm_go<8, 1>(x, xmap, y, ymap, M, C, eps, w, st);
+    if (c4 <= 16) return rmsnorm_go<16, 1>(x, xmap, y, ymap, M, C, eps, w, st);
+    if (c4 <= 32) return rmsnorm_go<32, 1>(x, xmap, y, ymap, M, C, eps, w, st);
+    if (c4 <= 64) return rmsnorm_go<64, 1>(x, xmap, y, ymap, M, C, eps, w, st);
+    if (c4 <= 128) return rmsnorm_go<64, 2>(x, xmap, y, ymap, M, C, eps, w, st);
+    if (c4 <= 256) return rmsnorm_go<64, 4>(x, xmap, y, ymap, M, C, eps, w, st);
+    if (c4 <= 512) return rmsnorm_go<64, 8>(x, xmap, y, ymap, M, C, eps, w, st);
+    return hipErrorInvalidValue;
+}
+
+// ------------------------------------------------------------------------------------------
+// cross-K per-head RMSNorm, in place:  k[L][B][H][S][dh] *= rsqrt(mean_d k^2 + eps) * w[L][H][dh]
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void headnorm_kernel(float* __restrict__ k, long rows, int B, int H, int S, int dh,
+                                                       float eps, const float* __restrict__ w) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    float* kr = k + row * dh;
+    const int h = (int)((row / S) % H);
+    const int l = (int)(row / ((long)S * H * B));
+    const float* wr = w + ((long)l * H + h) * dh;
+    float v0 = lane < dh ? kr[lane] : 0.f;
+    float v1 = lane + 64 < dh ? kr[lane + 64] : 0.f;
+    float ss = wave_sum(v0 * v0 + v1 * v1);
+    float rstd = 1.0f / sqrtf(ss / (float)dh + eps);
+    if (lane < dh) kr[lane] = v0 * rstd * wr[lane];
+    if (lane + 64 < dh) kr[lane + 64] = v1 * rstd * wr[lane + 64];
+}
+
+hipError_t launch_headnorm(float* k, int L, int B, int H, int S, int dh, float eps, const float* w, hipStream_t st) {
+    if (dh > 128) return hipErrorInvalidValue;
+    long rows = (long)L * B * H * S;
+    if (rows == 0) return hipSuccess;
+    hipLaunchKernelGGL(headnorm_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, k, rows, B, H, S, dh, eps, w);
+    LAUNCH_CHECK();
+}
+
+// ------------------------------------------------------------------------------------------
+// small element-wise kernels
+// ------------------------------------------------------------------------------------------
+__global__ void embedding_kernel(const int64_t* __restrict__ ids, const float* __restrict__ table,
+                                 float* __restrict__ out, int M, int C4, int vocab) {
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)M * C4) return;
+    int m = (int)(i / C4), c = (int)(i % C4);
+    long id = ids[m];
+    id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
+    reinterpret_cast<float4*>(out)[i] = reinterpret_cast<const float4*>(table)[id * C4 + c];
+}
+hipError_t launch_embedding(const int64_t* ids, const float* table, float* out, int M, int C, int vocab, hipStream_t st) {
+    long n = (long)M * (C / 4);
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(embedding_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, ids, table, out, M, C / 4, vocab);
+    LAUNCH_CHECK();
+}
+
+__global__ void time_sinusoid_kernel(const float* __restrict__ t, float* __restrict__ e, int rows) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * 256) return;
+    int r = i >> 8, c = i & 255;
+    int j = c & 127;
+    // model.py:25-27 : exp(arange(half).float() * -(ln 1e4 / (half-1))), then 1e3 * t * f
+    const float neg = -0.072522365133670733f;  // -ln(1e4)/127
+    float f = expf((float)j * neg);
+    float a = (1e3f * t[r]) * f;
+    e[i] = c < 128 ? sinf(a) : cosf(a);
+}
+hipError_t launch_time_sinusoid(const float* t, float* e, int rows, hipStream_t st) {
+    hipLaunchKernelGGL(time_sinusoid_kernel, dim3((rows * 256 + 255) / 256), dim3(256), 0, st, t, e, rows);
+    LAUNCH_CHECK();
+}
+
+__global__ void len_mask_kernel(const int64_t* __restrict__ len, uint8_t* __restrict__ mask, int B, int R) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * R) return;
+    int b = i / R, j = i % R;
+    long l = len[b];
+    l = l > R ? R : l;
+    mask[i] = j < l ? 1 : 0;
+}
+hipError_t launch_len_mask(const int64_t* len, uint8_t* mask, int B, int R, hipStream_t st) {
+    if (B * R == 0) return hipSuccess;
+    hipLaunchKernelGGL(len_mask_kernel, dim3((B * R + 255) / 256), dim3(256), 0, st, len, mask, B, R);
+    LAUNCH_CHECK();
+}
+
+__global__ void convpos_pack_kernel(const float* __restrict__ h, const uint8_t* __restrict__ mask,
+                                    float* __restrict__ gm, int B, int T, int G, int cpg, int pad, int gstride) {
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int TP = T + 2 * pad;
+    long total = (long)B * G * TP * gstride;
+    if (i >= total) return;
+    int c = (int)(i % gstride);
+    long r = i / gstride;
+    int tp = (int)(r % TP);
+    int zz = (int)(r / TP);
+    int b = zz / G, g = zz % G;
+    int t = tp - pad;
+    float v = 0.f;
+    if (t >= 0 && t < T && c < cpg && mask[b * T + t]) v = h[((long)b * T + t) * (G * cpg) + g * cpg + c];
+    gm[i] = v;
+}
+hipError_t launch_convpos_pack(const float* h, const uint8_t* mask, float* gm, int B, int T, int G, int cpg,
+                               int pad, int gstride, hipStream_t st) {
+    long total = (long)B * G * (T + 2 * pad) * gstride;
+    hipLaunchKernelGGL(convpos_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, h, mask, gm, B, T, G,
+                       cpg, pad, gstride);
+    LAUNCH_CHECK();
+}
+
+__global__ void axpby_kernel(float* __restrict__ out, const float* __restrict__ x, const float* __restrict__ y,
+                             float a, float b, long n) {
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = a * x[i] + b * y[i];
+}
+hipError_t launch_axpby(float* out, const float* x, const float* y, float a, float b, long n, hipStream_t st) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(axpby_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, out, x, y, a, b, n);
+    LAUNCH_CHECK();
+}
+
+__global__ void ode_step_kernel(float* __restrict__ xt, const float* __restrict__ v, float* __restrict__ x0_out,
+                                float a, float s, float a2, float s2, long n) {
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float x = xt[i], vv = v[i];
+    float x0 = a * x - s * vv;
+    float ep = s * x + a * vv;
+    x0_out[i] = x0;
+    xt[i] = a2 * x0 + s2 * ep;
+}
+hipError_t launch_ode_step(float* xt, const float* v, float* x0_out, float a, float s, float a2, float s2, long n,
+                           hipStream_t st) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(ode_step_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, xt, v, x0_out, a, s, a2, s2, n);
+    LAUNCH_CHECK();
+}
+
+__global__ void cfg_combine_kernel(const float* __restrict__ v3, float* __restrict__ v, float st_, float ss, long n) {
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float vc = v3[i], vt = v3[n + i], vs = v3[2 * n + i];
+    v[i] = vc + st_ * (vc - vt) + ss * (vc - vs);
+}
+hipError_t launch_cfg_combine(const float* v3, float* v, float s_text, float s_spk, long n, hipStream_t st) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(cfg_combine_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, v3, v, s_text, s_spk, n);
+    LAUNCH_CHECK();
+}
+
+// ------------------------------------------------------------------------------------------
+// Philox4x32-10 + Box-Muller
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void philox4x32_10(uint32_t c[4], uint32_t k0, uint32_t k1) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        uint32_t hi0 = __umulhi(0xD2511F53u, c[0]), lo0 = 0xD2511F53u * c[0];
+        uint32_t hi1 = __umulhi(0xCD9E8D57u, c[2]), lo1 = 0xCD9E8D57u * c[2];
+        uint32_t n0 = hi1 ^ c[1] ^ k0, n1 = lo1, n2 = hi0 ^ c[3] ^ k1, n3 = lo0;
+        c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+}
+__global__ void randn_kernel(float* __restrict__ out, long n, uint64_t seed, uint64_t stream) {
+    long q = (long)blockIdx.x * blockDim.x + threadIdx.x;  // quad index
+    if (q * 4 >= n) return;
+    uint32_t c[4] = {(uint32_t)q, (uint32_t)((uint64_t)q >> 32), (uint32_t)stream, (uint32_t)(stream >> 32)};
+    philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+    float z[4];
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        float u1 = ((float)(c[2 * p] >> 8) + 0.5f) * 5.9604644775390625e-8f;      // (0,1)
+        float u2 = ((float)(c[2 * p + 1] >> 8) + 0.5f) * 5.9604644775390625e-8f;
+        float r = sqrtf(-2.0f * logf(u1));
+        float th = 6.283185307179586f * u2;
+        z[2 * p] = r * cosf(th);
+        z[2 * p + 1] = r * sinf(th);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        if (q * 4 + j < n) out[q * 4 + j] = z[j];
+}
+hipError_t launch_randn(float* out, long n, uint64_t seed, uint64_t stream, hipStream_t st) {
+    if (n == 0) return hipSuccess;
+    long quads = (n + 3) / 4;
+    hipLaunchKernelGGL(randn_kernel, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, st, out, n, seed, stream);
+    LAUNCH_CHECK();
+}
+
+// ------------------------------------------------------------------------------------------
+// synthetic weights + packing
+// ------------------------------------------------------------------------------------------
+__global__ void synth_kernel(float* __restrict__ out, long n, uint64_t key, float mean, float hr) {
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint64_t z = key + (uint64_t)i * 0x9E3779B97F4A7C15ull;
+    z ^= z >> 30; z *= 0xBF58476D1CE4E5B9ull;
+    z ^= z >> 27; z *= 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    float s = __fsub_rn(__fmul_rn((float)(uint32_t)(z >> 40), 1.1920928955078125e-7f), 1.0f);
+    out[i] = __fadd_rn(mean, __fmul_rn(hr, s));
+}
+hipError_t launch_synth(float* out, long n, uint64_t key, float mean, float half_range, hipStream_t st) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(synth_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, out, n, key, mean, half_range);
+    LAUNCH_CHECK();
+}
+
+__global__ void split_rows_kernel(const float* __restrict__ src, long src_ld, bf16_t* __restrict__ hi,
+                                  bf16_t* __restrict__ lo, long dst_ld, int rows, int cols,
+                                  const int* __restrict__ perm) {
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)rows * cols) return;
+    int r = (int)(i / cols), c = (int)(i % cols);
+    int sr = perm ? perm[r] : r;
+    float v = sr >= 0 ? src[(long)sr * src_ld + c] : 0.f;
+    bf16_t h = (bf16_t)v;
+    hi[(long)r * dst_ld + c] = h;
+    if (lo) lo[(long)r * dst_ld + c] = (bf16_t)(v - (float)h);
+}
+hipError_t launch_split_rows(const float* src, long src_ld, bf16_t* hi, bf16_t* lo, long dst_ld, int rows, int cols,
+                             const int* perm, hipStream_t st) {
+    long n = (long)rows * cols;
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(split_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, src, src_ld, hi, lo, dst_ld,
+                       rows, cols, perm);
+    LAUNCH_CHECK();
+}
+
+__global__ void fill_kernel(float* __restrict__ p, float v, long n) {
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+hipError_t launch_fill(float* p, float v, long n, hipStream_t st) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(fill_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, p, v, n);
+    LAUNCH_CHECK();
+}
+
+__global__ void copy_strided_kernel(const float* __restrict__ src, long sld, float* __restrict__ dst, long dld,
+                                    int rows, int cols) {
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)rows * cols) return;
+    int r = (int)(i / cols), c = (int)(i % cols);
+    dst[(long)r * dld + c] = src[(long)r * sld + c];
+}
+hipError_t launch_copy_strided(const float* src, long sld, float* dst, long dld, int rows, int cols, hipStream_t st) {
+    long n = (long)rows * cols;
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(copy_strided_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, src, sld, dst, dld, rows, cols);
+    LAUNCH_CHECK();
+}
+
+// ------------------------------------------------------------------------------------------
+// codec element-wise kernels on channels-last padded images x[b][pad + t][c]
+// ------------------------------------------------------------------------------------------
+// causal depthwise conv (weights packed [K][C]) + layer-scale residual; one thread per (b, t, 4 channels)
+__global__ __launch_bounds__(256) void dwconv_resid_kernel(float* __restrict__ x, const float* __restrict__ nrm,
+                                                           const float* __restrict__ w, const float* __restrict__ bias,
+                                                           const float* __restrict__ gamma, int B, int T, int C4,
+                                                           int K, int pad) {
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    long total = (long)B * T * C4;
+    if (i >= total) return;
+    int c = (int)(i % C4);
+    long r = i / C4;
+    int t = (int)(r % T), b = (int)(r / T);
+    const long frame0 = (long)b * (pad + T) + pad + t - (K - 1);
+    const float4* n4 = reinterpret_cast<const float4*>(nrm);
+    const float4* w4 = reinterpret_cast<const float4*>(w);
+    float4 acc = reinterpret_cast<const float4*>(bias)[c];
+    for (int k = 0; k < K; ++k) {
+        float4 nv = n4[(frame0 + k) * C4 + c];
+        float4 wv = w4[(long)k * C4 + c];
+        acc.x += wv.x * nv.x; acc.y += wv.y * nv.y; acc.z += wv.z * nv.z; acc.w += wv.w * nv.w;
+    }
+    float4 g = reinterpret_cast<const float4*>(gamma)[c];
+    float4* xp = reinterpret_cast<float4*>(x) + ((long)b * (pad + T) + pad + t) * C4 + c;
+    float4 xv = *xp;
+    xv.x += g.x * acc.x; xv.y += g.y * acc.y; xv.z += g.z * acc.z; xv.w += g.w * acc.w;
+    *xp = xv;
+}
+hipError_t launch_dwconv_resid(float* x, const float* n, const float* w, const float* bias, const float* gamma,
+                               int B, int T, int C, int K, int pad, hipStream_t st) {
+    if (C % 4 || pad < K - 1) return hipErrorInvalidValue;
+    long total = (long)B * T * (C / 4);
+    if (total == 0) return hipSuccess;
+    hipLaunchKernelGGL(dwconv_resid_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, x, n, w, bias, gamma, B,
+                       T, C / 4, K, pad);
+    LAUNCH_CHECK();
+}
+
+// head conv to 1 channel: weights packed [K][C]; 8 lanes cooperate on one output sample
+__global__ __launch_bounds__(256) void head_conv_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                        float bias, float* __restrict__ audio, int B, int T, int C,
+                                                        int K, int pad) {
+    const int sub = threadIdx.x & 7;
+    long s = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 3;
+    const bool live = s < (long)B * T;
+    int t = live ? (int)(s % T) : 0, b = live ? (int)(s / T) : 0;
+    const float* xr = x + ((long)b * (pad + T) + pad + t - (K - 1)) * C;  // K*C contiguous floats
+    const int n4 = (K * C) >> 2;
+    float acc = 0.f;
+    for (int i = sub; i < n4; i += 8) {
+        float4 xv = reinterpret_cast<const float4*>(xr)[i];
+        float4 wv = reinterpret_cast<const float4*>(w)[i];
+        acc += xv.x * wv.x + xv.y * wv.y + xv.z * wv.z + xv.w * wv.w;
+    }
+    acc = group_sum<8>(acc);
+    if (live && sub == 0) audio[s] = acc + bias;
+}
+hipError_t launch_head_conv(const float* x, const float* w, float bias, float* audio, int B, int T, int C, int K,
+                            int pad, hipStream_t st) {
+    if (C % 4 || pad < K - 1) return hipErrorInvalidValue;
+    long threads = (long)B * T * 8;
+    if (threads == 0) return hipSuccess;
+    hipLaunchKernelGGL(head_conv_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, x, w, bias, audio, B, T, C,
+                       K, pad);
+    LAUNCH_CHECK();
+}
+
+// encoder stem: 1 -> C channels, causal; weights [C][K]
+__global__ void stem_conv1_kernel(const float* __restrict__ audio, const float* __restrict__ w,
+                                  const float* __restrict__ bias, float* __restrict__ x, int B, int T, int C, int K,
+                                  int pad) {
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)B * T * C) return;
+    int c = (int)(i % C);
+    long r = i / C;
+    int t = (int)(r % T), b = (int)(r / T);
+    float acc = bias[c];
+    for (int k = 0; k < K; ++k) {
+        int tt = t - (K - 1) + k;
+        if (tt >= 0) acc += w[c * K + k] * audio[(long)b * T + tt];
+    }
+    x[((long)b * (pad + T) + pad + t) * C + c] = acc;
+}
+hipError_t launch_stem_conv1(const float* audio, const float* w, const float* bias, float* x, int B, int T, int C,
+                             int K, int pad, hipStream_t st) {
+    long n = (long)B * T * C;
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(stem_conv1_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, audio, w, bias, x, B, T, C, K, pad);
+    LAUNCH_CHECK();
+}
+
+__global__ void zero_pad_frames_kernel(float* __restrict__ x, int B, int T, int C, int pad) {
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    long per = (long)pad * C;
+    if (i >= (long)B * per) return;
+    int b = (int)(i / per);
+    long o = i % per;
+    x[(long)b * (pad + T) * C + o] = 0.f;
+}
+hipError_t launch_zero_pad_frames(float* x, int B, int T, int C, int pad, hipStream_t st) {
+    long n = (long)B * pad * C;
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(zero_pad_frames_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, x, B, T, C, pad);
+    LAUNCH_CHECK();
+}
+
+// ------------------------------------------------------------------------------------------
+// weight re-layout gather + rope tables
+// ------------------------------------------------------------------------------------------
+__global__ void gather_pack_kernel(const float* __restrict__ src, float* __restrict__ dst, int N, int K, GatherSpec g) {
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)N * K) return;
+    int n = (int)(i / K), k = (int)(i % K);
+    int n1 = n / g.n0dim, n0 = n % g.n0dim, k1 = k / g.k0dim, k0 = k % g.k0dim;
+    float v = 0.f;
+    if (k0 < g.k0valid) v = src[g.base + n1 * g.sn1 + n0 * g.sn0 + k1 * g.sk1 + k0 * g.sk0];
+    dst[i] = v;
+}
+hipError_t launch_gather_pack(const float* src, float* dst, int N, int K, GatherSpec g, hipStream_t st) {
+    long n = (long)N * K;
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(gather_pack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, src, dst, N, K, g);
+    LAUNCH_CHECK();
+}
+
+__global__ void rope_table_kernel(float* __restrict__ tab, int npos, int dim) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= npos * dim) return;
+    int pos = i / dim, d = i % dim;
+    float inv = 1.0f / powf(10000.0f, (float)(d & ~1) / (float)dim);
+    tab[i] = (float)pos * inv;
+}
+hipError_t launch_rope_table(float* tab, int npos, int dim, hipStream_t st) {
+    hipLaunchKernelGGL(rope_table_kernel, dim3((npos * dim + 255) / 256), dim3(256), 0, st, tab, npos, dim);
+    LAUNCH_CHECK();
+}

@@ -1,0 +1,91 @@
+// Launchers for the non-GEMM kernels of the smalltts gfx950 library (definitions in kernels.hip,
+// attention.hip, codec_kernels.hip).  All pointers are device pointers; all launches are async on `st`.
+#pragma once
+#include "common.hpp"
+
+// y[m][c] = LN(x[m][:]; eps, no affine)[c] * (1 + scale[r][c]) + shift[r][c],  r = mod_row0 + (m / rows_per_batch) * mod_rstride
+// (reference dit.py:19-25, 197-199, 35-39).  shift/scale are rows of the modulation table (ld = mod_ld).
+hipError_t launch_ln_modulate(const float* x, float* y, int M, int C, float eps, const float* shift,
+                              const float* scale, long mod_ld, int mod_row0, int mod_rstride, int rows_per_batch,
+                              hipStream_t st);
+
+// y[m][c] = x[m][c] * rsqrt(mean(x[m][:]^2) + eps) * w[c]   (reference dit.py:42-53, 1-D weight).
+// Rows are addressed through RowMaps so padded codec images can be normalised in place of a copy.
+hipError_t launch_rmsnorm(const float* x, RowMap xmap, float* y, RowMap ymap, int M, int C, float eps,
+                          const float* w, hipStream_t st);
+
+// In-place per-head RMSNorm of the cross-K cache [L][B][H][S][dh] with weights [L][H][dh] (dit.py:83).
+hipError_t launch_headnorm(float* k, int L, int B, int H, int S, int dh, float eps, const float* w, hipStream_t st);
+
+struct AttnArgs {
+    // self q/k/v/gate: element (b, n, h, d) at ptr[b*bs + n*rs + h*dh + d]
+    const float* q;
+    const float* k;
+    const float* v;
+    const float* gate;  // same addressing; out *= sigmoid(gate)
+    long bs, rs;
+    const float* qw;  // [H][dh] RMSNorm weights (q_norm / k_norm)
+    const float* kw;
+    float eps;
+    const float* rope;  // angles [pos][rot_dim] (a0 a0 a1 a1 ...), reference infer/onnx.py:42-47
+    int rot_dim;        // rotated leading dims (64 for DiT, dh for the encoders)
+    // cross keys (may be null / 0): [b][h][j][d] contiguous
+    const float* k_ref; const float* v_ref; int R;
+    const float* k_text; const float* v_text; int P;
+    const uint8_t* mask_self;  // [B][N]  key validity (may be null = all valid)
+    const uint8_t* mask_ref;   // [B][R]
+    const uint8_t* mask_text;  // [B][P]
+    float* out; long obs, ors;  // out (b, n, h*dh + d)
+    int B, N, H, dh;
+};
+hipError_t launch_attention(const AttnArgs& a, hipStream_t st);
+
+// out[m][:] = table[ids[m]][:]  (phonemes.py:201)
+hipError_t launch_embedding(const int64_t* ids, const float* table, float* out, int M, int C, int vocab, hipStream_t st);
+
+// e[r][i] = sin(1000 t[r] f_i) (i<128) | cos (i>=128), f_i = exp(-i ln(1e4)/127)   (model.py:23-28)
+hipError_t launch_time_sinusoid(const float* t, float* e, int rows, hipStream_t st);
+
+// mask[b][j] = j < min(len[b], R)   (style.py:155-162)
+hipError_t launch_len_mask(const int64_t* len, uint8_t* mask, int B, int R, hipStream_t st);
+
+// gm[(b*G+g)][pad + t][c] = mask[b][t] ? h[b][t][g*cpg + c] : 0 ; pad frames and c>=cpg are zero.
+hipError_t launch_convpos_pack(const float* h, const uint8_t* mask, float* gm, int B, int T, int G, int cpg,
+                               int pad, int gstride, hipStream_t st);
+
+// sampler element-wise steps (infer/onnx.py:105,125 ; teacher ODE see DESIGN.md)
+hipError_t launch_axpby(float* out, const float* x, const float* y, float a, float b, long n, hipStream_t st);
+// x0 = a*xt - s*v ; eps = s*xt + a*v ; xt_next = a2*x0 + s2*eps    (x0 written to x0_out)
+hipError_t launch_ode_step(float* xt, const float* v, float* x0_out, float a, float s, float a2, float s2, long n,
+                           hipStream_t st);
+// v = vc + st*(vc - vt) + ss*(vc - vs) over [3][n] stacked velocities (distill.py:101-105)
+hipError_t launch_cfg_combine(const float* v3, float* v, float s_text, float s_spk, long n, hipStream_t st);
+
+// Philox4x32-10 + Box-Muller standard normals; element i uses counter (i/4, stream, 0, 0), key (seed lo, hi).
+hipError_t launch_randn(float* out, long n, uint64_t seed, uint64_t stream, hipStream_t st);
+
+// synthetic weights (smalltts_amd/weights.py recipe, bit-exact)
+hipError_t launch_synth(float* out, long n, uint64_t key, float mean, float half_range, hipStream_t st);
+// fp32 -> bf16 hi/lo split with optional row permutation/packing: dst row r <- src row perm[r] (perm null = identity)
+hipError_t launch_split_rows(const float* src, long src_ld, bf16_t* hi, bf16_t* lo, long dst_ld, int rows, int cols,
+                             const int* perm, hipStream_t st);
+hipError_t launch_fill(float* p, float v, long n, hipStream_t st);
+hipError_t launch_copy_strided(const float* src, long sld, float* dst, long dld, int rows, int cols, hipStream_t st);
+// dst[n][k] (fp32, row-major N x K) = src[base + n1*sn1 + n0*sn0 + k1*sk1 + k0*sk0]  if k0 < k0valid else 0
+// with n1 = n / n0dim, n0 = n % n0dim, k1 = k / k0dim, k0 = k % k0dim.  Covers the conv->GEMM weight re-layouts.
+struct GatherSpec { long base, sn1, sn0, sk1, sk0; int n0dim, k0dim, k0valid; };
+hipError_t launch_gather_pack(const float* src, float* dst, int N, int K, GatherSpec g, hipStream_t st);
+// tab[pos][d] = pos * theta^(-(d & ~1)/dim)   pos < npos, d < dim   (rope angle tables; dit.py:138-149, style.py:13-18)
+hipError_t launch_rope_table(float* tab, int npos, int dim, hipStream_t st);
+
+// ---- codec element-wise kernels (channels-last padded images [B][pad + T][C]) -------------------
+// x[b][t][c] += gamma[c] * (sum_k w[c][k] * n[b][t - (K-1) + k][c] + bias[c])   (causal depthwise conv)
+hipError_t launch_dwconv_resid(float* x, const float* n, const float* w, const float* bias, const float* gamma,
+                               int B, int T, int C, int K, int pad, hipStream_t st);
+// audio[b][t] = bias + sum_{k,c} w[k][c] * x[b][t - (K-1) + k][c]    (head conv, Cout = 1)
+hipError_t launch_head_conv(const float* x, const float* w, float bias, float* audio, int B, int T, int C, int K,
+                            int pad, hipStream_t st);
+// x[b][pad+t][c] = bias[c] + sum_k w[c][k] * audio[b][t-(K-1)+k]   (encoder stem conv, Cin = 1)
+hipError_t launch_stem_conv1(const float* audio, const float* w, const float* bias, float* x, int B, int T, int C,
+                             int K, int pad, hipStream_t st);
+hipError_t launch_zero_pad_frames(float* x, int B, int T, int C, int pad, hipStream_t st);

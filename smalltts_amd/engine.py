@@ -1,0 +1,279 @@
+"""Python face of the gfx950 engine: torch-ROCm tensors in, raw HIP underneath.
+
+PyTorch is used only as the device allocator / stream owner; every operator goes through the
+C ABI of libsmalltts_hip.so (include/smalltts_hip.h).  One HipEngine per GPU.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Iterable, Optional
+
+import numpy as np
+import torch
+
+from . import _lib
+from .weights import (DEFAULT_CODEC, CodecSpec, codec_decoder_param_specs, codec_encoder_param_specs,
+                      dit_param_specs, init_rule, tensor_key)
+
+N_LAYERS, N_HEADS, HEAD_DIM, LATENT = 12, 8, 120, 64
+ACT = {"none": 0, "silu": 1, "gelu": 2, "mish": 3}
+PRECISION = {"bf16x3": 3, "bf16": 1}
+
+
+def _p(t: Optional[torch.Tensor]):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+class HipEngine:
+    def __init__(self, device: int = 0, precision: str = "bf16x3"):
+        if not torch.cuda.is_available():
+            raise RuntimeError("HipEngine needs a ROCm GPU (torch.cuda.is_available() is False)")
+        self.lib = _lib.load()
+        self.device_index = int(device)
+        self.device = torch.device("cuda", self.device_index)
+        h = C.c_void_p()
+        if self.lib.smtts_create(self.device_index, C.byref(h)) != 0:
+            raise RuntimeError("smtts_create: " + self.lib.smtts_last_error(None).decode())
+        self.h = h
+        self._ws: Optional[torch.Tensor] = None
+        self.codec_spec: CodecSpec = DEFAULT_CODEC
+        self.set_precision(precision)
+
+    # ---- plumbing ------------------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.smtts_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _ck(self, rc: int, what: str):
+        if rc != 0:
+            raise RuntimeError(f"{what}: {self.lib.smtts_last_error(self.h).decode()}")
+
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _workspace(self, nbytes: int) -> torch.Tensor:
+        if self._ws is None or self._ws.numel() < nbytes:
+            self._ws = None
+            self._ws = torch.empty(int(nbytes), dtype=torch.uint8, device=self.device)
+        return self._ws
+
+    def _dev(self, t, dtype) -> torch.Tensor:
+        if isinstance(t, np.ndarray):
+            t = torch.from_numpy(t)
+        return t.to(device=self.device, dtype=dtype).contiguous()
+
+    def set_precision(self, precision: str):
+        self.precision = precision
+        self._ck(self.lib.smtts_set_precision(self.h, PRECISION[precision]), "set_precision")
+
+    # ---- weights -------------------------------------------------------------------------------
+    def set_codec_spec(self, spec: CodecSpec):
+        self.codec_spec = spec
+        r = (C.c_int * len(spec.ratios))(*spec.ratios)
+        d = (C.c_int * len(spec.dec_depths))(*spec.dec_depths)
+        self._ck(self.lib.smtts_set_codec_spec(self.h, spec.latent_dim, spec.n_filters, spec.kernel, spec.ffn_mult,
+                                               spec.eps, r, len(spec.ratios), d), "set_codec_spec")
+
+    def set_tensor(self, name: str, arr):
+        if isinstance(arr, torch.Tensor):
+            t = arr.detach().to(torch.float32).contiguous()
+            on_dev = t.is_cuda
+            ptr, shape = t.data_ptr(), tuple(t.shape)
+        else:
+            t = np.ascontiguousarray(arr, dtype=np.float32)
+            on_dev, ptr, shape = False, t.ctypes.data, t.shape
+        sh = (C.c_int64 * max(1, len(shape)))(*shape)
+        self._ck(self.lib.smtts_set_tensor(self.h, name.encode(), C.c_void_p(ptr), sh, len(shape), int(on_dev)),
+                 f"set_tensor({name})")
+
+    def load_state_dict(self, sd: Dict[str, object]):
+        for k, v in sd.items():
+            self.set_tensor(k, v)
+
+    def load_synthetic(self, seed: int, parts: Iterable[str] = ("dit", "decoder", "encoder"),
+                       codec_spec: Optional[CodecSpec] = None):
+        """Fill weights on the GPU with the seeded recipe of weights.py (bit-identical to numpy)."""
+        spec = codec_spec or self.codec_spec
+        specs = []
+        if "dit" in parts:
+            specs += dit_param_specs()
+        if "decoder" in parts or "encoder" in parts:
+            self.set_codec_spec(spec)
+        if "decoder" in parts:
+            specs += codec_decoder_param_specs(spec)
+        if "encoder" in parts:
+            specs += codec_encoder_param_specs(spec)
+        for name, shape in specs:
+            mean, hr = init_rule(name, shape)
+            sh = (C.c_int64 * max(1, len(shape)))(*shape)
+            self._ck(self.lib.smtts_synth_tensor(self.h, name.encode(), sh, len(shape),
+                                                 C.c_uint64(tensor_key(name, seed)), mean, hr), f"synth({name})")
+
+    def get_tensor(self, name: str, shape) -> np.ndarray:
+        out = np.empty(shape, dtype=np.float32)
+        self._ck(self.lib.smtts_get_tensor(self.h, name.encode(), C.c_void_p(out.ctypes.data), out.size), "get_tensor")
+        return out
+
+    def finalize(self):
+        self._ck(self.lib.smtts_finalize(self.h), "finalize")
+
+    def has(self, part: str) -> bool:
+        return bool(self.lib.smtts_has_part(self.h, {"dit": 0, "decoder": 1, "encoder": 2}[part]))
+
+    # ---- operators -----------------------------------------------------------------------------
+    def cond_encode(self, ref, ref_len, ids, ph_mask, debug: bool = False) -> Dict[str, torch.Tensor]:
+        """(ref (B,R,64), ref_len (B,), ids (B,P), ph_mask (B,P)) -> cross-KV cache
+        (reference operator: condition_encoder.onnx, infer/onnx.py:91-96)."""
+        ref = self._dev(ref, torch.float32)
+        ref_len = self._dev(ref_len, torch.int64)
+        ids = self._dev(ids, torch.int64)
+        ph_mask = self._dev(ph_mask, torch.bool)
+        B, R, _ = ref.shape
+        P = ids.shape[1]
+        dev = self.device
+        out = {
+            "k_ref": torch.empty(N_LAYERS, B, N_HEADS, R, HEAD_DIM, device=dev),
+            "v_ref": torch.empty(N_LAYERS, B, N_HEADS, R, HEAD_DIM, device=dev),
+            "ref_mask": torch.zeros(B, R, dtype=torch.bool, device=dev),
+            "k_text": torch.empty(N_LAYERS, B, N_HEADS, P, HEAD_DIM, device=dev),
+            "v_text": torch.empty(N_LAYERS, B, N_HEADS, P, HEAD_DIM, device=dev),
+            "ph_mask": ph_mask,
+        }
+        if debug:
+            out["ref_seq"] = torch.empty(B, R, 960, device=dev)
+            out["phoneme_mem"] = torch.empty(B, P, 960, device=dev)
+        nb = self.lib.smtts_cond_workspace_bytes(self.h, B, R, P)
+        ws = self._workspace(nb)
+        self._ck(self.lib.smtts_cond_encode(self.h, self._stream(), _p(ref), _p(ref_len), _p(ids), _p(ph_mask), B, R, P,
+                                            _p(out["k_ref"]), _p(out["v_ref"]), _p(out["ref_mask"]), _p(out["k_text"]),
+                                            _p(out["v_text"]), _p(ws), ws.numel(), _p(out.get("ref_seq")),
+                                            _p(out.get("phoneme_mem"))), "cond_encode")
+        return out
+
+    def denoise_step(self, x_t, mask, t, cache, rope=None) -> torch.Tensor:
+        """velocity = denoiser(x_t, mask, t, cache...) (reference operator: denoiser.onnx, infer/onnx.py:107-124)."""
+        x_t = self._dev(x_t, torch.float32)
+        mask = self._dev(mask, torch.bool)
+        t = self._dev(t, torch.float32)
+        rope = None if rope is None else self._dev(rope, torch.float32)
+        B, N, _ = x_t.shape
+        R, P = cache["k_ref"].shape[3], cache["k_text"].shape[3]
+        v = torch.empty_like(x_t)
+        ws = self._workspace(self.lib.smtts_denoise_workspace_bytes(self.h, B, N))
+        self._ck(self.lib.smtts_denoise_step(self.h, self._stream(), _p(x_t), _p(mask), _p(t), _p(cache["k_ref"]),
+                                             _p(cache["v_ref"]), _p(cache["ref_mask"]), _p(cache["k_text"]),
+                                             _p(cache["v_text"]), _p(cache["ph_mask"]), _p(rope), B, N, R, P, _p(v),
+                                             _p(ws), ws.numel()), "denoise_step")
+        return v
+
+    def sample(self, cache, mask, num_steps: int = 4, mode: str = "dmd", cfg: bool = False, s_text: float = 2.0,
+               s_spk: float = 1.5, noise=None, seed: int = 0, return_steps: bool = False):
+        """Runs the whole sampler on the GPU. mask: (B,N) (cfg: rows are replicated x3 internally)."""
+        mask = self._dev(mask, torch.bool)
+        B, N = mask.shape
+        rows = cache["k_ref"].shape[1]
+        if cfg:
+            assert rows == 3 * B, "cfg sampling needs a 3B-row condition cache"
+            mask_in = mask.repeat(3, 1).contiguous()
+        else:
+            assert rows == B
+            mask_in = mask
+        R, P = cache["k_ref"].shape[3], cache["k_text"].shape[3]
+        noise = None if noise is None else self._dev(noise, torch.float32)
+        if noise is not None:
+            want = (num_steps, B, N, LATENT) if mode == "dmd" else (B, N, LATENT)
+            assert tuple(noise.shape) == want, f"noise shape {tuple(noise.shape)} != {want}"
+        x = torch.empty(B, N, LATENT, device=self.device)
+        steps = torch.empty(num_steps, B, N, LATENT, device=self.device) if return_steps else None
+        ws = self._workspace(self.lib.smtts_sample_workspace_bytes(self.h, B, N, num_steps, int(cfg)))
+        self._ck(self.lib.smtts_sample(self.h, self._stream(), {"dmd": 0, "ode": 1}[mode], num_steps, int(cfg), s_text,
+                                       s_spk, _p(mask_in), _p(cache["k_ref"]), _p(cache["v_ref"]),
+                                       _p(cache["ref_mask"]), _p(cache["k_text"]), _p(cache["v_text"]),
+                                       _p(cache["ph_mask"]), B, N, R, P, _p(noise), C.c_uint64(seed), _p(x), _p(steps),
+                                       _p(ws), ws.numel()), "sample")
+        return (x, steps) if return_steps else x
+
+    @property
+    def hop(self) -> int:
+        return int(self.lib.smtts_codec_hop(self.h))
+
+    def codec_decode(self, latents) -> torch.Tensor:
+        """(B,T,64) -> (B,1,hop*T) (reference operator: codec/decoder.onnx, codec/onnx.py:42-53)."""
+        lat = self._dev(latents, torch.float32)
+        B, T, _ = lat.shape
+        audio = torch.empty(B, 1, self.hop * T, device=self.device)
+        ws = self._workspace(self.lib.smtts_decode_workspace_bytes(self.h, B, T))
+        self._ck(self.lib.smtts_codec_decode(self.h, self._stream(), _p(lat), B, T, _p(audio), _p(ws), ws.numel()),
+                 "codec_decode")
+        return audio
+
+    def codec_encode(self, audio) -> torch.Tensor:
+        """(B,1,S) -> (B,S//hop,64) (reference operator: codec/encoder.onnx, codec/onnx.py:64-75)."""
+        a = self._dev(audio, torch.float32)
+        B, _, S = a.shape
+        T = S // self.hop
+        S_use = T * self.hop
+        if S_use != S:
+            a = a[:, :, :S_use].contiguous()
+        lat = torch.empty(B, T, LATENT, device=self.device)
+        if T == 0:
+            return lat
+        ws = self._workspace(self.lib.smtts_encode_workspace_bytes(self.h, B, S_use))
+        self._ck(self.lib.smtts_codec_encode(self.h, self._stream(), _p(a), B, S_use, _p(lat), _p(ws), ws.numel()),
+                 "codec_encode")
+        return lat
+
+    def randn(self, n: int, seed: int, stream_id: int = 0) -> torch.Tensor:
+        out = torch.empty(n, device=self.device)
+        self._ck(self.lib.smtts_randn(self.h, self._stream(), _p(out), n, C.c_uint64(seed), C.c_uint64(stream_id)), "randn")
+        return out
+
+    def alpha_sigma(self, t: float):
+        a, s = C.c_float(), C.c_float()
+        self.lib.smtts_alpha_sigma(C.c_float(t), C.byref(a), C.byref(s))
+        return a.value, s.value
+
+    # ---- single-kernel hooks (tests) -------------------------------------------------------------
+    def test_gemm(self, A, W, bias=None, act="none", split=3, cfg=-1):
+        A = self._dev(A, torch.float32)
+        W = self._dev(W, torch.float32)
+        bias = None if bias is None else self._dev(bias, torch.float32)
+        M, K = A.shape
+        N = W.shape[0]
+        out = torch.empty(M, N, device=self.device)
+        self._ck(self.lib.smtts_test_gemm(self.h, self._stream(), _p(A), K, _p(W), _p(bias), M, N, K, ACT[act], split,
+                                          cfg, _p(out), N), "test_gemm")
+        return out
+
+    def test_swiglu(self, A, W1, W3, b1=None, b3=None, split=3):
+        A, W1, W3 = (self._dev(x, torch.float32) for x in (A, W1, W3))
+        b1 = None if b1 is None else self._dev(b1, torch.float32)
+        b3 = None if b3 is None else self._dev(b3, torch.float32)
+        M, K = A.shape
+        F = W1.shape[0]
+        out = torch.empty(M, F, device=self.device)
+        self._ck(self.lib.smtts_test_swiglu(self.h, self._stream(), _p(A), _p(W1), _p(W3), _p(b1), _p(b3), M, F, K,
+                                            split, _p(out)), "test_swiglu")
+        return out
+
+    def test_attention(self, qkvg, qw, kw, eps, rope, rot_dim, H, dh, k_ref=None, v_ref=None, k_text=None, v_text=None,
+                       mask_self=None, mask_ref=None, mask_text=None):
+        qkvg = self._dev(qkvg, torch.float32)
+        B, N, _ = qkvg.shape
+        f = lambda x, dt=torch.float32: None if x is None else self._dev(x, dt)
+        qw, kw, rope, k_ref, v_ref, k_text, v_text = map(f, (qw, kw, rope, k_ref, v_ref, k_text, v_text))
+        mask_self, mask_ref, mask_text = (f(m, torch.bool) for m in (mask_self, mask_ref, mask_text))
+        R = 0 if k_ref is None else k_ref.shape[2]
+        P = 0 if k_text is None else k_text.shape[2]
+        out = torch.empty(B, N, H * dh, device=self.device)
+        self._ck(self.lib.smtts_test_attention(self.h, self._stream(), _p(qkvg), _p(qw), _p(kw), eps, _p(rope), rot_dim,
+                                               _p(k_ref), _p(v_ref), R, _p(k_text), _p(v_text), P, _p(mask_self),
+                                               _p(mask_ref), _p(mask_text), B, N, H, dh, _p(out)), "test_attention")
+        return out

@@ -1,0 +1,149 @@
+"""GPU parity of the DiT hot path (cond-encode, denoiser, samplers) through the C ABI against
+(a) golden vectors recorded from the reference's own PyTorch modules and (b) the CPU oracle on
+seeded inputs.  Tolerance: latent relative L2 < 1e-3 is the north-star bound; the split-bf16 path
+is held to 1e-4 here so regressions show long before the bound."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import dit_oracle as O
+from tests.conftest import golden, rel_l2
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4          # split-bf16 engine vs fp32 reference, rel L2
+NORTH_STAR = 1e-3
+
+
+@pytest.fixture(scope="module")
+def eng(golden_seed):
+    from smalltts_amd.engine import HipEngine
+    e = HipEngine(0)
+    e.load_synthetic(golden_seed, parts=("dit",))
+    e.finalize()
+    assert e.has("dit")
+    return e
+
+
+def test_device_weights_match_numpy_recipe(eng, dit_weights_np):
+    for name in ("dit.transformer_blocks.7.attn.to_out.0.weight", "style_encoder.blocks.3.mlp.w2.weight",
+                 "phoneme_embedding.text_embedding.weight", "dit.norm_out.linear.bias"):
+        w = dit_weights_np[name]
+        assert np.array_equal(eng.get_tensor(name, w.shape), w), name
+
+
+def _valid(got, ref, km):
+    sel = np.broadcast_to(km[:, None, :, None], got.shape)
+    return rel_l2(got[sel], ref[sel])
+
+
+@pytest.mark.parametrize("case", ["small", "cfgrows", "bench1"])
+def test_cond_encode_and_denoise_vs_reference_golden(eng, case):
+    g = golden(f"case_{case}.npz")
+    cache = eng.cond_encode(g["ref"], g["ref_len"], g["ids"], g["ph_mask"], debug=True)
+    torch.cuda.synchronize()
+    assert np.array_equal(cache["ref_mask"].cpu().numpy(), g["ref_mask"])
+    assert rel_l2(cache["ref_seq"].cpu().numpy(), g["ref_seq"]) < TOL
+    for key in [k for k in g if k.startswith("L")]:
+        li, name = key[1:].split("_", 1)
+        km = g["ref_mask"] if name.endswith("ref") else g["ph_mask"]
+        err = _valid(cache[name][int(li)].cpu().numpy(), g[key], km)
+        assert err < TOL, f"{key}: {err:.3e}"
+    rope = O.rope_angles(g["x_t"].shape[1]).numpy()
+    for rp in (rope, None):  # caller-supplied angles (reference operator input) and the internal table
+        v = eng.denoise_step(g["x_t"], g["mask"], g["t"], cache, rope=rp).cpu().numpy()
+        m = g["mask"]
+        err = rel_l2(v[m], g["velocity"][m])
+        assert err < TOL, f"velocity ({'rope arg' if rp is not None else 'internal rope'}): {err:.3e}"
+
+
+def test_sampler4_vs_reference_golden(eng):
+    g = golden("case_sampler4.npz")
+    B, N = g["noise"].shape[1:3]
+    P = g["ids"].shape[1]
+    cache = eng.cond_encode(g["ref"], np.array([g["ref"].shape[1]]), g["ids"], np.ones((B, P), bool))
+    x, steps = eng.sample(cache, np.ones((B, N), bool), num_steps=4, noise=g["noise"], return_steps=True)
+    steps = steps.cpu().numpy()
+    for i in range(4):
+        err = rel_l2(steps[i], g["x_pred_steps"][i])
+        assert err < TOL, f"step {i}: {err:.3e}"
+    assert rel_l2(x.cpu().numpy(), g["x_pred_steps"][-1]) < TOL
+
+
+def _bench_inputs(B=8, N=75, R=15, P=30, seed=0):
+    gen = torch.Generator().manual_seed(seed)
+    ref = torch.randn(B, R, 64, generator=gen)
+    ids = torch.arange(1, P + 1)[None].repeat(B, 1)
+    noise = torch.randn(4, B, N, 64, generator=gen)
+    return ref, torch.full((B,), R), ids, torch.ones(B, P, dtype=torch.bool), torch.ones(B, N, dtype=torch.bool), noise
+
+
+def test_full_bench_shape_vs_oracle(eng, dit_weights):
+    """configs[1] of BASELINE.json: B=8 x 10 s (N=75), R=15, P=30, 4 DMD steps."""
+    ref, ref_len, ids, pm, mask, noise = _bench_inputs()
+    with torch.no_grad():
+        oc = O.encode_conditions(dit_weights, ref, ref_len, ids, pm)
+        ox = O.sample_dmd(dit_weights, oc, pm, mask, noise, 4)
+    cache = eng.cond_encode(ref, ref_len, ids, pm)
+    x = eng.sample(cache, mask, num_steps=4, noise=noise).cpu().numpy()
+    err = rel_l2(x, ox.numpy())
+    assert err < TOL, f"latent rel L2 {err:.3e}"
+    # plain-bf16 mode: report its error against the north-star bound without hiding it
+    eng.set_precision("bf16")
+    try:
+        cache1 = eng.cond_encode(ref, ref_len, ids, pm)
+        x1 = eng.sample(cache1, mask, num_steps=4, noise=noise).cpu().numpy()
+    finally:
+        eng.set_precision("bf16x3")
+    e1 = rel_l2(x1, ox.numpy())
+    print(f"\n[precision] split-bf16 latent rel L2 = {err:.3e} ; single-pass bf16 = {e1:.3e} (bound {NORTH_STAR})")
+    assert e1 < 5e-2
+
+
+def test_ragged_batch_equals_per_utterance(eng):
+    """A1 (infer/onnx.py:131-159): padded batch == per-utterance results on the valid frames."""
+    gen = torch.Generator().manual_seed(3)
+    lens = [(9, 6, 20), (4, 11, 13), (7, 3, 17)]  # (R, P, N) per utterance
+    Rm, Pm, Nm = (max(l[i] for l in lens) for i in range(3))
+    B = len(lens)
+    ref = torch.zeros(B, Rm, 64); ids = torch.zeros(B, Pm, dtype=torch.int64)
+    pm = torch.zeros(B, Pm, dtype=torch.bool); mask = torch.zeros(B, Nm, dtype=torch.bool)
+    noise = torch.randn(4, B, Nm, 64, generator=gen)
+    for b, (r, p, n) in enumerate(lens):
+        ref[b, :r] = torch.randn(r, 64, generator=gen)
+        ids[b, :p] = torch.randint(1, 198, (p,), generator=gen)
+        pm[b, :p] = True; mask[b, :n] = True
+    rl = torch.tensor([l[0] for l in lens])
+    xb = eng.sample(eng.cond_encode(ref, rl, ids, pm), mask, noise=noise).cpu()
+    for b, (r, p, n) in enumerate(lens):
+        c1 = eng.cond_encode(ref[b:b + 1, :r], rl[b:b + 1], ids[b:b + 1, :p], pm[b:b + 1, :p])
+        x1 = eng.sample(c1, mask[b:b + 1, :n], noise=noise[:, b:b + 1, :n].contiguous()).cpu()
+        err = rel_l2(xb[b, :n].numpy(), x1[0].numpy())
+        assert err < 2e-5, f"utterance {b}: {err:.3e}"
+
+
+def test_teacher_ode_cfg_vs_oracle(eng, dit_weights):
+    """S2 (build-defined): deterministic ODE + CFG (distill.py:60-134), 6 steps here; 128 in bench."""
+    gen = torch.Generator().manual_seed(5)
+    B, N, R, P, steps = 2, 16, 6, 9, 6
+    ref = torch.randn(B, R, 64, generator=gen)
+    ids = torch.randint(1, 198, (B, P), generator=gen)
+    pm = torch.ones(B, P, dtype=torch.bool); rl = torch.full((B,), R)
+    mask = torch.ones(B, N, dtype=torch.bool)
+    noise = torch.randn(B, N, 64, generator=gen)
+    ref3, len3, ids3, pm3 = O.cfg_conditions(ref, rl, ids, pm)
+    with torch.no_grad():
+        oc = O.encode_conditions(dit_weights, ref3, len3, ids3, pm3)
+        ox = O.sample_teacher_ode(dit_weights, oc, pm3, mask, noise, steps)
+    cache3 = eng.cond_encode(ref3, len3, ids3, pm3)
+    x = eng.sample(cache3, mask, num_steps=steps, mode="ode", cfg=True, noise=noise).cpu().numpy()
+    err = rel_l2(x, ox.numpy())
+    assert err < 5 * TOL, f"teacher ODE rel L2 {err:.3e}"
+
+
+def test_on_device_noise_is_seeded_and_reproducible(eng):
+    ref, ref_len, ids, pm, mask, _ = _bench_inputs(B=2, N=20)
+    cache = eng.cond_encode(ref, ref_len, ids, pm)
+    a = eng.sample(cache, mask, seed=11).cpu()
+    b = eng.sample(cache, mask, seed=11).cpu()
+    c = eng.sample(cache, mask, seed=12).cpu()
+    assert torch.equal(a, b) and not torch.equal(a, c) and torch.isfinite(a).all()
