@@ -1,0 +1,195 @@
+#!/usr/bin/env python
+"""Headline benchmark: audio-seconds/sec of the full synthesis hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run)
+
+One "step" = one pass of the hot path over one batch per GPU: condition-encode -> 4-step DMD sampler
+-> codec decode of B=8 utterances x 10 s (N=75 frames, R=15 reference frames, P=30 phoneme ids:
+BASELINE.json configs[1], workload of the reference's src/server/src/bin/bench.rs:3-25), inputs
+already resident in HBM, synthetic seeded weights (no released weights exist offline).  With N GPUs
+every rank synthesises its own 8-utterance shard (weak scaling, no data-path collective) and the
+waveform shards are reassembled with one RCCL all-gather inside the timed step.
+
+Rank 0 prints ONE JSON line (contract in the task statement) including
+  roofline     : dominant kernel, algorithmic work / HIP-event time measured live on the launch stream
+  cpu_baseline : the CPU oracle (stand-in for the reference's ORT-CPU path, which cannot run offline)
+                 timed on this box's host cores on a bounded sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+B, N_FRAMES, R_FRAMES, P_TOK, DMD_STEPS = 8, 75, 15, 30, 4
+AUDIO_SEC_PER_UTT = N_FRAMES * 3200 / 24000.0  # 10.0
+SEED = 20260928
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8 TB/s spec
+MFMA_BF16_PEAK_TF = 2500.0   # dense bf16
+
+
+def make_inputs(device, rank):
+    g = torch.Generator().manual_seed(1000 + rank)
+    ref = torch.randn(B, R_FRAMES, 64, generator=g)
+    ids = torch.arange(1, P_TOK + 1)[None].repeat(B, 1)
+    d = dict(ref=ref, ref_len=torch.full((B,), R_FRAMES, dtype=torch.int64), ids=ids,
+             ph_mask=torch.ones(B, P_TOK, dtype=torch.bool), mask=torch.ones(B, N_FRAMES, dtype=torch.bool))
+    return {k: v.to(device) for k, v in d.items()}
+
+
+def one_step(eng, inp, seed, gather=None):
+    cache = eng.cond_encode(inp["ref"], inp["ref_len"], inp["ids"], inp["ph_mask"])
+    x = eng.sample(cache, inp["mask"], num_steps=DMD_STEPS, seed=seed)
+    audio = eng.codec_decode(x)
+    if gather is not None:
+        import torch.distributed as dist
+        dist.all_gather_into_tensor(gather, audio)
+        return gather
+    return audio
+
+
+def cpu_baseline(cores):
+    """Oracle on the host cores: DiT part on the full 8 x 10 s batch, codec on 1 of the 8 utterances
+    (x8), so the leg stays ~10-30 s. kind = "port": the reference's ORT path cannot run offline."""
+    from oracle import codec_oracle as CO
+    from oracle import dit_oracle as O
+    from smalltts_amd.weights import DEFAULT_CODEC, codec_decoder_param_specs, dit_param_specs, synth_state_dict
+    torch.set_num_threads(cores)
+    w = O.to_torch(synth_state_dict(dit_param_specs(), SEED))
+    wd = O.to_torch(synth_state_dict(codec_decoder_param_specs(DEFAULT_CODEC), SEED))
+    g = torch.Generator().manual_seed(1000)
+    ref = torch.randn(B, R_FRAMES, 64, generator=g)
+    ids = torch.arange(1, P_TOK + 1)[None].repeat(B, 1)
+    pm = torch.ones(B, P_TOK, dtype=torch.bool)
+    mask = torch.ones(B, N_FRAMES, dtype=torch.bool)
+    noise = torch.randn(DMD_STEPS, B, N_FRAMES, 64, generator=g)
+    with torch.no_grad():
+        t0 = time.perf_counter()
+        cache = O.encode_conditions(w, ref, torch.full((B,), R_FRAMES), ids, pm)
+        x = O.sample_dmd(w, cache, pm, mask, noise, DMD_STEPS)
+        t_dit = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        CO.decode(wd, x[:1], DEFAULT_CODEC)
+        t_dec1 = time.perf_counter() - t0
+    total = t_dit + B * t_dec1
+    return {"value": round(B * AUDIO_SEC_PER_UTT / total, 3), "unit": "audio-seconds/sec", "cores": cores,
+            "kind": "port",
+            "sample": f"CPU oracle (torch fp32): cond-encode + 4 DMD steps on the full 8x10s batch ({t_dit:.2f} s) + "
+                      f"codec decode of 1 of 8 utterances ({t_dec1:.2f} s, scaled x8); stands in for the reference's "
+                      "ORT-CPU path, which cannot run offline",
+            "dit_seconds": round(t_dit, 3), "codec_decode_seconds_per_utt": round(t_dec1, 3)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--precision", default="bf16x3", choices=["bf16x3", "bf16"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    n_gpus = world if world > 1 else 1
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+
+    from smalltts_amd.engine import HipEngine
+    eng = HipEngine(local, args.precision)
+    eng.load_synthetic(SEED, parts=("dit", "decoder"))
+    eng.finalize()
+    inp = make_inputs(device, rank)
+    gather = torch.empty(world * B, 1, 3200 * N_FRAMES, device=device) if world > 1 else None
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        one_step(eng, inp, i, gather)
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        out = one_step(eng, inp, 100 + i, gather)
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        tmax = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    assert torch.isfinite(out).all()
+
+    audio_s = n_gpus * B * AUDIO_SEC_PER_UTT * args.steps
+    res = {
+        "metric": "audio-seconds/sec (RTF) at batch=8, 10 s utterances; 1->8 GPU scaling",
+        "value": round(audio_s / dt, 2), "unit": "audio-seconds/sec", "n_gpus": n_gpus, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None,
+        "dtype": "bf16 MFMA x3 split (fp32-class), fp32 accumulate/residual" if args.precision == "bf16x3" else "bf16",
+        "data": "synthetic (seeded inputs + seeded random weights; no released weights offline)",
+        "rtf": round(dt / audio_s, 7),
+        "config": {"workload": "cond-encode + 4-step DMD sampler + codec decode, B=8 x 10 s per GPU "
+                               "(N=75 frames, R=15 ref frames, P=30 tokens; reference bench.rs workload)",
+                   "global_batch": n_gpus * B, "utterance_seconds": AUDIO_SEC_PER_UTT, "sampler_steps": DMD_STEPS,
+                   "parallelism": f"dp{n_gpus} (utterance shards, waveform all-gather)" if n_gpus > 1 else "single GPU"},
+    }
+
+    if rank == 0 and not args.no_roofline:
+        # per-kernel HIP-event timing on the launch stream, separate (untimed) passes
+        eng.profile(True)
+        reps = 3
+        for i in range(reps):
+            one_step(eng, inp, 900 + i, None)
+        torch.cuda.synchronize()
+        rows = eng.profile_report()
+        eng.profile(False)
+        rows.sort(key=lambda r: -r["ms"])
+        tot = sum(r["ms"] for r in rows)
+        top = rows[0]
+        per = top["ms"] / top["launches"] * 1e-3
+        tf = top["flops"] / top["launches"] / per / 1e12
+        gbs = top["bytes"] / top["launches"] / per / 1e9
+        mfma_frac, hbm_frac = tf / MFMA_BF16_PEAK_TF, gbs / HBM_PEAK_GBS
+        bound = "mfma" if mfma_frac >= hbm_frac else "hbm"
+        res["roofline"] = {
+            "kernel": top["name"], "bound": bound,
+            "achieved": round(tf if bound == "mfma" else gbs, 3),
+            "peak": MFMA_BF16_PEAK_TF if bound == "mfma" else HBM_PEAK_GBS,
+            "unit": "TFLOP/s" if bound == "mfma" else "GB/s",
+            "frac": round(max(mfma_frac, hbm_frac), 5), "traffic": None,
+            "avg_launch_us": round(per * 1e6, 3), "launches_per_step": top["launches"] // reps,
+            "share_of_kernel_time": round(top["ms"] / tot, 4),
+            "note": "algorithmic flops (2MNK, counted once, not x3 for the split) and bytes per launch / HIP-event time",
+        }
+        res["kernel_breakdown"] = [
+            {"name": r["name"], "launches_per_step": r["launches"] // reps, "ms_per_step": round(r["ms"] / reps, 4),
+             "TFLOPs": round(r["flops"] / max(r["ms"], 1e-9) / 1e9, 2), "GBs": round(r["bytes"] / max(r["ms"], 1e-9) / 1e6, 1)}
+            for r in rows[:12]]
+    if rank == 0 and n_gpus == 1 and not args.no_cpu_baseline:
+        res["cpu_baseline"] = cpu_baseline(os.cpu_count() or 1)
+    if rank == 0:
+        print(json.dumps(res))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

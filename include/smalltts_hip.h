@@ -102,6 +102,11 @@ int smtts_randn(smtts_handle h, void* stream, float* out, int64_t n, uint64_t se
 /* (alpha, sigma) of the reference schedule for t (infer/onnx.py:31-39); host-side, float64 math */
 void smtts_alpha_sigma(float t, float* alpha, float* sigma);
 
+/* per-kernel HIP-event timing on the launch stream (bench.py roofline): enable, run, then read a JSON array
+ * [{"name","launches","ms","flops","bytes"}] of algorithmic work and measured time per kernel class */
+int smtts_profile_enable(smtts_handle h, int on);
+int smtts_profile_report(smtts_handle h, char* buf, size_t cap);
+
 /* ---- single-kernel test hooks (used by tests/ to check kernels in isolation) -------------------- */
 /* C[M,N] = A[M,K] (f32, lda) * W[N,K]^T (f32 host-layout on device, split internally) + bias ; act as ACT_* */
 int smtts_test_gemm(smtts_handle h, void* stream, const float* A, int lda, const float* W, const float* bias, int M,

@@ -1,0 +1,181 @@
+"""Drop-in Python API of the reference (`smalltts.SmallTTS`, `estimate_duration`, codec `Encoder` /
+`Decoder`) on top of the gfx950 engine.
+
+Mirrors reference `src/smalltts/infer/onnx.py` (class SmallTTS :50-159, constants :11-14,
+estimate_duration :17-18) and `src/smalltts/codec/onnx.py` (Encoder/Decoder :34-75): same positional
+arguments, argument meaning, return types and error-by-exception behaviour.  The three ONNX path
+arguments are accepted for call compatibility; weights come from `weights=` (keyword-only
+addition): a flat weight file written by `smalltts_amd.weights.save_weight_file`, a torch
+checkpoint holding the reference's state_dict (optionally under "student_model",
+distill.py:468-479), or "synthetic:<seed>" (seeded random weights — there are no released weights
+offline).  Unlike the reference, `forward` runs all utterances as ONE padded batch on the GPU.
+"""
+from __future__ import annotations
+
+import os
+from typing import Dict, Iterable, List, Optional, Sequence
+
+import numpy as np
+import torch
+
+from .engine import HipEngine
+from .weights import DEFAULT_CODEC, CodecSpec, clean_state_dict_keys, load_weight_file
+
+SAMPLE_RATE = 24_000
+HOP_SIZE = 3_200
+NUM_STEPS = 4
+CHARS_PER_SECOND = 11.5
+DEFAULT_WEIGHTS = os.environ.get("SMALLTTS_WEIGHTS", "assets/smalltts.smtts")
+
+_ENGINES: Dict[tuple, HipEngine] = {}
+
+
+def estimate_duration(text: str, min_sec: float = 0.5, max_sec: float = 30.0) -> float:
+    return max(min_sec, min(len(text) / CHARS_PER_SECOND, max_sec))
+
+
+def _load_weights_into(eng: HipEngine, weights: str, parts: Sequence[str]) -> None:
+    if weights.startswith("synthetic"):
+        seed = int(weights.split(":", 1)[1]) if ":" in weights else 0
+        eng.load_synthetic(seed, parts=parts)
+    elif weights.endswith((".pt", ".pth", ".ckpt")):
+        ck = torch.load(weights, map_location="cpu")
+        for key in ("student_model", "model"):
+            if isinstance(ck, dict) and key in ck:
+                ck = ck[key]
+        eng.load_state_dict({k: v for k, v in clean_state_dict_keys(ck).items() if hasattr(v, "shape")})
+    else:
+        if not os.path.exists(weights):
+            raise FileNotFoundError(
+                f"weight file {weights!r} not found. The reference downloads its ONNX weights from HuggingFace "
+                "(assets/ensure.py); offline, pass weights='synthetic:<seed>' or a converted weight file.")
+        tensors, codec = load_weight_file(weights)
+        if codec:
+            eng.set_codec_spec(CodecSpec(**codec))
+        eng.load_state_dict(tensors)
+    eng.finalize()
+
+
+def get_engine(weights: Optional[str] = None, device: int = 0, precision: str = "bf16x3",
+               parts: Sequence[str] = ("dit", "decoder", "encoder")) -> HipEngine:
+    """One engine (one weight copy) per (weights, device, parts); shared by SmallTTS/Encoder/Decoder."""
+    weights = weights or DEFAULT_WEIGHTS
+    key = (weights, int(device), tuple(sorted(parts)))
+    eng = _ENGINES.get(key)
+    if eng is None:
+        eng = HipEngine(device, precision)
+        _load_weights_into(eng, weights, parts)
+        _ENGINES[key] = eng
+    if eng.precision != precision:
+        eng.set_precision(precision)
+    return eng
+
+
+def _frames(duration_sec: float) -> int:
+    return max(1, int(duration_sec * SAMPLE_RATE / HOP_SIZE))  # floor, infer/onnx.py:84
+
+
+class SmallTTS:
+    """DMD few-step synthesis: condition-encode -> n-step sampler -> codec decode, all on one MI355X."""
+
+    def __init__(self, cond_encoder_path: str = "assets/dmd/condition_encoder.onnx",
+                 denoiser_path: str = "assets/dmd/denoiser.onnx",
+                 codec_decoder_path: str = "assets/codec/decoder.onnx",
+                 providers: Optional[Iterable[str]] = None, *, weights: Optional[str] = None, device: int = 0,
+                 precision: str = "bf16x3", num_steps: int = NUM_STEPS, seed: Optional[int] = None,
+                 engine: Optional[HipEngine] = None) -> None:
+        self.engine = engine or get_engine(weights, device, precision, parts=("dit", "decoder", "encoder"))
+        if not (self.engine.has("dit") and self.engine.has("decoder")):
+            raise RuntimeError("SmallTTS needs DiT and codec-decoder weights")
+        self.num_steps = int(num_steps)
+        self._rng = np.random.default_rng(seed) if seed is not None else None
+
+    def _next_seed(self) -> int:
+        # the reference draws noise from numpy's global RNG (infer/onnx.py:104); seeding numpy (or seed=)
+        # therefore makes runs reproducible here too, while the normals themselves come from the GPU
+        if self._rng is not None:
+            return int(self._rng.integers(0, 2 ** 63 - 1))
+        return int(np.random.randint(0, 2 ** 31 - 1)) * 2654435761 % (2 ** 63)
+
+    def synthesize_batch(self, ref_latents: Sequence[np.ndarray], phoneme_ids: Sequence[Sequence[int]],
+                         durations, *, noise: Optional[np.ndarray] = None, return_latents: bool = False):
+        """Batched synthesize: per-utterance (R_i,64) refs, token lists and durations -> list of (1, samples)."""
+        B = len(ref_latents)
+        if B == 0:
+            return []
+        if np.isscalar(durations):
+            durations = [float(durations)] * B
+        ns = [_frames(d) for d in durations]
+        rs = [int(np.asarray(r).shape[0]) for r in ref_latents]
+        ps = [len(p) for p in phoneme_ids]
+        Rm, Pm, Nm = max(max(rs), 1), max(max(ps), 1), max(ns)
+        ref = np.zeros((B, Rm, 64), np.float32)
+        ids = np.zeros((B, Pm), np.int64)
+        pm = np.zeros((B, Pm), bool)
+        mask = np.zeros((B, Nm), bool)
+        for b in range(B):
+            ref[b, :rs[b]] = np.asarray(ref_latents[b], np.float32)
+            ids[b, :ps[b]] = np.asarray(list(phoneme_ids[b]), np.int64)
+            pm[b, :ps[b]] = True
+            mask[b, :ns[b]] = True
+        eng = self.engine
+        cache = eng.cond_encode(ref, np.asarray(rs, np.int64), ids, pm)
+        x = eng.sample(cache, mask, num_steps=self.num_steps, noise=noise, seed=self._next_seed())
+        audio = eng.codec_decode(x)                           # (B, 1, HOP * Nm); causal => prefixes are exact
+        audio = audio.cpu().numpy()
+        outs = [audio[b, :, : HOP_SIZE * ns[b]] for b in range(B)]
+        if return_latents:
+            xl = x.cpu().numpy()
+            return outs, [xl[b, : ns[b]] for b in range(B)]
+        return outs
+
+    def synthesize(self, ref_latents: np.ndarray, phoneme_ids: list, duration_sec: float) -> np.ndarray:
+        """ref_latents (T,64) f32, phoneme ids, duration -> audio (1, samples) f32 @ 24 kHz."""
+        return self.synthesize_batch([ref_latents], [phoneme_ids], [duration_sec])[0]
+
+    def forward(self, conditionings: List[torch.Tensor], transcriptions: list, texts: list,
+                duration_sec: float = 3.0) -> List[torch.Tensor]:
+        from .phonemes import get_token_ids
+        toks = []
+        for trans, text in zip(transcriptions, texts):
+            a = get_token_ids(trans) if isinstance(trans, str) else list(map(int, trans))
+            b = get_token_ids(text) if isinstance(text, str) else list(map(int, text))
+            toks.append(a + b)                                 # transcription + text, infer/onnx.py:144-152
+        n = min(len(conditionings), len(toks))
+        refs = [c.detach().cpu().numpy().astype(np.float32) for c in conditionings[:n]]
+        outs = self.synthesize_batch(refs, toks[:n], duration_sec)
+        return [torch.from_numpy(np.ascontiguousarray(o)) for o in outs]
+
+    __call__ = forward
+
+
+class _CodecRunner:
+    _part = ""
+
+    def __init__(self, path: str, providers: Optional[Iterable[str]] = None, *, weights: Optional[str] = None,
+                 device: int = 0, precision: str = "bf16x3", engine: Optional[HipEngine] = None) -> None:
+        self.engine = engine or get_engine(weights, device, precision, parts=("dit", "decoder", "encoder"))
+        if not self.engine.has(self._part):
+            raise RuntimeError(f"codec {self._part} weights are not loaded")
+
+
+class Decoder(_CodecRunner):
+    _part = "decoder"
+
+    def __init__(self, path: str = "assets/codec/decoder.onnx", providers: Optional[Iterable[str]] = None, **kw):
+        super().__init__(path, providers, **kw)
+
+    def decode(self, latents: torch.Tensor) -> torch.Tensor:
+        """latents f32 (batch, T, 64) -> audio f32 (batch, 1, 3200*T), returned on the CPU like the reference."""
+        return self.engine.codec_decode(latents.detach()).cpu()
+
+
+class Encoder(_CodecRunner):
+    _part = "encoder"
+
+    def __init__(self, path: str = "assets/codec/encoder.onnx", providers: Optional[Iterable[str]] = None, **kw):
+        super().__init__(path, providers, **kw)
+
+    def encode(self, audio: torch.Tensor) -> torch.Tensor:
+        """audio f32 (batch, 1, time) @ 24 kHz -> latents f32 (batch, time // 3200, 64), on the CPU."""
+        return self.engine.codec_encode(audio.detach()).cpu()

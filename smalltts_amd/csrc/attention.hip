@@ -12,6 +12,7 @@
 // broadcast from LDS.  All math fp32: attention is 0.16 % of the model FLOPs and
 // its scores need fp32 to hold the 1e-3 latent parity.
 #include "kernels.hpp"
+#include "prof.hpp"
 
 template <int DH>
 __global__ __launch_bounds__(256) void attention_kernel(AttnArgs a) {
@@ -225,6 +226,11 @@ static hipError_t attention_go(const AttnArgs& a, hipStream_t st) {
 hipError_t launch_attention(const AttnArgs& a, hipStream_t st) {
     if (a.N <= 0 || a.B <= 0) return hipSuccess;
     if (a.rot_dim & 1 || a.rot_dim > a.dh) return hipErrorInvalidValue;
+    const double kt = a.N + (a.k_ref ? a.R : 0) + (a.k_text ? a.P : 0);
+    const double bh = (double)a.B * a.H;
+    // algorithmic: QK^T + PV flops; bytes = q,k,v,gate,out rows once + cross K/V once
+    ProfScope ps(st, a.dh == 120 ? "attention<120>" : a.dh == 64 ? "attention<64>" : "attention<128>",
+                 4.0 * bh * a.N * kt * a.dh, 4.0 * bh * a.dh * (5.0 * a.N + 2.0 * (kt - a.N)));
     switch (a.dh) {
         case 64: return attention_go<64>(a, st);
         case 120: return attention_go<120>(a, st);

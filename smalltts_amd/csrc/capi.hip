@@ -1,6 +1,7 @@
 // extern "C" surface of libsmalltts_hip.so — see include/smalltts_hip.h for the contract.
 #include "../../include/smalltts_hip.h"
 
+#include <cstring>
 #include <string>
 
 #include "engine.hpp"
@@ -117,6 +118,14 @@ int smtts_randn(smtts_handle h, void* stream, float* out, int64_t n, uint64_t se
 }
 
 void smtts_alpha_sigma(float t, float* alpha, float* sigma) { alpha_sigma_host(t, *alpha, *sigma); }
+
+int smtts_profile_enable(smtts_handle h, int on) { E.profile_enable(on != 0); return 0; }
+int smtts_profile_report(smtts_handle h, char* buf, size_t cap) {
+    std::string r = E.profile_report();
+    if (r.size() + 1 > cap) return E.fail("profile_report: buffer too small");
+    memcpy(buf, r.c_str(), r.size() + 1);
+    return 0;
+}
 
 // ---- test hooks -------------------------------------------------------------------------------
 int smtts_test_gemm(smtts_handle h, void* stream, const float* A, int lda, const float* W, const float* bias, int M,

@@ -27,9 +27,35 @@ struct Bump {  // bump allocator over a caller-owned workspace (also used, with 
 inline std::string sidx(const std::string& a, int i, const std::string& b) { return a + std::to_string(i) + b; }
 }  // namespace
 
+thread_local Profiler* g_prof = nullptr;
+
 Engine::Engine(int device) : device_(device) {}
 
+void Engine::profile_enable(bool on) {
+    prof_on_ = on;
+    prof_.reset();
+    g_prof = on ? &prof_ : nullptr;
+}
+
+std::string Engine::profile_report() {
+    (void)hipSetDevice(device_);
+    (void)hipDeviceSynchronize();
+    auto agg = prof_.collect();
+    std::string out = "[";
+    bool first = true;
+    char buf[512];
+    for (auto& kv : agg) {
+        snprintf(buf, sizeof buf, "%s{\"name\": \"%s\", \"launches\": %ld, \"ms\": %.6f, \"flops\": %.6e, \"bytes\": %.6e}",
+                 first ? "" : ", ", kv.first.c_str(), kv.second.launches, kv.second.ms, kv.second.flops, kv.second.bytes);
+        out += buf;
+        first = false;
+    }
+    prof_.reset();
+    return out + "]";
+}
+
 Engine::~Engine() {
+    if (g_prof == &prof_) g_prof = nullptr;
     (void)hipSetDevice(device_);
     for (void* p : allocs_) (void)hipFree(p);
 }

@@ -10,6 +10,7 @@
 
 #include "gemm_ops.hpp"
 #include "kernels.hpp"
+#include "prof.hpp"
 
 struct RawTensor {
     float* d = nullptr;
@@ -116,6 +117,9 @@ class Engine {
     int codec_encode(hipStream_t st, const float* audio, int B, int S, float* latents, void* ws, size_t ws_bytes);
 
     const CodecSpecC& codec_spec() const { return cspec_; }
+    // per-kernel HIP-event timing (bench.py); report = JSON array, valid after the stream is synchronised
+    void profile_enable(bool on);
+    std::string profile_report();
     // single-kernel hooks for tests (W* are fp32 [N][K] on the device; split here, freed after the call)
     int test_gemm(hipStream_t st, const float* A, int lda, const float* W, const float* bias, int M, int N, int K,
                   int act, int split, int cfg, float* C, int ldc);
@@ -152,6 +156,8 @@ class Engine {
     std::map<std::string, RawTensor> raw_;
     std::vector<void*> allocs_;
     int split_ = 3;
+    Profiler prof_;
+    bool prof_on_ = false;
     bool finalized_ = false;
 
     // DiT packs

@@ -1,7 +1,26 @@
 // Non-template entry points for the fused GEMM family (definitions in gemm_store.hip,
 // gemm_resid.hip, gemm_misc.hip so the instantiations compile in parallel).
 #pragma once
+#include <string>
+
 #include "gemm.hpp"
+
+// kernel identity used by the profiler, e.g. "gemm<64x128x64,s3,store_gelu>"; mirrors the template
+// arguments of the gemm_kernel instantiation that gemm_launch() picks for (cfg, split, K).
+static inline std::string gemm_prof_name(int M, int N, int K, bool paired, int cfg, int split, const char* epi) {
+    if (cfg < 0) cfg = gemm_pick_cfg(M, N, K, paired);
+    static const char* tiles[] = {"64x128x64", "64x64x64", "128x128x64", "128x32x64", "128x64x64"};
+    std::string t = tiles[cfg];
+    if (cfg == CFG_128x64 && K <= 32) t = "128x64x32";
+    return "gemm<" + t + ",s" + std::to_string(split) + "," + epi + ">";
+}
+// algorithmic work of one GEMM launch: 2*M*N*K flops (x Z); bytes = A fp32 read once + W (bf16 hi[+lo]) read
+// once + C fp32 written once (+ read once for residual epilogues)
+static inline double gemm_flops(const GemmOperands& g, int Z) { return 2.0 * g.M * (double)g.N * g.K * Z; }
+static inline double gemm_bytes(const GemmOperands& g, int Z, int split, double c_elems_per_out, bool w_shared = false) {
+    double w = (double)g.N * g.K * 2.0 * (split == 3 ? 2 : 1) * (w_shared ? 1 : Z);
+    return Z * ((double)g.M * g.K * 4.0 + (double)g.M * g.N * 4.0 * c_elems_per_out) + w;
+}
 
 // act: ACT_NONE / ACT_SILU / ACT_GELU / ACT_MISH
 hipError_t gemm_store(const GemmOperands& g, int act, const EpiStore<ACT_NONE>& p, int Z, int split, hipStream_t st, int cfg = -1);

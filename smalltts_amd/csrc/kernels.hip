@@ -2,6 +2,7 @@
 // HBM-bound streaming kernels: one wave (or sub-wave group) per row, float4 accesses where the
 // layout permits, grid sized to cover the chip (>= 256 CUs x several waves).
 #include "kernels.hpp"
+#include "prof.hpp"
 
 #define LAUNCH_CHECK() return hipGetLastError()
 
@@ -48,6 +49,7 @@ hipError_t launch_ln_modulate(const float* x, float* y, int M, int C, float eps,
                               const float* scale, long mod_ld, int mod_row0, int mod_rstride, int rows_per_batch,
                               hipStream_t st) {
     if (C > 1024) return hipErrorInvalidValue;
+    ProfScope ps(st, "ln_modulate", 8.0 * M * C, 8.0 * M * C);
     dim3 grid((M + 3) / 4), block(256);
     hipLaunchKernelGGL(ln_modulate_kernel<16>, grid, block, 0, st, x, y, M, C, eps, shift, scale, mod_ld,
                        mod_row0, mod_rstride, rows_per_batch);
@@ -102,6 +104,7 @@ static hipError_t rmsnorm_go(const float* x, RowMap xmap, float* y, RowMap ymap,
 hipError_t launch_rmsnorm(const float* x, RowMap xmap, float* y, RowMap ymap, int M, int C, float eps,
                           const float* w, hipStream_t st) {
     if (C % 4) return hipErrorInvalidValue;
+    ProfScope ps(st, "rmsnorm", 4.0 * M * C, 8.0 * M * C);
     int c4 = C / 4;
     if (c4 <= 8) return rmsnorm_go<8, 1>(x, xmap, y, ymap, M, C, eps, w, st);
     if (c4 <= 16) return rmsnorm_go<16, 1>(x, xmap, y, ymap, M, C, eps, w, st);
@@ -137,6 +140,7 @@ hipError_t launch_headnorm(float* k, int L, int B, int H, int S, int dh, float e
     if (dh > 128) return hipErrorInvalidValue;
     long rows = (long)L * B * H * S;
     if (rows == 0) return hipSuccess;
+    ProfScope ps(st, "headnorm", 4.0 * rows * dh, 8.0 * rows * dh);
     hipLaunchKernelGGL(headnorm_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, k, rows, B, H, S, dh, eps, w);
     LAUNCH_CHECK();
 }
@@ -392,6 +396,7 @@ hipError_t launch_dwconv_resid(float* x, const float* n, const float* w, const f
     if (C % 4 || pad < K - 1) return hipErrorInvalidValue;
     long total = (long)B * T * (C / 4);
     if (total == 0) return hipSuccess;
+    ProfScope ps(st, "dwconv_resid", 2.0 * B * T * C * (K + 1), 12.0 * B * T * C);
     hipLaunchKernelGGL(dwconv_resid_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, x, n, w, bias, gamma, B,
                        T, C / 4, K, pad);
     LAUNCH_CHECK();
@@ -421,6 +426,7 @@ hipError_t launch_head_conv(const float* x, const float* w, float bias, float* a
     if (C % 4 || pad < K - 1) return hipErrorInvalidValue;
     long threads = (long)B * T * 8;
     if (threads == 0) return hipSuccess;
+    ProfScope ps(st, "head_conv", 2.0 * B * T * C * K, 4.0 * B * T * (C + 1));
     hipLaunchKernelGGL(head_conv_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, x, w, bias, audio, B, T, C,
                        K, pad);
     LAUNCH_CHECK();

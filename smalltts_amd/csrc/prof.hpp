@@ -1,0 +1,63 @@
+// Optional per-kernel timing with HIP events on the launch stream (bench.py's live roofline numbers).
+// Disabled by default: when off, prof_begin/prof_end are a null-pointer test.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <map>
+#include <string>
+#include <vector>
+
+struct ProfAgg {
+    long launches = 0;
+    double ms = 0, flops = 0, bytes = 0;
+};
+
+class Profiler {
+  public:
+    ~Profiler() { reset(); }
+    void begin(hipStream_t st, const std::string& name, double flops, double bytes) {
+        Rec r;
+        r.name = name; r.flops = flops; r.bytes = bytes;
+        (void)hipEventCreate(&r.a);
+        (void)hipEventCreate(&r.b);
+        (void)hipEventRecord(r.a, st);
+        recs_.push_back(r);
+    }
+    void end(hipStream_t st) {
+        if (!recs_.empty()) (void)hipEventRecord(recs_.back().b, st);
+    }
+    // call after the stream is synchronised
+    std::map<std::string, ProfAgg> collect() {
+        std::map<std::string, ProfAgg> out;
+        for (auto& r : recs_) {
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) {
+                ProfAgg& a = out[r.name];
+                a.launches++; a.ms += ms; a.flops += r.flops; a.bytes += r.bytes;
+            }
+        }
+        return out;
+    }
+    void reset() {
+        for (auto& r : recs_) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+        recs_.clear();
+    }
+
+  private:
+    struct Rec { std::string name; double flops, bytes; hipEvent_t a, b; };
+    std::vector<Rec> recs_;
+};
+
+extern thread_local Profiler* g_prof;  // set by Engine while profiling is enabled
+
+struct ProfScope {
+    hipStream_t st;
+    bool on;
+    ProfScope(hipStream_t s, const char* name, double flops, double bytes) : st(s), on(g_prof != nullptr) {
+        if (on) g_prof->begin(st, name, flops, bytes);
+    }
+    ProfScope(hipStream_t s, const std::string& name, double flops, double bytes) : st(s), on(g_prof != nullptr) {
+        if (on) g_prof->begin(st, name, flops, bytes);
+    }
+    ~ProfScope() { if (on) g_prof->end(st); }
+};

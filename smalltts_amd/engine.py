@@ -235,6 +235,15 @@ class HipEngine:
         self._ck(self.lib.smtts_randn(self.h, self._stream(), _p(out), n, C.c_uint64(seed), C.c_uint64(stream_id)), "randn")
         return out
 
+    def profile(self, on: bool):
+        self._ck(self.lib.smtts_profile_enable(self.h, int(on)), "profile_enable")
+
+    def profile_report(self):
+        import json
+        buf = C.create_string_buffer(1 << 20)
+        self._ck(self.lib.smtts_profile_report(self.h, buf, len(buf)), "profile_report")
+        return json.loads(buf.value.decode())
+
     def alpha_sigma(self, t: float):
         a, s = C.c_float(), C.c_float()
         self.lib.smtts_alpha_sigma(C.c_float(t), C.byref(a), C.byref(s))
