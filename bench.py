@@ -183,7 +183,11 @@ def main():
              "TFLOPs": round(r["flops"] / max(r["ms"], 1e-9) / 1e9, 2), "GBs": round(r["bytes"] / max(r["ms"], 1e-9) / 1e6, 1)}
             for r in rows[:12]]
     if rank == 0 and n_gpus == 1 and not args.no_cpu_baseline:
-        res["cpu_baseline"] = cpu_baseline(os.cpu_count() or 1)
+        try:
+            avail = len(os.sched_getaffinity(0))
+        except Exception:
+            avail = os.cpu_count() or 1
+        res["cpu_baseline"] = cpu_baseline(min(avail, 16))  # small-op torch graphs thrash beyond ~16 threads
     if rank == 0:
         print(json.dumps(res))
     if dist is not None:
