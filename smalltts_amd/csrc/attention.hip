@@ -51,8 +51,7 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnArgs a) {
             float y = d < DH ? x[i] * rstd * wgt[d] : 0.f;
             float partner = __shfl_xor(y, 1, 64);
             if (d < a.rot_dim) {
-                float ang = a.rope[(long)pos * a.rot_dim + d];
-                float c = cosf(ang), s = sinf(ang);
+                const float c = a.rope_cos[(long)pos * a.rot_dim + d], s = a.rope_sin[(long)pos * a.rot_dim + d];
                 y = (d & 1) ? (y * c + partner * s) : (y * c - partner * s);
             }
             out[i] = y;
@@ -203,8 +202,17 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnArgs a) {
         for (int i = 0; i < DPL; ++i) {
             int d = lane + 64 * i;
             if (d < DH) {
-                float g = a.gate[(long)b * a.bs + (long)n * a.rs + h * DH + d];
-                a.out[(long)b * a.obs + (long)n * a.ors + h * DH + d] = o[qi][i] * inv / (1.0f + expf(-g));
+                const float g = a.gate[(long)b * a.bs + (long)n * a.rs + h * DH + d];
+                const float val = o[qi][i] * inv / (1.0f + expf(-g));
+                const long oo = (long)b * a.obs + (long)n * a.ors + h * DH + d;
+                if (a.out_hi) {
+                    bf16_t hh, ll;
+                    split1(val, hh, ll);
+                    a.out_hi[oo] = hh;
+                    if (a.out_lo) a.out_lo[oo] = ll;
+                } else {
+                    a.out[oo] = val;
+                }
             }
         }
     }

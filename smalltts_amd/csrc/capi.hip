@@ -127,6 +127,16 @@ int smtts_profile_report(smtts_handle h, char* buf, size_t cap) {
     return 0;
 }
 
+int smtts_bench_gemm(smtts_handle h, int M, int N, int K, int epi, int split, int cfg, int iters, int ver, float* avg_us) {
+    return E.bench_gemm(M, N, K, epi, split, cfg, iters, ver, avg_us);
+}
+int smtts_test_gemm3(smtts_handle h, void* stream, const float* A, const float* W, const float* bias, int M, int N, int K,
+                     int act, int split, int cfg, float* C) {
+    return E.test_gemm3(ST(stream), A, W, bias, M, N, K, act, split, cfg, C);
+}
+int smtts_test_set_fused_ffn(smtts_handle h, int on) { E.set_fused_ffn(on != 0); return 0; }
+int smtts_test_force_gemm_v1(int on) { g_gemm_force_v1 = on; return 0; }
+
 // ---- test hooks -------------------------------------------------------------------------------
 int smtts_test_gemm(smtts_handle h, void* stream, const float* A, int lda, const float* W, const float* bias, int M,
                     int N, int K, int act, int split, int cfg, float* C, int ldc) {
@@ -144,13 +154,21 @@ int smtts_test_attention(smtts_handle h, void* stream, const float* qkvg, const 
     const int D = H * dh;
     a.q = qkvg; a.k = qkvg + D; a.v = qkvg + 2 * D; a.gate = qkvg + 3 * D;
     a.bs = (long)N * 4 * D; a.rs = 4 * D;
-    a.qw = qw; a.kw = kw; a.eps = eps; a.rope = rope; a.rot_dim = rot_dim;
+    float *rc = nullptr, *rs = nullptr;
+    const int nr = N * rot_dim;
+    if (hipMalloc(&rc, (size_t)nr * 4) != hipSuccess || hipMalloc(&rs, (size_t)nr * 4) != hipSuccess)
+        return E.fail("test_attention: alloc failed");
+    (void)launch_rope_cossin(rope, rc, rs, nr, ST(stream));
+    a.qw = qw; a.kw = kw; a.eps = eps; a.rope_cos = rc; a.rope_sin = rs; a.rot_dim = rot_dim;
     a.k_ref = R > 0 ? k_ref : nullptr; a.v_ref = v_ref; a.R = R;
     a.k_text = P > 0 ? k_text : nullptr; a.v_text = v_text; a.P = P;
     a.mask_self = mask_self; a.mask_ref = mask_ref; a.mask_text = mask_text;
     a.out = out; a.obs = (long)N * D; a.ors = D;
     a.B = B; a.N = N; a.H = H; a.dh = dh;
     hipError_t e = launch_attention(a, ST(stream));
+    (void)hipStreamSynchronize(ST(stream));
+    (void)hipFree(rc);
+    (void)hipFree(rs);
     return e == hipSuccess ? 0 : E.fail_hip(e, "attention");
 }
 

@@ -46,9 +46,20 @@ __device__ __forceinline__ float group_sum(float v) {  // reduce within aligned 
     return v;
 }
 
-__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
-__device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + __expf(-x)); }
-__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+// Cheap transcendentals for fused epilogues (the exact libm erff/expf/tanhf cost 50-150 VALU ops per
+// element and made the codec FFN1 epilogue VALU-bound).  v_exp_f32 / v_rcp_f32 are ~1 ulp.
+__device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ float silu_f(float x) { return x * fast_rcp(1.0f + __expf(-x)); }
+__device__ __forceinline__ float sigmoid_f(float x) { return fast_rcp(1.0f + __expf(-x)); }
+// exact-erf GELU via Abramowitz-Stegun 7.1.26 (|erf error| <= 1.5e-7); the negative side is evaluated in
+// erfc form so the tail keeps its relative accuracy.
+__device__ __forceinline__ float gelu_f(float x) {
+    const float z = fabsf(x) * 0.70710678118654752f;
+    const float t = fast_rcp(1.0f + 0.3275911f * z);
+    const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+    const float q = poly * __expf(-z * z);  // erfc(z)
+    return x > 0.f ? 0.5f * x * (2.0f - q) : 0.5f * x * q;
+}
 __device__ __forceinline__ float mish_f(float x) {
     // x * tanh(softplus(x)); softplus with torch's threshold (20) for parity
     float sp = x > 20.0f ? x : log1pf(expf(x));
@@ -58,8 +69,22 @@ __device__ __forceinline__ float mish_f(float x) {
 enum { ACT_NONE = 0, ACT_SILU = 1, ACT_GELU = 2, ACT_MISH = 3 };
 template <int ACT>
 __device__ __forceinline__ float apply_act(float x) {
-    if (ACT == ACT_SILU) return x / (1.0f + expf(-x));
+    if (ACT == ACT_SILU) return silu_f(x);
     if (ACT == ACT_GELU) return gelu_f(x);
     if (ACT == ACT_MISH) return mish_f(x);
     return x;
+}
+
+// fp32 -> (bf16 hi, bf16 lo) with x ~= hi + lo
+__device__ __forceinline__ void split1(float v, bf16_t& h, bf16_t& l) {
+    h = (bf16_t)v;
+    l = (bf16_t)(v - (float)h);
+}
+__device__ __forceinline__ void store_split4(bf16_t* hi, bf16_t* lo, long off, const float4& v) {
+    bf16x4 h, l;
+    h[0] = (bf16_t)v.x; h[1] = (bf16_t)v.y; h[2] = (bf16_t)v.z; h[3] = (bf16_t)v.w;
+    l[0] = (bf16_t)(v.x - (float)h[0]); l[1] = (bf16_t)(v.y - (float)h[1]);
+    l[2] = (bf16_t)(v.z - (float)h[2]); l[3] = (bf16_t)(v.w - (float)h[3]);
+    *reinterpret_cast<bf16x4*>(hi + off) = h;
+    if (lo) *reinterpret_cast<bf16x4*>(lo + off) = l;
 }

@@ -28,6 +28,7 @@ inline std::string sidx(const std::string& a, int i, const std::string& b) { ret
 }  // namespace
 
 thread_local Profiler* g_prof = nullptr;
+int g_gemm_force_v1 = 1;  // fp32-A GEMMs (cold paths) use the register-staged v1 kernel; 0 routes them to the v2 DMA kernel
 
 Engine::Engine(int device) : device_(device) {}
 
@@ -134,18 +135,24 @@ int Engine::set_codec_spec(const CodecSpecC& s) {
 // ---------------------------------------------------------------------------------------------
 // packing helpers
 // ---------------------------------------------------------------------------------------------
-PW Engine::pack_from_f32(const float* src, int N, int K) {
+PW Engine::pack_from_f32(const float* src, int N, int K, int k_pad, int n_pad) {
     PW w;
+    const int Kp = k_pad > K ? k_pad : K;
+    const int Np = n_pad > N ? n_pad : N;  // extra all-zero rows (allocation only; w.N stays the logical row count)
     w.N = N;
-    w.K = K;
-    w.hi = static_cast<bf16_t*>(dalloc((size_t)N * K * 2));
-    w.lo = static_cast<bf16_t*>(dalloc((size_t)N * K * 2));
+    w.K = Kp;
+    w.hi = static_cast<bf16_t*>(dalloc((size_t)Np * Kp * 2));
+    w.lo = static_cast<bf16_t*>(dalloc((size_t)Np * Kp * 2));
     if (!w.hi || !w.lo) { w.N = 0; return w; }
-    if (launch_split_rows(src, K, w.hi, w.lo, K, N, K, nullptr, 0) != hipSuccess) w.N = 0;
+    if (Kp != K || Np != N) {
+        (void)hipMemsetAsync(w.hi, 0, (size_t)Np * Kp * 2, 0);
+        (void)hipMemsetAsync(w.lo, 0, (size_t)Np * Kp * 2, 0);
+    }
+    if (launch_split_rows(src, K, w.hi, w.lo, Kp, N, K, nullptr, 0) != hipSuccess) w.N = 0;
     return w;
 }
 
-PW Engine::pack_rows(const std::vector<std::string>& names, const std::vector<int>* perm) {
+PW Engine::pack_rows(const std::vector<std::string>& names, const std::vector<int>* perm, int k_pad) {
     PW w;
     int K = -1, Ntot = 0;
     for (auto& n : names) {
@@ -155,7 +162,7 @@ PW Engine::pack_rows(const std::vector<std::string>& names, const std::vector<in
         if (K != t->shape[1]) { err_ = "pack: K mismatch at " + n; return w; }
         Ntot += (int)t->shape[0];
     }
-    if (names.size() == 1 && !perm) return pack_from_f32(raw(names[0])->d, Ntot, K);
+    if (names.size() == 1 && !perm) return pack_from_f32(raw(names[0])->d, Ntot, K, k_pad);
     float* tmp = nullptr;
     if (hipMalloc(&tmp, (size_t)Ntot * K * 4) != hipSuccess) { err_ = "pack: temp alloc failed"; return w; }
     long off = 0;
@@ -236,9 +243,20 @@ int Engine::build_encoder(EncoderW& e, const std::string& prefix, int dim, int h
     }
     e.final_norm = rawp(prefix + ".norm.weight");
     if (!e.final_norm) return fail("missing " + prefix + ".norm.weight");
-    e.rope = static_cast<float*>(dalloc((size_t)kMaxPos * e.dh * 4));
-    if (!e.rope) return fail("rope table alloc failed");
-    HIPC(launch_rope_table(e.rope, kMaxPos, e.dh, 0));
+    return make_rope(e.dh, &e.rope_cos, &e.rope_sin);
+}
+
+int Engine::make_rope(int dim, float** cos_out, float** sin_out) {
+    const size_t n = (size_t)kMaxPos * dim;
+    float* ang = nullptr;
+    HIPC(hipMalloc(&ang, n * 4));
+    *cos_out = static_cast<float*>(dalloc(n * 4));
+    *sin_out = static_cast<float*>(dalloc(n * 4));
+    if (!*cos_out || !*sin_out) return fail("rope table alloc failed");
+    HIPC(launch_rope_table(ang, kMaxPos, dim, 0));
+    HIPC(launch_rope_cossin(ang, *cos_out, *sin_out, (int)n, 0));
+    HIPC(hipStreamSynchronize(0));
+    HIPC(hipFree(ang));
     return 0;
 }
 
@@ -308,7 +326,7 @@ int Engine::finalize_dit() {
                               {kHidden});
         b.out = pack_rows({p + ".attn.to_out.0.weight"});
         b.ff13 = pack_rows({p + ".ff.w1.weight", p + ".ff.w3.weight"}, &perm);
-        b.ff2 = pack_rows({p + ".ff.w2.weight"});
+        b.ff2 = pack_rows({p + ".ff.w2.weight"}, nullptr, kFFp);
         b.b1 = rawp(p + ".ff.w1.bias"); b.b3 = rawp(p + ".ff.w3.bias"); b.b2 = rawp(p + ".ff.w2.bias");
         b.qn = rawp(p + ".attn.q_norm.weight"); b.kn = rawp(p + ".attn.k_norm.weight");
         if (!b.qkvg.N || !b.b_qkvg || !b.out.N || !b.ff13.N || !b.ff2.N || !b.b1 || !b.b3 || !b.b2 || !b.qn || !b.kn)
@@ -321,9 +339,10 @@ int Engine::finalize_dit() {
     if (!raw("style_encoder.log_scale")) return fail("missing style_encoder.log_scale");
     HIPC(hipMemcpy(&ls, rawp("style_encoder.log_scale"), 4, hipMemcpyDeviceToHost));
     style_scale_ = expf(ls);
-    rope_dit_ = static_cast<float*>(dalloc((size_t)kMaxPos * 64 * 4));
-    if (!rope_dit_) return fail("rope alloc failed");
-    HIPC(launch_rope_table(rope_dit_, kMaxPos, 64, 0));
+    if (make_rope(64, &rope_dit_cos_, &rope_dit_sin_)) return 1;
+    rope_tmp_cos_ = static_cast<float*>(dalloc((size_t)kMaxPos * 64 * 4));
+    rope_tmp_sin_ = static_cast<float*>(dalloc((size_t)kMaxPos * 64 * 4));
+    if (!rope_tmp_cos_ || !rope_tmp_sin_) return fail("rope alloc failed");
     for (const char* n : {"time_embedding.mlp.0.bias", "time_embedding.mlp.2.bias", "dit.emb_proj.0.bias",
                           "dit.emb_proj.2.bias", "dit.input_embed.proj.bias", "velocity.bias", "dit.phoneme_proj.bias",
                           "style_encoder.in_proj.bias", "style_encoder.out_proj.bias",
@@ -401,6 +420,13 @@ int Engine::finalize_codec(bool decoder) {
             b.w1 = pack_rows({p + ".ffn.w1.weight"});
             b.w2 = pack_rows({p + ".ffn.w2.weight"});
             if (!b.w1.N || !b.w2.N) return fail("codec ffn pack failed: " + p + " " + err_);
+            const int F = s.ffn_mult * C;
+            if ((C == 32 || C == 64 || C == 128) && F % 64 == 0) {
+                const int CP = C < 64 ? 64 : C;
+                b.w1f = pack_from_f32(rawp(p + ".ffn.w1.weight"), F, C, CP, 0);
+                b.w2f = pack_from_f32(rawp(p + ".ffn.w2.weight"), C, F, 0, CP);
+                if (!b.w1f.N || !b.w2f.N) return fail("codec fused ffn pack failed: " + p);
+            }
             st.blocks.push_back(b);
         }
         h.stages.push_back(st);
@@ -466,36 +492,84 @@ static inline GemmOperands ops(const float* A, RowMap amap, const PW& w, int M, 
     g.w_zmod = 0;
     return g;
 }
+struct SplitBuf {  // activation stored as a split bf16 pair (x ~= hi + lo), the A operand of gemm3
+    bf16_t* hi;
+    bf16_t* lo;
+};
+static inline Gemm3Operands ops3(SplitBuf a, RowMap amap, const PW& w, int M, int row0 = 0, int nrows = -1) {
+    Gemm3Operands g;
+    g.Ahi = a.hi;
+    g.Alo = a.lo;
+    g.amap = amap;
+    g.Whi = w.hi + (long)row0 * w.K;
+    g.Wlo = w.lo + (long)row0 * w.K;
+    g.ldw = w.K;
+    g.M = M;
+    g.N = nrows < 0 ? w.N : nrows;
+    g.K = w.K;
+    g.a_z = 0;
+    g.w_z = 0;
+    g.w_zmod = 0;
+    return g;
+}
 static inline EpiStore<ACT_NONE> store_to(float* out, RowMap omap, const float* bias, float scale = 1.f,
                                           const uint8_t* rowmask = nullptr) {
-    return EpiStore<ACT_NONE>{out, omap, 0, bias, 0, scale, rowmask};
+    return EpiStore<ACT_NONE>{out, omap, 0, bias, 0, scale, rowmask, nullptr, nullptr};
+}
+static inline EpiStore<ACT_NONE> store_split_to(SplitBuf o, RowMap omap, const float* bias, float scale = 1.f,
+                                                const uint8_t* rowmask = nullptr) {
+    return EpiStore<ACT_NONE>{nullptr, omap, 0, bias, 0, scale, rowmask, o.hi, o.lo};
+}
+template <class T>
+static inline SplitBuf take_split(T& bump, size_t elems) {
+    SplitBuf s;
+    s.hi = bump.template take<bf16_t>(elems);
+    s.lo = bump.template take<bf16_t>(elems);
+    return s;
 }
 
 // ---------------------------------------------------------------------------------------------
-// K10: encoder stack (style.py:70-105 / phonemes.py:131-167), x updated in place
+// K10: encoder stack (style.py:70-105 / phonemes.py:131-167), x (fp32 residual) updated in place.
+// GEMM inputs (y, o, ffh) live as split bf16 pairs written by the producing kernel.
 // ---------------------------------------------------------------------------------------------
-int Engine::run_encoder(hipStream_t st, const EncoderW& e, float* x, float* y, float* qkvg, float* o, float* ffh,
-                        int B, int S, const uint8_t* key_mask) {
+namespace {
+struct EncWs {
+    float *x, *qkvg, *seq;
+    SplitBuf y, o, ffh, seqs;
+    void plan(Bump& b, int Mx) {
+        x = b.take<float>((size_t)Mx * 512);
+        qkvg = b.take<float>((size_t)Mx * 2048);
+        seq = b.take<float>((size_t)Mx * kHidden);
+        y = take_split(b, (size_t)Mx * 512);
+        o = take_split(b, (size_t)Mx * 512);
+        ffh = take_split(b, (size_t)Mx * 1536);
+        seqs = take_split(b, (size_t)Mx * kHidden);
+    }
+};
+}  // namespace
+
+int Engine::run_encoder(hipStream_t st, const EncoderW& e, void* wsv, int B, int S, const uint8_t* key_mask) {
+    EncWs& w = *static_cast<EncWs*>(wsv);
     const int M = B * S, D = e.dim;
+    const RowMap rd = rowmap_plain(D);
     for (const EncBlockW& b : e.blocks) {
-        HIPC(launch_rmsnorm(x, rowmap_plain(D), y, rowmap_plain(D), M, D, e.eps, b.an, st));
-        HIPC(gemm_store(ops(y, rowmap_plain(D), b.qkvg, M), ACT_NONE, store_to(qkvg, rowmap_plain(4 * D), nullptr), 1,
-                        split_, st));
+        HIPC(launch_rmsnorm(w.x, rd, nullptr, w.y.hi, w.y.lo, rd, M, D, e.eps, b.an, st));
+        HIPC(gemm3_store(ops3(w.y, rd, b.qkvg, M), ACT_NONE, store_to(w.qkvg, rowmap_plain(4 * D), nullptr), 1, split_, st));
         AttnArgs a{};
-        a.q = qkvg; a.k = qkvg + D; a.v = qkvg + 2 * D; a.gate = qkvg + 3 * D;
+        a.q = w.qkvg; a.k = w.qkvg + D; a.v = w.qkvg + 2 * D; a.gate = w.qkvg + 3 * D;
         a.bs = (long)S * 4 * D; a.rs = 4 * D;
         a.qw = b.qn; a.kw = b.kn; a.eps = e.eps;
-        a.rope = e.rope; a.rot_dim = e.dh;
+        a.rope_cos = e.rope_cos; a.rope_sin = e.rope_sin; a.rot_dim = e.dh;
         a.mask_self = key_mask;
-        a.out = o; a.obs = (long)S * D; a.ors = D;
+        a.out = nullptr; a.out_hi = w.o.hi; a.out_lo = w.o.lo; a.obs = (long)S * D; a.ors = D;
         a.B = B; a.N = S; a.H = e.heads; a.dh = e.dh;
         HIPC(launch_attention(a, st));
-        EpiResid<0> r1{x, rowmap_plain(D), nullptr, nullptr, 0, 0, 0, 1, nullptr};
-        HIPC(gemm_resid(ops(o, rowmap_plain(D), b.wo, M), 0, r1, split_, st));
-        HIPC(launch_rmsnorm(x, rowmap_plain(D), y, rowmap_plain(D), M, D, e.eps, b.mn, st));
-        EpiSwiGLU sw{ffh, e.ff, nullptr, nullptr};
-        HIPC(gemm_swiglu(ops(y, rowmap_plain(D), b.ff13, M), sw, split_, st));
-        HIPC(gemm_resid(ops(ffh, rowmap_plain(e.ff), b.w2, M), 0, r1, split_, st));
+        EpiResid<0> r1{w.x, rd, nullptr, nullptr, 0, 0, 0, 1, nullptr};
+        HIPC(gemm3_resid(ops3(w.o, rd, b.wo, M), 0, r1, split_, st));
+        HIPC(launch_rmsnorm(w.x, rd, nullptr, w.y.hi, w.y.lo, rd, M, D, e.eps, b.mn, st));
+        EpiSwiGLU sw{nullptr, e.ff, nullptr, nullptr, w.ffh.hi, w.ffh.lo};
+        HIPC(gemm3_swiglu(ops3(w.y, rd, b.ff13, M), sw, split_, st));
+        HIPC(gemm3_resid(ops3(w.ffh, rowmap_plain(e.ff), b.w2, M), 0, r1, split_, st));
     }
     return 0;
 }
@@ -503,26 +577,12 @@ int Engine::run_encoder(hipStream_t st, const EncoderW& e, float* x, float* y, f
 // ---------------------------------------------------------------------------------------------
 // E0: condition encoder (model.py:88-95)
 // ---------------------------------------------------------------------------------------------
-namespace {
-struct CondWs {
-    float *x, *y, *qkvg, *o, *ffh, *seq;
-    size_t plan(Bump& b, int Mx) {
-        x = b.take<float>((size_t)Mx * 512);
-        y = b.take<float>((size_t)Mx * 512);
-        qkvg = b.take<float>((size_t)Mx * 2048);
-        o = b.take<float>((size_t)Mx * 512);
-        ffh = b.take<float>((size_t)Mx * 1536);
-        seq = b.take<float>((size_t)Mx * kHidden);
-        return b.off;
-    }
-};
-}  // namespace
-
 size_t Engine::cond_ws_bytes(int B, int R, int P) const {
     Bump b(nullptr);
-    CondWs w;
+    EncWs w;
     int Mx = B * (R > P ? R : P);
-    return w.plan(b, Mx > 0 ? Mx : 1) + 256;
+    w.plan(b, Mx > 0 ? Mx : 1);
+    return b.off + 256;
 }
 
 int Engine::cond_encode(hipStream_t st, const float* ref, const int64_t* ref_len, const int64_t* ids,
@@ -533,37 +593,39 @@ int Engine::cond_encode(hipStream_t st, const float* ref, const int64_t* ref_len
     if (ws_bytes < cond_ws_bytes(B, R, P)) return fail("cond_encode: workspace too small");
     HIPC(hipSetDevice(device_));
     Bump bump(ws);
-    CondWs w;
+    EncWs w;
     w.plan(bump, B * (R > P ? R : P) > 0 ? B * (R > P ? R : P) : 1);
+    const RowMap r512 = rowmap_plain(512), rh = rowmap_plain(kHidden);
 
     // ---- E1 style encoder (style.py:144-174) -------------------------------------------------
     if (R > 0) {
         const int M = B * R;
         HIPC(launch_len_mask(ref_len, ref_mask, B, R, st));
         HIPC(gemm_store(ops(ref, rowmap_plain(kLatent), style_in_, M), ACT_NONE,
-                        store_to(w.x, rowmap_plain(512), rawp("style_encoder.in_proj.bias"), style_scale_), 1, split_, st));
-        if (run_encoder(st, style_, w.x, w.y, w.qkvg, w.o, w.ffh, B, R, ref_mask)) return 1;
-        HIPC(launch_rmsnorm(w.x, rowmap_plain(512), w.y, rowmap_plain(512), M, 512, style_.eps, style_.final_norm, st));
+                        store_to(w.x, r512, rawp("style_encoder.in_proj.bias"), style_scale_), 1, split_, st));
+        if (run_encoder(st, style_, &w, B, R, ref_mask)) return 1;
+        HIPC(launch_rmsnorm(w.x, r512, nullptr, w.y.hi, w.y.lo, r512, M, 512, style_.eps, style_.final_norm, st));
         float* seq = ref_seq_out ? ref_seq_out : w.seq;
-        HIPC(gemm_store(ops(w.y, rowmap_plain(512), style_out_, M), ACT_NONE,
-                        store_to(seq, rowmap_plain(kHidden), rawp("style_encoder.out_proj.bias"), 1.f, ref_mask), 1,
-                        split_, st));
+        HIPC(gemm3_store(ops3(w.y, r512, style_out_, M), ACT_NONE,
+                         store_to(seq, rh, rawp("style_encoder.out_proj.bias"), 1.f, ref_mask), 1, split_, st));
         // ---- E3 cross KV for the reference tokens (dit.py:80-93) -------------------------------
+        HIPC(launch_to_split(seq, rh, w.seqs.hi, w.seqs.lo, rh, M, kHidden, st));
         EpiKV kv{k_ref, v_ref, kvref_b_, B, kHeads, kDh, R};
-        HIPC(gemm_kv(ops(seq, rowmap_plain(kHidden), kvref_, M), kv, split_, st));
+        HIPC(gemm3_kv(ops3(w.seqs, rh, kvref_, M), kv, split_, st));
         HIPC(launch_headnorm(k_ref, kBlocks, B, kHeads, R, kDh, 1e-6f, knc_, st));
     }
     // ---- E2 text encoder (phonemes.py:200-207) + phoneme_proj (dit.py:293-298) ---------------
     if (P > 0) {
         const int M = B * P;
         HIPC(launch_embedding(ids, rawp("phoneme_embedding.text_embedding.weight"), w.x, M, 512, 198, st));
-        if (run_encoder(st, text_, w.x, w.y, w.qkvg, w.o, w.ffh, B, P, ph_mask)) return 1;
-        HIPC(launch_rmsnorm(w.x, rowmap_plain(512), w.y, rowmap_plain(512), M, 512, text_.eps, text_.final_norm, st));
+        if (run_encoder(st, text_, &w, B, P, ph_mask)) return 1;
+        HIPC(launch_rmsnorm(w.x, r512, nullptr, w.y.hi, w.y.lo, r512, M, 512, text_.eps, text_.final_norm, st));
         float* mem = mem_out ? mem_out : w.seq;
-        HIPC(gemm_store(ops(w.y, rowmap_plain(512), phproj_, M), ACT_NONE,
-                        store_to(mem, rowmap_plain(kHidden), rawp("dit.phoneme_proj.bias"), 1.f, ph_mask), 1, split_, st));
+        HIPC(gemm3_store(ops3(w.y, r512, phproj_, M), ACT_NONE,
+                         store_to(mem, rh, rawp("dit.phoneme_proj.bias"), 1.f, ph_mask), 1, split_, st));
+        HIPC(launch_to_split(mem, rh, w.seqs.hi, w.seqs.lo, rh, M, kHidden, st));
         EpiKV kv{k_text, v_text, kvtext_b_, B, kHeads, kDh, P};
-        HIPC(gemm_kv(ops(mem, rowmap_plain(kHidden), kvtext_, M), kv, split_, st));
+        HIPC(gemm3_kv(ops3(w.seqs, rh, kvtext_, M), kv, split_, st));
         HIPC(launch_headnorm(k_text, kBlocks, B, kHeads, P, kDh, 1e-6f, knc_, st));
     }
     return 0;
@@ -571,7 +633,9 @@ int Engine::cond_encode(hipStream_t st, const float* ref, const int64_t* ref_len
 
 // ---------------------------------------------------------------------------------------------
 // D1/D3/D5/D8 modulation table: all AdaLN vectors for `rows` distinct timesteps in one pass
-//   mod[r] = [ blk0: shift_msa scale_msa gate_msa shift_mlp scale_mlp gate_mlp | ... | final: scale shift ]
+//   mod[r] = [ blk0: shift_msa scale_msa tanh(gate_msa) shift_mlp scale_mlp tanh(gate_mlp) | ... | final: scale shift ]
+// (tiny-M GEMM chain on the fp32-A kernel; the tanh of the gates, dit.py:198,201, is applied once here
+// instead of per output element in the residual epilogues)
 // ---------------------------------------------------------------------------------------------
 int Engine::modulation(hipStream_t st, const float* t_dev, int rows, float* sinb, float* t1, float* temb, float* e1,
                        float* semb, float* mod) {
@@ -587,6 +651,7 @@ int Engine::modulation(hipStream_t st, const float* t_dev, int rows, float* sinb
                     store_to(semb, rowmap_plain(kHidden), rawp("dit.emb_proj.2.bias")), 1, split_, st));
     HIPC(gemm_store(ops(semb, rowmap_plain(kHidden), modall_, rows), ACT_NONE,
                     store_to(mod, rowmap_plain(kModLd), modall_b_), 1, split_, st));
+    HIPC(launch_tanh_gates(mod, rows, kModLd, kBlocks, kModPerBlock, kHidden, st));
     return 0;
 }
 
@@ -603,19 +668,20 @@ struct ModWs {
     }
 };
 struct CoreWs {
-    float *h, *gm1, *gm2, *x, *y, *qkvg, *o, *ffh;
+    float *h, *x, *qkvg;
+    SplitBuf gm1, gm2, y, o, ffh;
     size_t gm_elems;
     void plan(Bump& b, int B, int N) {
         const size_t M = (size_t)B * N;
         gm_elems = (size_t)B * kConvG * (N + 2 * kConvPad) * kConvGs;
         h = b.take<float>(M * kHidden);
-        gm1 = b.take<float>(gm_elems);
-        gm2 = b.take<float>(gm_elems);
         x = b.take<float>(M * kHidden);
-        y = b.take<float>(M * kHidden);
         qkvg = b.take<float>(M * 4 * kHidden);
-        o = b.take<float>(M * kHidden);
-        ffh = b.take<float>(M * kFF);
+        gm1 = take_split(b, gm_elems);
+        gm2 = take_split(b, gm_elems);
+        y = take_split(b, M * kHidden);
+        o = take_split(b, M * kHidden);
+        ffh = take_split(b, M * kFFp);
     }
 };
 }  // namespace
@@ -642,64 +708,75 @@ int Engine::denoise_core(hipStream_t st, const float* x_t, const uint8_t* mask, 
     // D2 input embedding (dit.py:246-253): h = proj(x); x = mask*mish(conv2(mask*mish(conv1(mask*h)))) + h
     HIPC(gemm_store(ops(x_t, rowmap_plain(kLatent), inproj_, M), ACT_NONE,
                     store_to(w.h, rh, rawp("dit.input_embed.proj.bias")), 1, split_, st));
-    HIPC(launch_convpos_pack(w.h, mask, w.gm1, B, N, kConvG, kConvCpg, kConvPad, kConvGs, st));
-    HIPC(hipMemsetAsync(w.gm2, 0, w.gm_elems * 4, st));
+    HIPC(launch_convpos_pack(w.h, mask, w.gm1.hi, w.gm1.lo, B, N, kConvG, kConvCpg, kConvPad, kConvGs, st));
+    HIPC(hipMemsetAsync(w.gm2.hi, 0, w.gm_elems * 2, st));
+    HIPC(hipMemsetAsync(w.gm2.lo, 0, w.gm_elems * 2, st));
     {
         // grouped conv k=31 as B*G small GEMMs: z = b*G + g, rows = frames, K = 31 taps x 64 (padded) channels
         const long zs = (long)(N + 2 * kConvPad) * kConvGs;
-        GemmOperands g = ops(w.gm1, rowmap_plain(kConvGs), conv1_, N, 0, kConvCpg);
+        Gemm3Operands g = ops3(w.gm1, rowmap_plain(kConvGs), conv1_, N, 0, kConvCpg);
         g.a_z = zs;
         g.w_z = (long)kConvCpg * conv1_.K;
         g.w_zmod = kConvG;
-        EpiConvPos<0> e1{w.gm2, nullptr, rawp("dit.input_embed.conv_pos_embed.conv1.bias"), mask, kConvG, kConvCpg, N,
-                         kConvPad, kConvGs};
-        HIPC(gemm_convpos(g, false, e1, B * kConvG, split_, st));
-        g = ops(w.gm2, rowmap_plain(kConvGs), conv2_, N, 0, kConvCpg);
+        EpiConvPos<0> e1{nullptr, nullptr, rawp("dit.input_embed.conv_pos_embed.conv1.bias"), mask, kConvG, kConvCpg, N,
+                         kConvPad, kConvGs, w.gm2.hi, w.gm2.lo};
+        HIPC(gemm3_convpos(g, false, e1, B * kConvG, split_, st));
+        g = ops3(w.gm2, rowmap_plain(kConvGs), conv2_, N, 0, kConvCpg);
         g.a_z = zs;
         g.w_z = (long)kConvCpg * conv2_.K;
         g.w_zmod = kConvG;
         EpiConvPos<0> e2{w.x, w.h, rawp("dit.input_embed.conv_pos_embed.conv2.bias"), mask, kConvG, kConvCpg, N,
-                         kConvPad, kConvGs};
-        HIPC(gemm_convpos(g, true, e2, B * kConvG, split_, st));
+                         kConvPad, kConvGs, nullptr, nullptr};
+        HIPC(gemm3_convpos(g, true, e2, B * kConvG, split_, st));
     }
-    const float* rp = rope ? rope : rope_dit_;
+    // zero the padded tail columns [2400, 2432) of the FF hidden once per call
+    HIPC(hipMemsetAsync(w.ffh.hi, 0, (size_t)M * kFFp * 2, st));
+    HIPC(hipMemsetAsync(w.ffh.lo, 0, (size_t)M * kFFp * 2, st));
+    const float* rc = rope_dit_cos_;
+    const float* rs = rope_dit_sin_;
+    if (rope) {  // caller-supplied angle table (reference operator input, infer/onnx.py:42-47,122)
+        HIPC(launch_rope_cossin(rope, rope_tmp_cos_, rope_tmp_sin_, N * 64, st));
+        rc = rope_tmp_cos_;
+        rs = rope_tmp_sin_;
+    }
     for (int l = 0; l < kBlocks; ++l) {
         const DitBlockW& b = blocks_[l];
         const float* m = mod + (long)l * kModPerBlock;
         // D5 AdaLN-Zero (dit.py:19-25)
-        HIPC(launch_ln_modulate(w.x, w.y, M, kHidden, 1e-6f, m + 0 * kHidden, m + 1 * kHidden, kModLd, mod_row0,
-                                mod_rstride, N, st));
+        HIPC(launch_ln_modulate(w.x, nullptr, w.y.hi, w.y.lo, M, kHidden, 1e-6f, m + 0 * kHidden, m + 1 * kHidden, kModLd,
+                                mod_row0, mod_rstride, N, st));
         // D6 joint attention (dit.py:95-135)
-        HIPC(gemm_store(ops(w.y, rh, b.qkvg, M), ACT_NONE, store_to(w.qkvg, rowmap_plain(4 * kHidden), b.b_qkvg), 1,
-                        split_, st));
+        HIPC(gemm3_store(ops3(w.y, rh, b.qkvg, M), ACT_NONE, store_to(w.qkvg, rowmap_plain(4 * kHidden), b.b_qkvg), 1,
+                         split_, st));
         AttnArgs a{};
         a.q = w.qkvg; a.k = w.qkvg + kHidden; a.v = w.qkvg + 2 * kHidden; a.gate = w.qkvg + 3 * kHidden;
         a.bs = (long)N * 4 * kHidden; a.rs = 4 * kHidden;
         a.qw = b.qn; a.kw = b.kn; a.eps = 1e-6f;
-        a.rope = rp; a.rot_dim = 64;
+        a.rope_cos = rc; a.rope_sin = rs; a.rot_dim = 64;
         const long lr = (long)l * B * kHeads * R * kDh, lp = (long)l * B * kHeads * P * kDh;
         a.k_ref = R > 0 ? k_ref + lr : nullptr; a.v_ref = R > 0 ? v_ref + lr : nullptr; a.R = R;
         a.k_text = P > 0 ? k_text + lp : nullptr; a.v_text = P > 0 ? v_text + lp : nullptr; a.P = P;
         a.mask_self = mask; a.mask_ref = ref_mask; a.mask_text = ph_mask;
-        a.out = w.o; a.obs = (long)N * kHidden; a.ors = kHidden;
+        a.out = nullptr; a.out_hi = w.o.hi; a.out_lo = w.o.lo; a.obs = (long)N * kHidden; a.ors = kHidden;
         a.B = B; a.N = N; a.H = kHeads; a.dh = kDh;
         HIPC(launch_attention(a, st));
         // to_out + mask + gated residual (dit.py:117-118,198)
         EpiResid<0> r1{w.x, rh, nullptr, m + 2 * kHidden, kModLd, mod_row0, mod_rstride, N, mask};
-        HIPC(gemm_resid(ops(w.o, rh, b.out, M), 1, r1, split_, st));
+        HIPC(gemm3_resid(ops3(w.o, rh, b.out, M), 1, r1, split_, st));
         // D7 feed-forward (dit.py:199-201)
-        HIPC(launch_ln_modulate(w.x, w.y, M, kHidden, 1e-6f, m + 3 * kHidden, m + 4 * kHidden, kModLd, mod_row0,
-                                mod_rstride, N, st));
-        EpiSwiGLU sw{w.ffh, kFF, b.b1, b.b3};
-        HIPC(gemm_swiglu(ops(w.y, rh, b.ff13, M), sw, split_, st));
+        HIPC(launch_ln_modulate(w.x, nullptr, w.y.hi, w.y.lo, M, kHidden, 1e-6f, m + 3 * kHidden, m + 4 * kHidden, kModLd,
+                                mod_row0, mod_rstride, N, st));
+        EpiSwiGLU sw{nullptr, kFFp, b.b1, b.b3, w.ffh.hi, w.ffh.lo};
+        HIPC(gemm3_swiglu(ops3(w.y, rh, b.ff13, M), sw, split_, st));
         EpiResid<0> r2{w.x, rh, b.b2, m + 5 * kHidden, kModLd, mod_row0, mod_rstride, N, nullptr};
-        HIPC(gemm_resid(ops(w.ffh, rowmap_plain(kFF), b.ff2, M), 1, r2, split_, st));
+        HIPC(gemm3_resid(ops3(w.ffh, rowmap_plain(kFFp), b.ff2, M), 1, r2, split_, st));
     }
     // D8 final AdaLN (chunk order scale, shift: dit.py:37) + velocity head (model.py:100)
     const float* mf = mod + (long)kBlocks * kModPerBlock;
-    HIPC(launch_ln_modulate(w.x, w.y, M, kHidden, 1e-6f, mf + kHidden, mf, kModLd, mod_row0, mod_rstride, N, st));
-    HIPC(gemm_store(ops(w.y, rh, velocity_, M), ACT_NONE, store_to(velocity, rowmap_plain(kLatent), rawp("velocity.bias")),
-                    1, split_, st));
+    HIPC(launch_ln_modulate(w.x, nullptr, w.y.hi, w.y.lo, M, kHidden, 1e-6f, mf + kHidden, mf, kModLd, mod_row0,
+                            mod_rstride, N, st));
+    HIPC(gemm3_store(ops3(w.y, rh, velocity_, M), ACT_NONE, store_to(velocity, rowmap_plain(kLatent), rawp("velocity.bias")),
+                     1, split_, st));
     return 0;
 }
 
@@ -849,28 +926,57 @@ int Engine::sample(hipStream_t st, int mode, int n_steps, int cfg, float s_text,
 // front of each batch item implement the causal left padding of every conv, so strided / transposed /
 // k-tap convs all become plain GEMMs over overlapping rows.
 // ---------------------------------------------------------------------------------------------
-int Engine::codec_block(hipStream_t st, const CodecBlockW& w, float* x, float* nbuf, float* hidden, int B, int T,
-                        int C) {
+int Engine::codec_block(hipStream_t st, const CodecBlockW& w, float* x, float* nbuf, bf16_t* n2hi, bf16_t* n2lo,
+                        bf16_t* hhi, bf16_t* hlo, int B, int T, int C) {
     const int M = B * T, pad = kCodecPad;
     const RowMap img = rowmap_batched(C, T, (long)(pad + T) * C, (long)pad * C);
-    HIPC(launch_rmsnorm(x, img, nbuf, img, M, C, cspec_.eps, w.norm_w, st));
-    HIPC(launch_dwconv_resid(x, nbuf, w.dw_w, w.dw_b, w.gamma, B, T, C, cspec_.kernel, pad, st));
-    HIPC(launch_rmsnorm(x, img, nbuf, img, M, C, cspec_.eps, w.ffn_norm_w, st));
     const int F = cspec_.ffn_mult * C;
-    HIPC(gemm_store(ops(nbuf, img, w.w1, M), ACT_GELU, store_to(hidden, rowmap_plain(F), w.b1), 1, split_, st));
+    const RowMap rc = rowmap_plain(C), rf = rowmap_plain(F);
+    // mixer: RMSNorm -> causal depthwise conv -> LayerScale residual
+    HIPC(launch_rmsnorm(x, img, nbuf, nullptr, nullptr, img, M, C, cspec_.eps, w.norm_w, st));
+    HIPC(launch_dwconv_resid(x, nbuf, w.dw_w, w.dw_b, w.gamma, B, T, C, cspec_.kernel, pad, st));
+    // FFN: RMSNorm -> Linear 4x -> GELU -> Linear -> LayerScale residual
+    if (w.w1f.N && fused_ffn_) {  // narrow stages: one fused kernel, hidden stays in LDS (codec_ffn.hip)
+        HIPC(launch_codec_ffn_fused(x, img, w.ffn_norm_w, w.w1f.hi, w.w1f.lo, w.b1, w.w2f.hi, w.w2f.lo, w.b2, w.ffn_gamma, M,
+                                    C, F, cspec_.eps, split_, st));
+        return 0;
+    }
+    // wide stages: two gemm3 launches; n2 / hidden are split bf16 pairs
+    SplitBuf hid{hhi, hlo};
+    if (F % 64 != 0) {  // hidden width not a whole k-tile (only tiny test specs): all-fp32-A path, hidden kept fp32
+        float* hf = reinterpret_cast<float*>(hhi);  // hhi/hlo are adjacent: 2 x F x M bf16 = F x M fp32
+        if (reinterpret_cast<char*>(hlo) < reinterpret_cast<char*>(hhi) + (size_t)M * F * 2) return fail("codec ws layout");
+        HIPC(launch_rmsnorm(x, img, nbuf, nullptr, nullptr, img, M, C, cspec_.eps, w.ffn_norm_w, st));
+        HIPC(gemm_store(ops(nbuf, img, w.w1, M), ACT_GELU, store_to(hf, rf, w.b1), 1, split_, st));
+        EpiResid<0> r0{x, img, w.b2, w.ffn_gamma, 0, 0, 0, 1, nullptr};
+        HIPC(gemm_resid(ops(hf, rf, w.w2, M), 2, r0, split_, st));
+        return 0;
+    }
+    if (C % 64 == 0) {
+        SplitBuf n2{n2hi, n2lo};
+        HIPC(launch_rmsnorm(x, img, nullptr, n2hi, n2lo, rc, M, C, cspec_.eps, w.ffn_norm_w, st));
+        HIPC(gemm3_store(ops3(n2, rc, w.w1, M), ACT_GELU, store_split_to(hid, rf, w.b1), 1, split_, st));
+    } else {  // K = C < 64 (last stage, C = 32): one k-tile on the fp32-A kernel, still writing the split hidden
+        HIPC(launch_rmsnorm(x, img, nbuf, nullptr, nullptr, img, M, C, cspec_.eps, w.ffn_norm_w, st));
+        HIPC(gemm_store(ops(nbuf, img, w.w1, M), ACT_GELU, store_split_to(hid, rf, w.b1), 1, split_, st));
+    }
     EpiResid<0> r{x, img, w.b2, w.ffn_gamma, 0, 0, 0, 1, nullptr};
-    HIPC(gemm_resid(ops(hidden, rowmap_plain(F), w.w2, M), 2, r, split_, st));
+    HIPC(gemm3_resid(ops3(hid, rf, w.w2, M), 2, r, split_, st));
     return 0;
 }
 
 namespace {
 struct CodecWs {
-    float *xa, *xb, *nb, *hid, *lat;
-    void plan(Bump& b, size_t max_img, size_t max_hidden, size_t lat_elems) {
+    float *xa, *xb, *nb, *lat;
+    bf16_t *n2hi, *n2lo, *hhi, *hlo;
+    void plan(Bump& b, size_t max_img, size_t max_rows_c, size_t max_hidden, size_t lat_elems) {
         xa = b.take<float>(max_img);
         xb = b.take<float>(max_img);
         nb = b.take<float>(max_img);
-        hid = b.take<float>(max_hidden);
+        n2hi = b.take<bf16_t>(max_rows_c);
+        n2lo = b.take<bf16_t>(max_rows_c);
+        hhi = b.take<bf16_t>(max_hidden);
+        hlo = b.take<bf16_t>(max_hidden);
         lat = b.take<float>(lat_elems);
     }
 };
@@ -891,7 +997,7 @@ size_t Engine::decode_ws_bytes(int B, int T) const {
     }
     Bump b(nullptr);
     CodecWs w;
-    w.plan(b, max_img, max_hid, (size_t)B * (kCodecPad + T) * s.latent_dim);
+    w.plan(b, max_img, max_img, max_hid, (size_t)B * (kCodecPad + T) * s.latent_dim);
     return b.off + 256;
 }
 
@@ -916,7 +1022,7 @@ int Engine::codec_decode(hipStream_t st, const float* latents, int B, int T, flo
     }
     Bump bump(ws);
     CodecWs w;
-    w.plan(bump, max_img, max_hid, (size_t)B * (pad + T) * L);
+    w.plan(bump, max_img, max_img, max_hid, (size_t)B * (pad + T) * L);
 
     // latent image with causal zero pad, then stem conv k (as GEMM over K*latent contiguous floats)
     HIPC(launch_zero_pad_frames(w.lat, B, T, L, pad, st));
@@ -948,7 +1054,7 @@ int Engine::codec_decode(hipStream_t st, const float* latents, int B, int T, flo
             C = Cn;
         }
         for (const CodecBlockW& b : sg.blocks)
-            if (codec_block(st, b, x, w.nb, w.hid, B, Ti, C)) return 1;
+            if (codec_block(st, b, x, w.nb, w.n2hi, w.n2lo, w.hhi, w.hlo, B, Ti, C)) return 1;
     }
     HIPC(launch_head_conv(x, dec_.head_w, dec_.head_b_host, audio, B, Ti, C, Kc, pad, st));
     return 0;
@@ -969,7 +1075,7 @@ size_t Engine::encode_ws_bytes(int B, int S_) const {
     }
     Bump b(nullptr);
     CodecWs w;
-    w.plan(b, max_img, max_hid, 1);
+    w.plan(b, max_img, max_img, max_hid, 1);
     return b.off + 256;
 }
 
@@ -993,7 +1099,7 @@ int Engine::codec_encode(hipStream_t st, const float* audio, int B, int S_, floa
     }
     Bump bump(ws);
     CodecWs w;
-    w.plan(bump, max_img, max_hid, 1);
+    w.plan(bump, max_img, max_img, max_hid, 1);
     float* x = w.xa;
     float* xn = w.xb;
     int Ti = S_;
@@ -1016,7 +1122,7 @@ int Engine::codec_encode(hipStream_t st, const float* audio, int B, int S_, floa
             C = Cn;
         }
         for (const CodecBlockW& b : sg.blocks)
-            if (codec_block(st, b, x, w.nb, w.hid, B, Ti, C)) return 1;
+            if (codec_block(st, b, x, w.nb, w.n2hi, w.n2lo, w.hhi, w.hlo, B, Ti, C)) return 1;
     }
     RowMap am = rowmap_batched(C, Ti, (long)(pad + Ti) * C, (long)(pad - (Kc - 1)) * C);
     HIPC(gemm_store(ops(x, am, enc_.head, B * Ti), ACT_NONE, store_to(latents, rowmap_plain(s.latent_dim), enc_.head_b), 1,
@@ -1043,6 +1149,25 @@ int Engine::test_gemm(hipStream_t st, const float* A, int lda, const float* W, c
     return e == hipSuccess ? 0 : fail_hip(e, "test_gemm");
 }
 
+int Engine::test_gemm3(hipStream_t st, const float* A, const float* W, const float* bias, int M, int N, int K, int act,
+                       int split, int cfg, float* C) {
+    HIPC(hipSetDevice(device_));
+    bf16_t *hi = nullptr, *lo = nullptr, *ahi = nullptr, *alo = nullptr;
+    HIPC(hipMalloc(&hi, (size_t)N * K * 2));
+    HIPC(hipMalloc(&lo, (size_t)N * K * 2));
+    HIPC(hipMalloc(&ahi, (size_t)M * K * 2));
+    HIPC(hipMalloc(&alo, (size_t)M * K * 2));
+    HIPC(launch_split_rows(W, K, hi, lo, K, N, K, nullptr, st));
+    HIPC(launch_to_split(A, rowmap_plain(K), ahi, alo, rowmap_plain(K), M, K, st));
+    PW w;
+    w.hi = hi; w.lo = lo; w.N = N; w.K = K;
+    hipError_t e = gemm3_store(ops3(SplitBuf{ahi, alo}, rowmap_plain(K), w, M), act, store_to(C, rowmap_plain(N), bias), 1,
+                               split, st, cfg);
+    (void)hipStreamSynchronize(st);
+    for (void* p : {(void*)hi, (void*)lo, (void*)ahi, (void*)alo}) (void)hipFree(p);
+    return e == hipSuccess ? 0 : fail_hip(e, "test_gemm3");
+}
+
 int Engine::test_swiglu(hipStream_t st, const float* A, const float* W1, const float* W3, const float* b1,
                         const float* b3, int M, int F, int K, int split, float* out) {
     HIPC(hipSetDevice(device_));
@@ -1061,9 +1186,70 @@ int Engine::test_swiglu(hipStream_t st, const float* A, const float* W1, const f
     HIPC(launch_split_rows(cat, K, hi, lo, K, 2 * F, K, dperm, st));
     PW w;
     w.hi = hi; w.lo = lo; w.N = 2 * F; w.K = K;
-    EpiSwiGLU sw{out, F, b1, b3};
+    EpiSwiGLU sw{out, F, b1, b3, nullptr, nullptr};
     hipError_t e = gemm_swiglu(ops(A, rowmap_plain(K), w, M), sw, split, st);
     (void)hipStreamSynchronize(st);
     (void)hipFree(cat); (void)hipFree(dperm); (void)hipFree(hi); (void)hipFree(lo);
     return e == hipSuccess ? 0 : fail_hip(e, "test_swiglu");
+}
+
+// epi: 0 store, 1 store+gelu, 2 swiglu (N = packed 2F), 3 resid tanh-gate
+int Engine::bench_gemm(int M, int N, int K, int epi, int split, int cfg, int iters, int ver, float* avg_us) {
+    HIPC(hipSetDevice(device_));
+    float *A = nullptr, *Wf = nullptr, *C = nullptr, *bias = nullptr, *gate = nullptr;
+    bf16_t *hi = nullptr, *lo = nullptr, *ahi = nullptr, *alo = nullptr;
+    const int saved_force = g_gemm_force_v1;
+    g_gemm_force_v1 = ver == 1;
+    HIPC(hipMalloc(&ahi, (size_t)M * K * 2));
+    HIPC(hipMalloc(&alo, (size_t)M * K * 2));
+    HIPC(hipMalloc(&A, (size_t)M * K * 4));
+    HIPC(hipMalloc(&Wf, (size_t)N * K * 4));
+    HIPC(hipMalloc(&C, (size_t)M * N * 4));
+    HIPC(hipMalloc(&bias, (size_t)N * 4));
+    HIPC(hipMalloc(&gate, (size_t)N * 4));
+    HIPC(hipMalloc(&hi, (size_t)N * K * 2));
+    HIPC(hipMalloc(&lo, (size_t)N * K * 2));
+    HIPC(launch_synth(A, (long)M * K, 1, 0.f, 1.f, 0));
+    HIPC(launch_synth(Wf, (long)N * K, 2, 0.f, 0.05f, 0));
+    HIPC(launch_synth(bias, N, 3, 0.f, 0.1f, 0));
+    HIPC(launch_synth(gate, N, 4, 0.f, 0.5f, 0));
+    HIPC(hipMemsetAsync(C, 0, (size_t)M * N * 4, 0));
+    HIPC(launch_split_rows(Wf, K, hi, lo, K, N, K, nullptr, 0));
+    PW w;
+    w.hi = hi; w.lo = lo; w.N = N; w.K = K;
+    GemmOperands g = ops(A, rowmap_plain(K), w, M);
+    HIPC(launch_to_split(A, rowmap_plain(K), ahi, alo, rowmap_plain(K), M, K, 0));
+    Gemm3Operands g3 = ops3(SplitBuf{ahi, alo}, rowmap_plain(K), w, M);
+    auto run = [&]() -> hipError_t {
+        if (ver == 3) {
+            switch (epi) {
+                case 0: return gemm3_store(g3, ACT_NONE, store_to(C, rowmap_plain(N), bias), 1, split, 0, cfg);
+                case 1: return gemm3_store(g3, ACT_GELU, store_to(C, rowmap_plain(N), bias), 1, split, 0, cfg);
+                case 2: { EpiSwiGLU sw{C, N / 2, bias, bias, nullptr, nullptr}; return gemm3_swiglu(g3, sw, split, 0); }
+                default: { EpiResid<0> r{C, rowmap_plain(N), bias, gate, 0, 0, 0, M, nullptr}; return gemm3_resid(g3, 1, r, split, 0, cfg); }
+            }
+        }
+        switch (epi) {
+            case 0: return gemm_store(g, ACT_NONE, store_to(C, rowmap_plain(N), bias), 1, split, 0, cfg);
+            case 1: return gemm_store(g, ACT_GELU, store_to(C, rowmap_plain(N), bias), 1, split, 0, cfg);
+            case 2: { EpiSwiGLU sw{C, N / 2, bias, bias, nullptr, nullptr}; return gemm_swiglu(g, sw, split, 0); }
+            default: { EpiResid<0> r{C, rowmap_plain(N), bias, gate, 0, 0, 0, M, nullptr}; return gemm_resid(g, 1, r, split, 0, cfg); }
+        }
+    };
+    for (int i = 0; i < 3; ++i) HIPC(run());
+    hipEvent_t e0, e1;
+    HIPC(hipEventCreate(&e0));
+    HIPC(hipEventCreate(&e1));
+    HIPC(hipEventRecord(e0, 0));
+    for (int i = 0; i < iters; ++i) HIPC(run());
+    HIPC(hipEventRecord(e1, 0));
+    HIPC(hipEventSynchronize(e1));
+    float ms = 0.f;
+    HIPC(hipEventElapsedTime(&ms, e0, e1));
+    *avg_us = ms * 1000.f / iters;
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    for (void* p : {(void*)A, (void*)Wf, (void*)C, (void*)bias, (void*)gate, (void*)hi, (void*)lo, (void*)ahi, (void*)alo})
+        (void)hipFree(p);
+    g_gemm_force_v1 = saved_force;
+    return 0;
 }

@@ -21,7 +21,7 @@ struct RawTensor {
 struct PW {  // packed GEMM weight [N][K], bf16 hi + lo
     bf16_t* hi = nullptr;
     bf16_t* lo = nullptr;
-    int N = 0, K = 0;
+    int N = 0, K = 0;  // K = row stride = GEMM K (may be zero-padded beyond the source width)
 };
 
 struct EncBlockW {
@@ -33,7 +33,8 @@ struct EncoderW {
     float eps;
     std::vector<EncBlockW> blocks;
     const float* final_norm;
-    float* rope;  // [MAXPOS][dh]
+    float* rope_cos;  // [MAXPOS][dh] cos / sin of pos * theta^(-2i/dh)
+    float* rope_sin;
 };
 struct DitBlockW {
     PW qkvg, out, ff13, ff2;
@@ -44,6 +45,7 @@ struct CodecBlockW {
     const float *norm_w, *dw_b, *gamma, *ffn_norm_w, *b1, *b2, *ffn_gamma;
     float* dw_w;  // [K][C]
     PW w1, w2;
+    PW w1f, w2f;  // fused-FFN packs for C <= 128: w1f [F][CP], w2f [CP][F], CP = max(C, 64); N == 0 when unused
 };
 struct CodecStageW {
     int C = 0, r = 0;  // r: resample ratio entering this stage (0 for stage 0)
@@ -88,6 +90,7 @@ class Engine {
     bool has_decoder() const { return dec_.ready; }
     bool has_encoder() const { return enc_.ready; }
     void set_precision(int split) { split_ = split == 1 ? 1 : 3; }
+    void set_fused_ffn(bool on) { fused_ffn_ = on; }
     int precision() const { return split_; }
 
     // ---- operators (device pointers, async on `st`) ------------------------------------------
@@ -126,6 +129,11 @@ class Engine {
     int test_swiglu(hipStream_t st, const float* A, const float* W1, const float* W3, const float* b1, const float* b3,
                     int M, int F, int K, int split, float* out);
 
+    // microbenchmark: time `iters` launches of one GEMM configuration with HIP events (tools/gemm_bench.py)
+    int bench_gemm(int M, int N, int K, int epi, int split, int cfg, int iters, int ver, float* avg_us);
+    int test_gemm3(hipStream_t st, const float* A, const float* W, const float* bias, int M, int N, int K, int act,
+                   int split, int cfg, float* C);
+
     int fail(const std::string& m) { err_ = m; return 1; }
     int fail_hip(hipError_t e, const char* what);
 
@@ -133,14 +141,14 @@ class Engine {
     void* dalloc(size_t bytes);
     const RawTensor* raw(const std::string& n) const;
     const float* rawp(const std::string& n) const;
-    PW pack_rows(const std::vector<std::string>& names, const std::vector<int>* perm = nullptr);
-    PW pack_from_f32(const float* src, int N, int K);
+    PW pack_rows(const std::vector<std::string>& names, const std::vector<int>* perm = nullptr, int k_pad = 0);
+    PW pack_from_f32(const float* src, int N, int K, int k_pad = 0, int n_pad = 0);
     float* concat_vec(const std::vector<std::string>& names, const std::vector<int>& zero_len = {});
     int finalize_dit();
     int finalize_codec(bool decoder);
     int build_encoder(EncoderW& e, const std::string& prefix, int dim, int heads, int ff, int layers, float eps);
-    int run_encoder(hipStream_t st, const EncoderW& e, float* x, float* y, float* qkvg, float* o, float* ffh, int B,
-                    int S, const uint8_t* key_mask);
+    int run_encoder(hipStream_t st, const EncoderW& e, void* enc_ws, int B, int S, const uint8_t* key_mask);
+    int make_rope(int dim, float** cos_out, float** sin_out);
     int modulation(hipStream_t st, const float* t_dev, int rows, float* sinb, float* t1, float* temb, float* e1,
                    float* semb, float* mod);
     struct DenoiseWs;
@@ -149,13 +157,15 @@ class Engine {
                      const float* k_text, const float* v_text, const uint8_t* ph_mask, const float* rope, int B,
                      int N, int R, int P, float* velocity, char* ws);
     size_t denoise_core_bytes(int B, int N) const;
-    int codec_block(hipStream_t st, const CodecBlockW& w, float* x, float* nbuf, float* hidden, int B, int T, int C);
+    int codec_block(hipStream_t st, const CodecBlockW& w, float* x, float* nbuf, bf16_t* n2hi, bf16_t* n2lo, bf16_t* hhi,
+                    bf16_t* hlo, int B, int T, int C);
 
     int device_;
     std::string err_;
     std::map<std::string, RawTensor> raw_;
     std::vector<void*> allocs_;
     int split_ = 3;
+    bool fused_ffn_ = true;  // test hook: smtts_test_set_fused_ffn
     Profiler prof_;
     bool prof_on_ = false;
     bool finalized_ = false;
@@ -168,7 +178,8 @@ class Engine {
     std::vector<DitBlockW> blocks_;
     EncoderW style_, text_;
     float style_scale_ = 1.f;
-    float* rope_dit_ = nullptr;  // [MAXPOS][64]
+    float *rope_dit_cos_ = nullptr, *rope_dit_sin_ = nullptr;  // [MAXPOS][64]
+    float *rope_tmp_cos_ = nullptr, *rope_tmp_sin_ = nullptr;  // cos/sin of a caller-supplied angle table
 
     CodecSpecC cspec_;
     CodecHalfW dec_, enc_;
@@ -178,6 +189,7 @@ void alpha_sigma_host(float t, float& a, float& s);
 
 static constexpr int kMaxPos = 4096;   // reference rope tables (dit.py:139, style.py:140)
 static constexpr int kHidden = 960, kHeads = 8, kDh = 120, kBlocks = 12, kFF = 2400, kLatent = 64;
+static constexpr int kFFp = 2432;  // FF hidden row stride: 2400 padded to a multiple of 64 (zero tail) for the DMA GEMM
 static constexpr int kModPerBlock = 6 * kHidden;
 static constexpr long kModLd = (long)kBlocks * kModPerBlock + 2 * kHidden;  // 71040
 static constexpr int kConvK = 31, kConvG = 16, kConvCpg = 60, kConvPad = 15, kConvGs = 64;

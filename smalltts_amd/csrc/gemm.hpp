@@ -37,6 +37,13 @@ __device__ __forceinline__ void split4(const float4& v, uint2& hi, uint2& lo) {
     lo = *reinterpret_cast<uint2*>(&l);
 }
 
+
+struct RowCtx;
+// Shared accumulator write-out for gemm_kernel / gemm2_kernel.  mw0 / nw0 = first row / column of this wave.
+template <int TM, int TN, class Epi>
+__device__ __forceinline__ void gemm_epilogue(const Epi& epi, floatx16 (&acc)[TM][TN], int M, int N, int mw0, int nw0,
+                                              int z, int lane);
+
 template <int BM, int BN, int BK, int WM, int WN, int SPLIT, class Epi>
 __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(GemmOperands g, Epi epi) {
     constexpr int NT = WM * WN * 64;
@@ -172,40 +179,25 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(GemmOperands g, Epi e
         }
     }
 
-    // epilogue: C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
-    const int cn = lane & 31, rm = 4 * (lane >> 5);
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-        const int mb = m0 + (wm * TM + i) * 32 + rm;
-        if (Epi::PAIRED) {
-            const int nb = n0 + wn * 64;  // packed column base (64 packed = 32 outputs)
-            const int nh = nb / 2 + cn;
-            if (nb + cn < g.N) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    int m = mb + (r & 3) + 8 * (r >> 2);
-                    if (m < g.M) epi.pair(z, m, nh, acc[i][0][r], acc[i][TN - 1][r]);
-                }
-            }
-        } else {
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const int n = n0 + (wn * TN + j) * 32 + cn;
-                if (n < g.N) {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        int m = mb + (r & 3) + 8 * (r >> 2);
-                        if (m < g.M) epi.one(z, m, n, acc[i][j][r]);
-                    }
-                }
-            }
-        }
-    }
+    gemm_epilogue<TM, TN, Epi>(epi, acc, g.M, g.N, m0 + wm * TM * 32, n0 + wn * TN * 32, z, lane);
 }
 
 // ------------------------------------------------------------------------------------------
 // Epilogues
+//
+// A lane of a 32x32 MFMA tile owns ONE output column n and 16 rows m_r = mb + (r&3) + 8*(r>>2).
+// Protocol: `rows()` derives everything that depends on the row only (addresses, masks, gate rows)
+// once per 32-row tile; `col()` then handles one column: every global LOAD (bias, gate, residual)
+// is issued before the first STORE, so the 16 elements pipeline instead of paying one memory
+// round trip each (output and parameter pointers may alias as far as the compiler knows).
 // ------------------------------------------------------------------------------------------
+struct RowCtx {
+    long off[16];
+    int aux[16];
+    unsigned valid;  // bit r: row in range (and not masked out, where the epilogue skips masked rows)
+};
+__device__ __forceinline__ int epi_row(int mb, int r) { return mb + (r & 3) + 8 * (r >> 2); }
+
 // out[omap(m) + n] = mask(m) * act((acc + bias[n]) * scale)
 template <int ACT>
 struct EpiStore {
@@ -216,14 +208,39 @@ struct EpiStore {
     const float* bias;     // may be null; indexed [n] (+ z*bias_z)
     long bias_z;
     float scale;
-    const uint8_t* rowmask;  // may be null; [m]
-    __device__ __forceinline__ void one(int z, int m, int n, float v) const {
-        if (bias) v += bias[(long)z * bias_z + n];
-        v = apply_act<ACT>(v * scale);
-        if (rowmask && !rowmask[m]) v = 0.f;
-        out[(long)z * o_z + omap.at(m) + n] = v;
+    const uint8_t* rowmask;  // may be null; [m]: masked rows are written as 0
+    bf16_t* ohi;             // when non-null the result is written as a split bf16 pair (ohi/olo) instead of `out`
+    bf16_t* olo;
+    __device__ __forceinline__ void rows(int z, int mb, int M, RowCtx& rc) const {
+        rc.valid = 0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = epi_row(mb, r);
+            const bool ok = m < M;
+            rc.off[r] = (long)z * o_z + omap.at(ok ? m : 0);
+            rc.aux[r] = (ok && rowmask) ? rowmask[m] : 1;
+            rc.valid |= (ok ? 1u : 0u) << r;
+        }
     }
-    __device__ __forceinline__ void pair(int, int, int, float, float) const {}
+    __device__ __forceinline__ void col(int z, int n, const RowCtx& rc, const floatx16& acc) const {
+        const float b = bias ? bias[(long)z * bias_z + n] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            if (rc.valid >> r & 1) {
+                float v = apply_act<ACT>((acc[r] + b) * scale);
+                v = rc.aux[r] ? v : 0.f;
+                if (ohi) {
+                    bf16_t hh, ll;
+                    split1(v, hh, ll);
+                    ohi[rc.off[r] + n] = hh;
+                    if (olo) olo[rc.off[r] + n] = ll;
+                } else {
+                    out[rc.off[r] + n] = v;
+                }
+            }
+        }
+    }
+    __device__ __forceinline__ void colpair(int, int, const RowCtx&, const floatx16&, const floatx16&) const {}
 };
 
 // SwiGLU on interleaved [w1 | w3] 32-column groups: out[m][nh] = silu(a + b1[nh]) * (b + b3[nh])
@@ -233,39 +250,82 @@ struct EpiSwiGLU {
     long ldo;
     const float* b1;  // may be null
     const float* b3;
-    __device__ __forceinline__ void one(int, int, int, float) const {}
-    __device__ __forceinline__ void pair(int, int m, int nh, float a, float b) const {
-        if (b1) { a += b1[nh]; b += b3[nh]; }
-        out[(long)m * ldo + nh] = (a / (1.0f + expf(-a))) * b;
+    bf16_t* ohi;      // optional split output (see EpiStore)
+    bf16_t* olo;
+    __device__ __forceinline__ void rows(int, int mb, int M, RowCtx& rc) const {
+        rc.valid = 0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = epi_row(mb, r);
+            rc.off[r] = (long)m * ldo;
+            rc.valid |= (m < M ? 1u : 0u) << r;
+        }
+    }
+    __device__ __forceinline__ void col(int, int, const RowCtx&, const floatx16&) const {}
+    __device__ __forceinline__ void colpair(int, int nh, const RowCtx& rc, const floatx16& a, const floatx16& b) const {
+        const float v1 = b1 ? b1[nh] : 0.f, v3 = b1 ? b3[nh] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            if (rc.valid >> r & 1) {
+                const float x = a[r] + v1;
+                const float v = silu_f(x) * (b[r] + v3);
+                if (ohi) {
+                    bf16_t hh, ll;
+                    split1(v, hh, ll);
+                    ohi[rc.off[r] + nh] = hh;
+                    if (olo) olo[rc.off[r] + nh] = ll;
+                } else {
+                    out[rc.off[r] + nh] = v;
+                }
+            }
+        }
     }
 };
 
 // x[xmap(m) + n] += mask(m) * g(batch(m), n) * (acc + bias[n])
-//   GATE 0: g = 1      GATE 1: g = tanh(gate[(grow0 + batch*grstride) * gld + n])     GATE 2: g = gate[n]
+//   GATE 0: g = 1      GATE 1: g = gate[(grow0 + batch*grstride) * gld + n]  (table holds tanh(gate) already,
+//   launch_tanh_gates)     GATE 2: g = gate[n]
 template <int GATE>
 struct EpiResid {
     static constexpr bool PAIRED = false;
     float* x;
     RowMap xmap;
     const float* bias;       // may be null
-    const float* gate;       // table (GATE 1: rows selected by grow[], GATE 2: vector)
+    const float* gate;       // table (GATE 1) or vector (GATE 2)
     long gld;
     int grow0, grstride;     // gate-table row of batch b = grow0 + b*grstride (GATE 1)
     int rows_per_batch;      // batch(m) = m / rows_per_batch (GATE 1)
-    const uint8_t* rowmask;  // may be null
-    __device__ __forceinline__ void one(int, int m, int n, float v) const {
-        if (rowmask && !rowmask[m]) return;
-        if (bias) v += bias[n];
-        if (GATE == 1) {
-            int b = m / rows_per_batch;
-            v *= tanhf(gate[(long)(grow0 + b * grstride) * gld + n]);
-        } else if (GATE == 2) {
-            v *= gate[n];
+    const uint8_t* rowmask;  // may be null: masked rows are left untouched
+    __device__ __forceinline__ void rows(int, int mb, int M, RowCtx& rc) const {
+        rc.valid = 0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = epi_row(mb, r);
+            bool ok = m < M;
+            if (ok && rowmask) ok = rowmask[m] != 0;
+            rc.off[r] = xmap.at(ok ? m : 0);
+            rc.aux[r] = GATE == 1 ? grow0 + ((ok ? m : 0) / rows_per_batch) * grstride : 0;
+            rc.valid |= (ok ? 1u : 0u) << r;
         }
-        long o = xmap.at(m) + n;
-        x[o] += v;
     }
-    __device__ __forceinline__ void pair(int, int, int, float, float) const {}
+    __device__ __forceinline__ void col(int, int n, const RowCtx& rc, const floatx16& acc) const {
+        const float b = bias ? bias[n] : 0.f;
+        float gv[16], xv[16];
+        const float g2 = GATE == 2 ? gate[n] : 1.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const bool ok = rc.valid >> r & 1;
+            gv[r] = (GATE == 1 && ok) ? gate[(long)rc.aux[r] * gld + n] : g2;
+            xv[r] = ok ? x[rc.off[r] + n] : 0.f;
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            if (rc.valid >> r & 1) {
+                x[rc.off[r] + n] = xv[r] + gv[r] * (acc[r] + b);
+            }
+        }
+    }
+    __device__ __forceinline__ void colpair(int, int, const RowCtx&, const floatx16&, const floatx16&) const {}
 };
 
 // Cross-KV scatter (reference dit.py:80-93): rows m = (b, j), columns n = ((layer*2 + kv)*H + h)*dh + d
@@ -276,16 +336,30 @@ struct EpiKV {
     float* vdst;
     const float* bias;  // [n]
     int B, H, dh, S;    // S = keys per batch row (R or P)
-    __device__ __forceinline__ void one(int, int m, int n, float v) const {
-        v += bias[n];
-        int d = n % dh, t = n / dh;
-        int h = t % H; t /= H;
-        int kv = t & 1, layer = t >> 1;
-        int b = m / S, j = m % S;
-        long o = ((((long)layer * B + b) * H + h) * S + j) * dh + d;
-        (kv ? vdst : kdst)[o] = v;
+    __device__ __forceinline__ void rows(int, int mb, int M, RowCtx& rc) const {
+        rc.valid = 0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = epi_row(mb, r);
+            const bool ok = m < M;
+            const int b = (ok ? m : 0) / S, j = (ok ? m : 0) % S;
+            rc.off[r] = ((long)b * H * S + j) * dh;
+            rc.valid |= (ok ? 1u : 0u) << r;
+        }
     }
-    __device__ __forceinline__ void pair(int, int, int, float, float) const {}
+    __device__ __forceinline__ void col(int, int n, const RowCtx& rc, const floatx16& acc) const {
+        const float bv = bias[n];
+        int d = n % dh, t = n / dh;
+        const int h = t % H;
+        t /= H;
+        const int kv = t & 1, layer = t >> 1;
+        float* dst = kv ? vdst : kdst;
+        const long cbase = ((long)layer * B * H + h) * S * dh + d;
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            if (rc.valid >> r & 1) dst[cbase + rc.off[r]] = acc[r] + bv;
+    }
+    __device__ __forceinline__ void colpair(int, int, const RowCtx&, const floatx16&, const floatx16&) const {}
 };
 
 // Grouped conv position embedding (reference dit.py:215-236) as per-(batch, group) GEMMs.
@@ -300,20 +374,70 @@ struct EpiConvPos {
     const float* bias;    // [G*cpg]
     const uint8_t* mask;  // [B][T]
     int G, cpg, T, pad, gstride;  // gstride = padded channels per group in gm image
-    __device__ __forceinline__ void one(int z, int m, int n, float v) const {
-        int b = z / G, g = z % G;
-        int ch = g * cpg + n;
-        v = mish_f(v + bias[ch]);
-        if (!mask[b * T + m]) v = 0.f;
-        if (FINAL) {
-            long o = ((long)b * T + m) * (G * cpg) + ch;
-            out[o] = v + h[o];
-        } else {
-            out[((long)z * (T + 2 * pad) + pad + m) * gstride + n] = v;
+    bf16_t* ohi;          // FINAL == 0: optional split output image
+    bf16_t* olo;
+    __device__ __forceinline__ void rows(int z, int mb, int M, RowCtx& rc) const {
+        const int b = z / G;
+        rc.valid = 0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = epi_row(mb, r);
+            const bool ok = m < M;
+            const int mm = ok ? m : 0;
+            rc.aux[r] = mask[b * T + mm];
+            rc.off[r] = FINAL ? ((long)b * T + mm) * (G * cpg) : ((long)z * (T + 2 * pad) + pad + mm) * gstride;
+            rc.valid |= (ok ? 1u : 0u) << r;
         }
     }
-    __device__ __forceinline__ void pair(int, int, int, float, float) const {}
+    __device__ __forceinline__ void col(int z, int n, const RowCtx& rc, const floatx16& acc) const {
+        const int ch = (z % G) * cpg + n;
+        const float bv = bias[ch];
+        float hv[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) hv[r] = (FINAL && (rc.valid >> r & 1)) ? h[rc.off[r] + ch] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            if (rc.valid >> r & 1) {
+                const float v = rc.aux[r] ? mish_f(acc[r] + bv) : 0.f;
+                if (FINAL) {
+                    out[rc.off[r] + ch] = v + hv[r];
+                } else if (ohi) {
+                    bf16_t hh, ll;
+                    split1(v, hh, ll);
+                    ohi[rc.off[r] + n] = hh;
+                    if (olo) olo[rc.off[r] + n] = ll;
+                } else {
+                    out[rc.off[r] + n] = v;
+                }
+            }
+        }
+    }
+    __device__ __forceinline__ void colpair(int, int, const RowCtx&, const floatx16&, const floatx16&) const {}
 };
+
+// C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+template <int TM, int TN, class Epi>
+__device__ __forceinline__ void gemm_epilogue(const Epi& epi, floatx16 (&acc)[TM][TN], int M, int N, int mw0, int nw0,
+                                              int z, int lane) {
+    const int cn = lane & 31, rm = 4 * (lane >> 5);
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int mb = mw0 + i * 32 + rm;
+        if (mb - rm >= M) continue;
+        RowCtx rc;
+        epi.rows(z, mb, M, rc);
+        if (Epi::PAIRED) {
+            const int nh = nw0 / 2 + cn;  // packed column base nw0 (64 packed = 32 outputs)
+            if (nw0 + cn < N) epi.colpair(z, nh, rc, acc[i][0], acc[i][TN - 1]);
+        } else {
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int n = nw0 + j * 32 + cn;
+                if (n < N) epi.col(z, n, rc, acc[i][j]);
+            }
+        }
+    }
+}
 
 // ------------------------------------------------------------------------------------------
 // Launcher

@@ -1,0 +1,288 @@
+// GEMM v3 for gfx950 — the hot-path kernel.
+//   C[M,N] = A[M,K] x W[N,K]^T with BOTH operands already split into bf16 hi/lo arrays in HBM:
+//   weights at smtts_finalize, activations by the epilogue / norm kernel that produced them (each
+//   element is split exactly once, instead of once per consuming workgroup as in v1/v2).
+// * all four tile arrays (Ahi, Alo, Whi, Wlo; [rows][64] bf16 = 128 B rows) arrive by direct-to-LDS
+//   DMA (global_load_lds_dwordx4, 1 KiB per wave-instruction) into an S-stage ring; the XOR swizzle
+//   (16-B chunk c of row r at position c ^ ((r>>1)&7)) is applied on the per-lane SOURCE address so
+//   every ds_read_b128 fragment read is bank-conflict free;
+// * the k-loop is ds_read_b128 + v_mfma_f32_32x32x16_bf16 only (no VALU conversion, no ds_write),
+//   one raw s_barrier per k-tile, counted s_waitcnt vmcnt so S-1 tiles stay in flight;
+// * 8 waves (2 per SIMD) per workgroup so one wave's LDS latency hides under the other's MFMAs.
+// Requires K % 64 == 0, 16-B aligned rows.  Epilogue functors are shared with gemm.hpp.
+#pragma once
+#include "gemm2.hpp"
+
+struct Gemm3Operands {
+    const bf16_t* Ahi;
+    const bf16_t* Alo;
+    RowMap amap;  // element offsets into Ahi / Alo
+    const bf16_t* Whi;
+    const bf16_t* Wlo;
+    long ldw;
+    int M, N, K;
+    long a_z, w_z;
+    int w_zmod;
+};
+
+template <int BM, int BN, int WM, int WN, int SPLIT, int S, class Epi>
+__global__ __launch_bounds__(WM* WN * 64) void gemm3_kernel(Gemm3Operands g, Epi epi) {
+    constexpr int BK = 64;
+    constexpr int NW = WM * WN;
+    constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
+    constexpr int NARR = SPLIT == 3 ? 2 : 1;
+    constexpr int A_ARR = BM * 128, W_ARR = BN * 128;  // bytes per array per stage
+    constexpr int STAGE = NARR * (A_ARR + W_ARR);
+    constexpr int NA = NARR * (BM / 8), NWS = NARR * (BN / 8);  // DMA slots (8 rows each)
+    constexpr int PW = (NA + NWS) / NW;                         // slots per wave per stage
+    static_assert(PW * NW == NA + NWS, "DMA slots must divide evenly over the waves");
+    static_assert(!Epi::PAIRED || TN == 2, "paired epilogue needs a 32x64 wave tile");
+    // L2 prefetch-touch: one dword load per 128-B line of the tile PFD k-tiles beyond the stage being DMA'd.  HBM
+    // has spare bandwidth (the loop is bound by bytes-in-flight / latency), so touching early makes the later DMA an
+    // L2 hit.  Issued from every wave right after each stage's DMA so the vmcnt arithmetic stays uniform.
+    // Measured on MI355X: no gain (dit.qkvg 36.5 -> 42 us), i.e. HBM-miss latency is not what binds -> disabled (PFD = 0).
+    constexpr int PFD = 0;
+    constexpr int LINES = NARR * (BM + BN);
+    constexpr int PFN = PFD ? (LINES + NW * 64 - 1) / (NW * 64) : 0;  // touch instructions per wave per k-tile
+    constexpr int OPS = PW + PFN;                            // VMEM ops per wave per k-tile
+    static_assert((S - 2) * PW + (S - 1) * PFN <= 63, "vmcnt immediate overflow");
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    // XCD-aware tile order (workgroup p runs on XCD p % 8, each XCD has its own L2): give every XCD a
+    // contiguous run of virtual tile ids, M-tile fastest, so all M-tiles that share one W panel (and the
+    // activation rows they stream) hit the same L2 instead of re-fetching the panel on 8 XCDs.
+    const int Mt = (g.M + BM - 1) / BM, Nt = (g.N + BN - 1) / BN;
+    int vid;
+    {
+        const int p = blockIdx.x, tot = Mt * Nt;
+        const int q = tot / 8, r = tot % 8, xcd = p % 8, loc = p / 8;
+        vid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+    }
+    const int m0 = (vid % Mt) * BM, n0 = (vid / Mt) * BN, z = blockIdx.z;
+    const long wz = (long)(g.w_zmod ? z % g.w_zmod : z) * g.w_z;
+
+    // ---- per-lane DMA sources: slot -> (array, 8-row block) --------------------------------------
+    const bf16_t* src[PW];
+    unsigned dst[PW];  // wave-uniform LDS byte offset inside a stage
+#pragma unroll
+    for (int i = 0; i < PW; ++i) {
+        const int slot = wave * PW + i;  // wave-uniform
+        const int rl = lane >> 3, p = lane & 7;
+        if (slot < NA) {
+            const int arr = slot / (BM / 8), rb = slot % (BM / 8);
+            const int r = rb * 8 + rl;
+            const int c = p ^ ((r >> 1) & 7);
+            int m = m0 + r;
+            m = m < g.M ? m : g.M - 1;
+            src[i] = (arr ? g.Alo : g.Ahi) + (long)z * g.a_z + g.amap.at(m) + c * 8;
+            dst[i] = arr * A_ARR + rb * 1024;
+        } else {
+            const int s2 = slot - NA;
+            const int arr = s2 / (BN / 8), rb = s2 % (BN / 8);
+            const int r = rb * 8 + rl;
+            const int c = p ^ ((r >> 1) & 7);
+            int n = n0 + r;
+            n = n < g.N ? n : g.N - 1;
+            src[i] = (arr ? g.Wlo : g.Whi) + wz + (long)n * g.ldw + c * 8;
+            dst[i] = NARR * A_ARR + arr * W_ARR + rb * 1024;
+        }
+    }
+
+    auto dma16 = [&](const void* gsrc, unsigned lds_dst) {
+        unsigned keep;
+        asm volatile(
+            "s_mov_b32 %0, m0\n\t"
+            "s_mov_b32 m0, %2\n\t"
+            "s_nop 0\n\t"
+            "global_load_lds_dwordx4 %1, off\n\t"
+            "s_mov_b32 m0, %0"
+            : "=&s"(keep)
+            : "v"(gsrc), "s"(lds_dst)
+            : "memory");
+    };
+    const unsigned lds0 = (unsigned)(size_t)SM_LPTR(smem);
+    const int nk = g.K / BK;
+    const bf16_t* pf[PFN ? PFN : 1];
+#pragma unroll
+    for (int i = 0; i < PFN; ++i) {
+        int L = i * NW * 64 + tid;  // line index: [arrays of A rows | arrays of W rows]
+        L = L < LINES ? L : LINES - 1;
+        if (L < NARR * BM) {
+            const int arr = L / BM;
+            int m = m0 + L % BM;
+            m = m < g.M ? m : g.M - 1;
+            pf[i] = (arr ? g.Alo : g.Ahi) + (long)z * g.a_z + g.amap.at(m);
+        } else {
+            const int L2 = L - NARR * BM, arr = L2 / BN;
+            int n = n0 + L2 % BN;
+            n = n < g.N ? n : g.N - 1;
+            pf[i] = (arr ? g.Wlo : g.Whi) + wz + (long)n * g.ldw;
+        }
+    }
+    // The touch is a 4-byte LDS-DMA into a 256-B dummy slot behind the ring: a VGPR destination would be written
+    // asynchronously, long after hipcc may have reused that register (e.g. for a DMA address -> memory fault).
+    auto touch4 = [&](const void* gsrc, unsigned lds_dst) {
+        unsigned keep;
+        asm volatile(
+            "s_mov_b32 %0, m0\n\t"
+            "s_mov_b32 m0, %2\n\t"
+            "s_nop 0\n\t"
+            "global_load_lds_dword %1, off\n\t"
+            "s_mov_b32 m0, %0"
+            : "=&s"(keep)
+            : "v"(gsrc), "s"(lds_dst)
+            : "memory");
+    };
+    auto issue = [&](int kt) {
+        const unsigned st = lds0 + (unsigned)((kt % S) * STAGE);
+#pragma unroll
+        for (int i = 0; i < PW; ++i)
+            dma16(src[i] + kt * BK, st + (unsigned)__builtin_amdgcn_readfirstlane((int)dst[i]));
+        int kp = kt + PFD;
+        kp = kp < nk ? kp : nk - 1;
+#pragma unroll
+        for (int i = 0; i < PFN; ++i)
+            touch4(pf[i] + kp * BK, lds0 + (unsigned)(S * STAGE));
+    };
+
+    floatx16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // fragment byte offsets inside a stage for the 4 k16-steps (constant over k-tiles)
+    const int fr = lane & 31, fh = lane >> 5;
+    int a_off[TM][4], w_off[TN][4];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int r = (wm * TM + i) * 32 + fr;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) a_off[i][kk] = r * 128 + (((kk * 2 + fh) ^ ((r >> 1) & 7)) << 4);
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int r = (wn * TN + j) * 32 + fr;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+            w_off[j][kk] = NARR * A_ARR + r * 128 + (((kk * 2 + fh) ^ ((r >> 1) & 7)) << 4);
+    }
+
+#pragma unroll
+    for (int s = 0; s < S - 1; ++s)
+        if (s < nk) issue(s);
+
+    for (int kt = 0; kt < nk; ++kt) {
+        // younger than stage kt's DMA: its own touch loads + (S-2) full later stages
+        if (kt + S - 1 <= nk)
+            wait_vmcnt<(S - 2) * OPS + PFN>();
+        else
+            wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        if (kt + S - 1 < nk) issue(kt + S - 1);
+        const char* st = smem + (kt % S) * STAGE;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            bf16x8 ah[TM], al[TM], bh[TN], bl[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                ah[i] = *reinterpret_cast<const bf16x8*>(st + a_off[i][kk]);
+                if (SPLIT == 3) al[i] = *reinterpret_cast<const bf16x8*>(st + a_off[i][kk] + A_ARR);
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                bh[j] = *reinterpret_cast<const bf16x8*>(st + w_off[j][kk]);
+                if (SPLIT == 3) bl[j] = *reinterpret_cast<const bf16x8*>(st + w_off[j][kk] + W_ARR);
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    if (SPLIT == 3) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+                    }
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+                }
+        }
+    }
+    gemm_epilogue<TM, TN, Epi>(epi, acc, g.M, g.N, m0 + wm * TM * 32, n0 + wn * TN * 32, z, lane);
+}
+
+template <int BM, int BN, int WM, int WN, int SPLIT, int S, class Epi>
+static inline hipError_t gemm3_launch_cfg(const Gemm3Operands& g, const Epi& epi, int Z, hipStream_t st) {
+    constexpr int NARR = SPLIT == 3 ? 2 : 1;
+    constexpr size_t lds = (size_t)S * NARR * (BM + BN) * 128 + 256;  // ring + dummy slot of the prefetch touches
+    static_assert(lds <= 160 * 1024, "LDS ring exceeds 160 KiB");
+    dim3 grid(((g.N + BN - 1) / BN) * ((g.M + BM - 1) / BM), 1, Z);  // 1-D tile index, remapped per XCD in-kernel
+    auto kern = gemm3_kernel<BM, BN, WM, WN, SPLIT, S, Epi>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(kern, grid, dim3(WM * WN * 64), lds, st, g, epi);
+    return hipGetLastError();
+}
+
+enum Gemm3Cfg {
+    G3_64x128 = 0,   // 8 waves 2x4, wave 32x32, 3 stages (144 KiB): general
+    G3_128x128 = 1,  // 8 waves 4x2, wave 32x64, 2 stages (128 KiB): SwiGLU pairs, large M x N
+    G3_64x64 = 2,    // 4 waves 2x2, wave 32x32, 2 stages (64 KiB) -> 2 workgroups / CU: small N
+    G3_128x64 = 3,   // 8 waves 4x2, wave 32x32, 3 stages (144 KiB): tall, N <= 64
+    G3_128x32 = 4,   // 4 waves 4x1, wave 32x32, 2 stages (80 KiB) -> 2 workgroups / CU: tall, N <= 32
+};
+
+static inline int gemm3_pick_cfg(int M, int N, bool paired) {
+    if (paired) return G3_128x128;
+    if (N <= 32) return G3_128x32;
+    if (N <= 64) return M >= 2048 ? G3_128x64 : G3_64x64;
+    const long t128 = (long)((M + 127) / 128) * ((N + 127) / 128);
+    if (t128 >= 512) return G3_128x128;
+    const long t64x128 = (long)((M + 63) / 64) * ((N + 127) / 128);
+    if (t64x128 >= 200) return G3_64x128;
+    return G3_64x64;
+}
+
+static inline bool gemm3_ok(const Gemm3Operands& g) {
+    return g.K % 64 == 0 && g.K >= 64 && (g.amap.ld % 8) == 0 && (g.amap.off % 8) == 0 && (g.ldw % 8) == 0 &&
+           (g.amap.bstride % 8) == 0;
+}
+
+template <int SPLIT, class Epi>
+static inline hipError_t gemm3_launch_split(const Gemm3Operands& g, const Epi& epi, int Z, int cfg, hipStream_t st) {
+    switch (cfg) {
+        case G3_128x128:
+            return gemm3_launch_cfg<128, 128, 4, 2, SPLIT, 2, Epi>(g, epi, Z, st);
+        case G3_64x128:
+            if constexpr (!Epi::PAIRED) return gemm3_launch_cfg<64, 128, 2, 4, SPLIT, 3, Epi>(g, epi, Z, st);
+            break;
+        case G3_64x64:
+            if constexpr (!Epi::PAIRED) return gemm3_launch_cfg<64, 64, 2, 2, SPLIT, 2, Epi>(g, epi, Z, st);
+            break;
+        case G3_128x64:
+            if constexpr (!Epi::PAIRED) return gemm3_launch_cfg<128, 64, 4, 2, SPLIT, 3, Epi>(g, epi, Z, st);
+            break;
+        case G3_128x32:
+            if constexpr (!Epi::PAIRED) return gemm3_launch_cfg<128, 32, 4, 1, SPLIT, 2, Epi>(g, epi, Z, st);
+            break;
+    }
+    return hipErrorInvalidValue;
+}
+
+template <class Epi>
+static inline hipError_t gemm3_launch(const Gemm3Operands& g, const Epi& epi, int Z, int split, hipStream_t st,
+                                      int cfg = -1) {
+    if (g.M <= 0 || g.N <= 0) return hipSuccess;
+    if (!gemm3_ok(g)) return hipErrorInvalidValue;
+    if (cfg < 0) cfg = gemm3_pick_cfg(g.M, g.N, Epi::PAIRED);
+    if (split == 3) return gemm3_launch_split<3, Epi>(g, epi, Z, cfg, st);
+    return gemm3_launch_split<1, Epi>(g, epi, Z, cfg, st);
+}

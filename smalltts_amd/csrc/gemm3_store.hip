@@ -1,0 +1,16 @@
+#include "gemm_ops.hpp"
+#include "prof.hpp"
+template <int ACT>
+static EpiStore<ACT> conv(const EpiStore<ACT_NONE>& p) {
+    return EpiStore<ACT>{p.out, p.omap, p.o_z, p.bias, p.bias_z, p.scale, p.rowmask, p.ohi, p.olo};
+}
+hipError_t gemm3_store(const Gemm3Operands& g, int act, const EpiStore<ACT_NONE>& p, int Z, int split, hipStream_t st, int cfg) {
+    static const char* names[] = {"store", "store_silu", "store_gelu", "store_mish"};
+    ProfScope ps(st, gemm3_prof_name(g, false, cfg, split, names[act & 3]), gemm3_flops(g, Z), gemm3_bytes(g, Z, split, 4.0));
+    switch (act) {
+        case ACT_NONE: return gemm3_launch(g, p, Z, split, st, cfg);
+        case ACT_SILU: return gemm3_launch(g, conv<ACT_SILU>(p), Z, split, st, cfg);
+        case ACT_GELU: return gemm3_launch(g, conv<ACT_GELU>(p), Z, split, st, cfg);
+    }
+    return hipErrorInvalidValue;
+}

@@ -3,16 +3,17 @@
 #pragma once
 #include <string>
 
-#include "gemm.hpp"
+#include "gemm3.hpp"
 
 // kernel identity used by the profiler, e.g. "gemm<64x128x64,s3,store_gelu>"; mirrors the template
 // arguments of the gemm_kernel instantiation that gemm_launch() picks for (cfg, split, K).
-static inline std::string gemm_prof_name(int M, int N, int K, bool paired, int cfg, int split, const char* epi) {
-    if (cfg < 0) cfg = gemm_pick_cfg(M, N, K, paired);
+static inline std::string gemm_prof_name(const GemmOperands& g, bool paired, int cfg, int split, const char* epi) {
+    if (cfg < 0) cfg = gemm_pick_cfg(g.M, g.N, g.K, paired);
     static const char* tiles[] = {"64x128x64", "64x64x64", "128x128x64", "128x32x64", "128x64x64"};
     std::string t = tiles[cfg];
-    if (cfg == CFG_128x64 && K <= 32) t = "128x64x32";
-    return "gemm<" + t + ",s" + std::to_string(split) + "," + epi + ">";
+    const bool v2 = !g_gemm_force_v1 && gemm2_ok(g);
+    if (!v2 && cfg == CFG_128x64 && g.K <= 32) t = "128x64x32";
+    return std::string(v2 ? "gemm2<" : "gemm<") + t + ",s" + std::to_string(split) + "," + epi + ">";
 }
 // algorithmic work of one GEMM launch: 2*M*N*K flops (x Z); bytes = A fp32 read once + W (bf16 hi[+lo]) read
 // once + C fp32 written once (+ read once for residual epilogues)
@@ -29,3 +30,20 @@ hipError_t gemm_swiglu(const GemmOperands& g, const EpiSwiGLU& p, int split, hip
 hipError_t gemm_resid(const GemmOperands& g, int gate_mode, const EpiResid<0>& p, int split, hipStream_t st, int cfg = -1);
 hipError_t gemm_kv(const GemmOperands& g, const EpiKV& p, int split, hipStream_t st);
 hipError_t gemm_convpos(const GemmOperands& g, bool final, const EpiConvPos<0>& p, int Z, int split, hipStream_t st);
+
+// ---- v3 (split-A, DMA ring, 8 waves) entry points: definitions in gemm3_ops.hip --------------------------
+static inline std::string gemm3_prof_name(const Gemm3Operands& g, bool paired, int cfg, int split, const char* epi) {
+    if (cfg < 0) cfg = gemm3_pick_cfg(g.M, g.N, paired);
+    static const char* tiles[] = {"64x128", "128x128", "64x64", "128x64", "128x32"};
+    return std::string("gemm3<") + tiles[cfg] + ",s" + std::to_string(split) + "," + epi + ">";
+}
+static inline double gemm3_flops(const Gemm3Operands& g, int Z) { return 2.0 * g.M * (double)g.N * g.K * Z; }
+static inline double gemm3_bytes(const Gemm3Operands& g, int Z, int split, double c_bytes_per_out, bool w_shared = false) {
+    const double e = split == 3 ? 4.0 : 2.0;
+    return Z * ((double)g.M * g.K * e + (double)g.M * g.N * c_bytes_per_out) + (double)g.N * g.K * e * (w_shared ? 1 : Z);
+}
+hipError_t gemm3_store(const Gemm3Operands& g, int act, const EpiStore<ACT_NONE>& p, int Z, int split, hipStream_t st, int cfg = -1);
+hipError_t gemm3_swiglu(const Gemm3Operands& g, const EpiSwiGLU& p, int split, hipStream_t st);
+hipError_t gemm3_resid(const Gemm3Operands& g, int gate_mode, const EpiResid<0>& p, int split, hipStream_t st, int cfg = -1);
+hipError_t gemm3_kv(const Gemm3Operands& g, const EpiKV& p, int split, hipStream_t st);
+hipError_t gemm3_convpos(const Gemm3Operands& g, bool final, const EpiConvPos<0>& p, int Z, int split, hipStream_t st);

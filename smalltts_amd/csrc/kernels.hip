@@ -10,7 +10,8 @@
 // AdaLN:  y = LN(x) * (1 + scale) + shift       one wave per row, row kept in registers
 // ------------------------------------------------------------------------------------------
 template <int MAXV>
-__global__ __launch_bounds__(256) void ln_modulate_kernel(const float* __restrict__ x, float* __restrict__ y, int M,
+__global__ __launch_bounds__(256) void ln_modulate_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                          bf16_t* __restrict__ yhi, bf16_t* __restrict__ ylo, int M,
                                                           int C, float eps, const float* __restrict__ shift,
                                                           const float* __restrict__ scale, long mod_ld,
                                                           int mod_row0, int mod_rstride, int rpb) {
@@ -41,17 +42,27 @@ __global__ __launch_bounds__(256) void ln_modulate_kernel(const float* __restric
 #pragma unroll
     for (int i = 0; i < MAXV; ++i) {
         int c = lane + 64 * i;
-        if (c < C) yr[c] = (v[i] - mean) * rstd * (1.0f + scale[r + c]) + shift[r + c];
+        if (c < C) {
+            const float o = (v[i] - mean) * rstd * (1.0f + scale[r + c]) + shift[r + c];
+            if (yhi) {
+                bf16_t h, l;
+                split1(o, h, l);
+                yhi[(long)row * C + c] = h;
+                if (ylo) ylo[(long)row * C + c] = l;
+            } else {
+                yr[c] = o;
+            }
+        }
     }
 }
 
-hipError_t launch_ln_modulate(const float* x, float* y, int M, int C, float eps, const float* shift,
-                              const float* scale, long mod_ld, int mod_row0, int mod_rstride, int rows_per_batch,
-                              hipStream_t st) {
+hipError_t launch_ln_modulate(const float* x, float* y, bf16_t* yhi, bf16_t* ylo, int M, int C, float eps,
+                              const float* shift, const float* scale, long mod_ld, int mod_row0, int mod_rstride,
+                              int rows_per_batch, hipStream_t st) {
     if (C > 1024) return hipErrorInvalidValue;
     ProfScope ps(st, "ln_modulate", 8.0 * M * C, 8.0 * M * C);
     dim3 grid((M + 3) / 4), block(256);
-    hipLaunchKernelGGL(ln_modulate_kernel<16>, grid, block, 0, st, x, y, M, C, eps, shift, scale, mod_ld,
+    hipLaunchKernelGGL(ln_modulate_kernel<16>, grid, block, 0, st, x, y, yhi, ylo, M, C, eps, shift, scale, mod_ld,
                        mod_row0, mod_rstride, rows_per_batch);
     LAUNCH_CHECK();
 }
@@ -61,7 +72,8 @@ hipError_t launch_ln_modulate(const float* x, float* y, int M, int C, float eps,
 // ------------------------------------------------------------------------------------------
 template <int LPR, int NV4>
 __global__ __launch_bounds__(256) void rmsnorm_kernel(const float* __restrict__ x, RowMap xmap, float* __restrict__ y,
-                                                      RowMap ymap, int M, int C, float eps,
+                                                      bf16_t* __restrict__ yhi, bf16_t* __restrict__ ylo, RowMap ymap,
+                                                      int M, int C, float eps,
                                                       const float* __restrict__ w) {
     constexpr int RPB = 256 / LPR;  // rows per block
     const int sub = threadIdx.x % LPR;
@@ -80,39 +92,41 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(const float* __restrict__ 
     ss = group_sum<LPR>(ss);
     const float rstd = 1.0f / sqrtf(ss / (float)C + eps);
     if (!live) return;
-    float4* yr = reinterpret_cast<float4*>(y + ymap.at(row));
+    const long yo = ymap.at(row);
     const float4* w4 = reinterpret_cast<const float4*>(w);
 #pragma unroll
     for (int i = 0; i < NV4; ++i) {
         int c = sub + LPR * i;
         if (c < c4n) {
             float4 g = w4[c];
-            yr[c] = make_float4(v[i].x * rstd * g.x, v[i].y * rstd * g.y, v[i].z * rstd * g.z, v[i].w * rstd * g.w);
+            const float4 o = make_float4(v[i].x * rstd * g.x, v[i].y * rstd * g.y, v[i].z * rstd * g.z, v[i].w * rstd * g.w);
+            if (yhi) store_split4(yhi, ylo, yo + c * 4, o);
+            else reinterpret_cast<float4*>(y + yo)[c] = o;
         }
     }
 }
 
 template <int LPR, int NV4>
-static hipError_t rmsnorm_go(const float* x, RowMap xmap, float* y, RowMap ymap, int M, int C, float eps,
-                             const float* w, hipStream_t st) {
+static hipError_t rmsnorm_go(const float* x, RowMap xmap, float* y, bf16_t* yhi, bf16_t* ylo, RowMap ymap, int M, int C,
+                             float eps, const float* w, hipStream_t st) {
     constexpr int RPB = 256 / LPR;
-    hipLaunchKernelGGL((rmsnorm_kernel<LPR, NV4>), dim3((M + RPB - 1) / RPB), dim3(256), 0, st, x, xmap, y, ymap, M,
-                       C, eps, w);
+    hipLaunchKernelGGL((rmsnorm_kernel<LPR, NV4>), dim3((M + RPB - 1) / RPB), dim3(256), 0, st, x, xmap, y, yhi, ylo,
+                       ymap, M, C, eps, w);
     LAUNCH_CHECK();
 }
 
-hipError_t launch_rmsnorm(const float* x, RowMap xmap, float* y, RowMap ymap, int M, int C, float eps,
-                          const float* w, hipStream_t st) {
+hipError_t launch_rmsnorm(const float* x, RowMap xmap, float* y, bf16_t* yhi, bf16_t* ylo, RowMap ymap, int M, int C,
+                          float eps, const float* w, hipStream_t st) {
     if (C % 4) return hipErrorInvalidValue;
     ProfScope ps(st, "rmsnorm", 4.0 * M * C, 8.0 * M * C);
     int c4 = C / 4;
-    if (c4 <= 8) return rmsnorm_go<8, 1>(x, xmap, y, ymap, M, C, eps, w, st);
-    if (c4 <= 16) return rmsnorm_go<16, 1>(x, xmap, y, ymap, M, C, eps, w, st);
-    if (c4 <= 32) return rmsnorm_go<32, 1>(x, xmap, y, ymap, M, C, eps, w, st);
-    if (c4 <= 64) return rmsnorm_go<64, 1>(x, xmap, y, ymap, M, C, eps, w, st);
-    if (c4 <= 128) return rmsnorm_go<64, 2>(x, xmap, y, ymap, M, C, eps, w, st);
-    if (c4 <= 256) return rmsnorm_go<64, 4>(x, xmap, y, ymap, M, C, eps, w, st);
-    if (c4 <= 512) return rmsnorm_go<64, 8>(x, xmap, y, ymap, M, C, eps, w, st);
+    if (c4 <= 8) return rmsnorm_go<8, 1>(x, xmap, y, yhi, ylo, ymap, M, C, eps, w, st);
+    if (c4 <= 16) return rmsnorm_go<16, 1>(x, xmap, y, yhi, ylo, ymap, M, C, eps, w, st);
+    if (c4 <= 32) return rmsnorm_go<32, 1>(x, xmap, y, yhi, ylo, ymap, M, C, eps, w, st);
+    if (c4 <= 64) return rmsnorm_go<64, 1>(x, xmap, y, yhi, ylo, ymap, M, C, eps, w, st);
+    if (c4 <= 128) return rmsnorm_go<64, 2>(x, xmap, y, yhi, ylo, ymap, M, C, eps, w, st);
+    if (c4 <= 256) return rmsnorm_go<64, 4>(x, xmap, y, yhi, ylo, ymap, M, C, eps, w, st);
+    if (c4 <= 512) return rmsnorm_go<64, 8>(x, xmap, y, yhi, ylo, ymap, M, C, eps, w, st);
     return hipErrorInvalidValue;
 }
 
@@ -195,7 +209,8 @@ hipError_t launch_len_mask(const int64_t* len, uint8_t* mask, int B, int R, hipS
 }
 
 __global__ void convpos_pack_kernel(const float* __restrict__ h, const uint8_t* __restrict__ mask,
-                                    float* __restrict__ gm, int B, int T, int G, int cpg, int pad, int gstride) {
+                                    bf16_t* __restrict__ gm_hi, bf16_t* __restrict__ gm_lo, int B, int T, int G, int cpg,
+                                    int pad, int gstride) {
     long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const int TP = T + 2 * pad;
     long total = (long)B * G * TP * gstride;
@@ -208,13 +223,16 @@ __global__ void convpos_pack_kernel(const float* __restrict__ h, const uint8_t* 
     int t = tp - pad;
     float v = 0.f;
     if (t >= 0 && t < T && c < cpg && mask[b * T + t]) v = h[((long)b * T + t) * (G * cpg) + g * cpg + c];
-    gm[i] = v;
+    bf16_t hh, ll;
+    split1(v, hh, ll);
+    gm_hi[i] = hh;
+    if (gm_lo) gm_lo[i] = ll;
 }
-hipError_t launch_convpos_pack(const float* h, const uint8_t* mask, float* gm, int B, int T, int G, int cpg,
-                               int pad, int gstride, hipStream_t st) {
+hipError_t launch_convpos_pack(const float* h, const uint8_t* mask, bf16_t* gm_hi, bf16_t* gm_lo, int B, int T, int G,
+                               int cpg, int pad, int gstride, hipStream_t st) {
     long total = (long)B * G * (T + 2 * pad) * gstride;
-    hipLaunchKernelGGL(convpos_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, h, mask, gm, B, T, G,
-                       cpg, pad, gstride);
+    hipLaunchKernelGGL(convpos_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, h, mask, gm_hi, gm_lo, B, T,
+                       G, cpg, pad, gstride);
     LAUNCH_CHECK();
 }
 
@@ -499,5 +517,55 @@ __global__ void rope_table_kernel(float* __restrict__ tab, int npos, int dim) {
 }
 hipError_t launch_rope_table(float* tab, int npos, int dim, hipStream_t st) {
     hipLaunchKernelGGL(rope_table_kernel, dim3((npos * dim + 255) / 256), dim3(256), 0, st, tab, npos, dim);
+    LAUNCH_CHECK();
+}
+
+// ------------------------------------------------------------------------------------------
+// modulation-table post-pass and fp32 -> split conversion
+// ------------------------------------------------------------------------------------------
+__global__ void tanh_gates_kernel(float* __restrict__ mod, int rows, long ld, int n_blocks, int per_block, int hidden) {
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    long per_row = (long)n_blocks * 2 * hidden;
+    if (i >= rows * per_row) return;
+    int r = (int)(i / per_row);
+    long j = i % per_row;
+    int blk = (int)(j / (2 * hidden)), w = (int)(j % (2 * hidden));
+    int col = blk * per_block + (w < hidden ? 2 * hidden + w : 5 * hidden + (w - hidden));  // gate_msa | gate_mlp
+    float* p = mod + (long)r * ld + col;
+    *p = tanhf(*p);
+}
+hipError_t launch_tanh_gates(float* mod, int rows, long ld, int n_blocks, int per_block, int hidden, hipStream_t st) {
+    long n = (long)rows * n_blocks * 2 * hidden;
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(tanh_gates_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, mod, rows, ld, n_blocks, per_block, hidden);
+    LAUNCH_CHECK();
+}
+
+__global__ void to_split_kernel(const float* __restrict__ x, RowMap xmap, bf16_t* __restrict__ hi, bf16_t* __restrict__ lo,
+                                RowMap omap, int M, int C4) {
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)M * C4) return;
+    int m = (int)(i / C4), c = (int)(i % C4);
+    float4 v = reinterpret_cast<const float4*>(x + xmap.at(m))[c];
+    store_split4(hi, lo, omap.at(m) + c * 4, v);
+}
+hipError_t launch_to_split(const float* x, RowMap xmap, bf16_t* hi, bf16_t* lo, RowMap omap, int M, int C, hipStream_t st) {
+    long n = (long)M * (C / 4);
+    if (n == 0) return hipSuccess;
+    ProfScope ps(st, "to_split", 0, 8.0 * M * C);
+    hipLaunchKernelGGL(to_split_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, x, xmap, hi, lo, omap, M, C / 4);
+    LAUNCH_CHECK();
+}
+
+__global__ void rope_cossin_kernel(const float* __restrict__ ang, float* __restrict__ c, float* __restrict__ s, int n) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float a = ang[i];
+    c[i] = cosf(a);
+    s[i] = sinf(a);
+}
+hipError_t launch_rope_cossin(const float* ang, float* c, float* s, int n, hipStream_t st) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(rope_cossin_kernel, dim3((n + 255) / 256), dim3(256), 0, st, ang, c, s, n);
     LAUNCH_CHECK();
 }

