@@ -49,7 +49,10 @@ def one_step(eng, inp, seed, gather=None):
     audio = eng.codec_decode(x)
     if gather is not None:
         import torch.distributed as dist
-        dist.all_gather_into_tensor(gather, audio)
+        if gather.is_cuda:
+            dist.all_gather_into_tensor(gather, audio)   # RCCL over xGMI: 7.68 MB per rank
+        else:                                            # gloo smoke path (CPU tensors)
+            dist.all_gather_into_tensor(gather, audio.cpu())
         return gather
     return audio
 
@@ -100,11 +103,16 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
+    backend = os.environ.get("SMTTS_DIST_BACKEND", "nccl")   # "gloo": 2-rank smoke test on a 1-GPU box
+    local = local % max(1, torch.cuda.device_count()) if backend != "nccl" else local
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
     n_gpus = world if world > 1 else 1
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
@@ -114,7 +122,8 @@ def main():
     eng.load_synthetic(SEED, parts=("dit", "decoder"))
     eng.finalize()
     inp = make_inputs(device, rank)
-    gather = torch.empty(world * B, 1, 3200 * N_FRAMES, device=device) if world > 1 else None
+    gather = (torch.empty(world * B, 1, 3200 * N_FRAMES, device=device if backend == "nccl" else "cpu")
+              if world > 1 else None)
 
     def barrier():
         torch.cuda.synchronize()
@@ -131,7 +140,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if dist is not None:
-        tmax = torch.tensor([dt], device=device, dtype=torch.float64)
+        tmax = torch.tensor([dt], device=device if backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
     assert torch.isfinite(out).all()
@@ -154,7 +163,7 @@ def main():
     if rank == 0 and not args.no_roofline:
         # per-kernel HIP-event timing on the launch stream, separate (untimed) passes
         eng.profile(True)
-        reps = 3
+        reps = min(args.steps, 5)   # same workload as the timed region, events on the launch stream
         for i in range(reps):
             one_step(eng, inp, 900 + i, None)
         torch.cuda.synchronize()

@@ -60,11 +60,27 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnArgs a) {
 
     // ---- queries of this wave -> LDS (pre-scaled by 1/sqrt(dh)) ------------------------------
     const int q0 = qt * QT + w * QW;
+    float qpre[QW][DPL];
+    if (a.prenormed) {
+#pragma unroll
+        for (int qi = 0; qi < QW; ++qi) {
+            const int n = q0 + qi < N ? q0 + qi : N - 1;
+            const float* qp = a.q + (long)b * a.bs + (long)n * a.rs + h * DH;
+#pragma unroll
+            for (int i = 0; i < DPL; ++i) {
+                const int d = lane + 64 * i;
+                qpre[qi][i] = qp[d < DH ? d : DH - 1];
+            }
+        }
+    }
 #pragma unroll
     for (int qi = 0; qi < QW; ++qi) {
         const int n = q0 + qi;
         float qv[DPL];
-        if (n < N) {
+        if (n < N && a.prenormed) {
+#pragma unroll
+            for (int i = 0; i < DPL; ++i) qv[i] = qpre[qi][i];
+        } else if (n < N) {
             norm_rope(a.q + (long)b * a.bs + (long)n * a.rs + h * DH, a.qw + h * DH, n, qv);
         } else {
 #pragma unroll
@@ -89,6 +105,58 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnArgs a) {
     for (int c0 = 0; c0 < Ktot; c0 += KC) {
         __syncthreads();  // previous chunk fully consumed (also orders the q_s writes on entry)
         // ---- stage K/V chunk: each wave fills rows w, w+4, ... ------------------------------
+        if (a.prenormed) {
+            // keys are plain copies: issue the loads of all 16 rows of this wave first, then the LDS stores
+            constexpr int RPW = KC / 4;
+            float kr_[RPW][DPL], vr_[RPW][DPL];
+#pragma unroll
+            for (int t = 0; t < RPW; ++t) {
+                const int gk = c0 + w + 4 * t;
+                const int gc = gk < Ktot ? gk : Ktot - 1;  // clamp: always a valid row, masked out below
+                const float* kp;
+                const float* vp;
+                if (gc < N) {
+                    const long base = (long)b * a.bs + (long)gc * a.rs + h * DH;
+                    kp = a.k + base; vp = a.v + base;
+                } else if (gc < N + R) {
+                    const long base = (((long)b * a.H + h) * R + (gc - N)) * DH;
+                    kp = a.k_ref + base; vp = a.v_ref + base;
+                } else {
+                    const long base = (((long)b * a.H + h) * P + (gc - N - R)) * DH;
+                    kp = a.k_text + base; vp = a.v_text + base;
+                }
+#pragma unroll
+                for (int i = 0; i < DPL; ++i) {
+                    const int d = lane + 64 * i;
+                    const int dc = d < DH ? d : DH - 1;
+                    kr_[t][i] = kp[dc];
+                    vr_[t][i] = vp[dc];
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < RPW; ++t) {
+                const int jj = w + 4 * t;
+#pragma unroll
+                for (int i = 0; i < DPL; ++i) {
+                    const int d = lane + 64 * i;
+                    if (d < DH) {
+                        K_s[jj * KS + d] = kr_[t][i];
+                        V_s[jj * DH + d] = vr_[t][i];
+                    }
+                }
+            }
+            // key validity: one lane per key (a consumed 1-byte load per row would drain the whole load queue)
+            if (tid < KC) {
+                const int gk = c0 + tid;
+                float ok = 0.f;
+                if (gk < Ktot) {
+                    const uint8_t* mk = gk < N ? a.mask_self : (gk < N + R ? a.mask_ref : a.mask_text);
+                    const int mi = gk < N ? b * N + gk : (gk < N + R ? b * R + (gk - N) : b * P + (gk - N - R));
+                    ok = (!mk || mk[mi]) ? 1.f : 0.f;
+                }
+                m_s[tid] = ok;
+            }
+        } else
         for (int jj = w; jj < KC; jj += 4) {
             const int gk = c0 + jj;
             float kv[DPL], vv[DPL];
@@ -148,23 +216,43 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnArgs a) {
             }
         }
         const bool kvalid = m_s[lane] != 0.f;
-        float p4[QW];
+        float p4[QW], sv[QW], cm[QW], al[QW], cs[QW];
+#pragma unroll
+        for (int qi = 0; qi < QW; ++qi) cm[qi] = sv[qi] = kvalid ? s[qi] : -INFINITY;
+        // the four queries' cross-lane reductions advance in lock-step: one wait per butterfly step, not per query
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            float t[QW];
+#pragma unroll
+            for (int qi = 0; qi < QW; ++qi) t[qi] = __shfl_xor(cm[qi], off, 64);
+#pragma unroll
+            for (int qi = 0; qi < QW; ++qi) cm[qi] = fmaxf(cm[qi], t[qi]);
+        }
 #pragma unroll
         for (int qi = 0; qi < QW; ++qi) {
-            const float sv = kvalid ? s[qi] : -INFINITY;
-            const float cm = wave_max(sv);
-            const float m_new = fmaxf(m_run[qi], cm);
+            const float m_new = fmaxf(m_run[qi], cm[qi]);
             float alpha = 1.f, p = 0.f;
             if (m_new != -INFINITY) {
-                alpha = (m_run[qi] == -INFINITY) ? 0.f : expf(m_run[qi] - m_new);
-                p = kvalid ? expf(sv - m_new) : 0.f;
+                alpha = (m_run[qi] == -INFINITY) ? 0.f : __expf(m_run[qi] - m_new);
+                p = kvalid ? __expf(sv[qi] - m_new) : 0.f;
             }
-            const float cs = wave_sum(p);
-            l_run[qi] = l_run[qi] * alpha + cs;
-#pragma unroll
-            for (int i = 0; i < DPL; ++i) o[qi][i] *= alpha;
+            al[qi] = alpha;
             m_run[qi] = m_new;
-            p4[qi] = p;
+            p4[qi] = cs[qi] = p;
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            float t[QW];
+#pragma unroll
+            for (int qi = 0; qi < QW; ++qi) t[qi] = __shfl_xor(cs[qi], off, 64);
+#pragma unroll
+            for (int qi = 0; qi < QW; ++qi) cs[qi] += t[qi];
+        }
+#pragma unroll
+        for (int qi = 0; qi < QW; ++qi) {
+            l_run[qi] = l_run[qi] * al[qi] + cs[qi];
+#pragma unroll
+            for (int i = 0; i < DPL; ++i) o[qi][i] *= al[qi];
         }
         float* pw = p_s + w * KC * QW;
         *reinterpret_cast<float4*>(pw + lane * QW) = make_float4(p4[0], p4[1], p4[2], p4[3]);
@@ -174,6 +262,7 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnArgs a) {
 
         // ---- P.V: lane = head dim ------------------------------------------------------------
         const int kc = (Ktot - c0) < KC ? (Ktot - c0) : KC;
+#pragma unroll 8
         for (int jj = 0; jj < kc; ++jj) {
             const float4 pp = *reinterpret_cast<const float4*>(pw + jj * QW);
             float vv[DPL];
@@ -192,30 +281,92 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnArgs a) {
         }
     }
 
-    // ---- normalise, gate, store ----------------------------------------------------------------
+    // ---- normalise, gate, store (all gate loads issued before the first store) ----------------------
+    {
+        float gv[QW][DPL];
 #pragma unroll
-    for (int qi = 0; qi < QW; ++qi) {
-        const int n = q0 + qi;
-        if (n >= N) continue;
-        const float inv = l_run[qi] > 0.f ? 1.0f / l_run[qi] : 0.f;
+        for (int qi = 0; qi < QW; ++qi) {
+            const int n = q0 + qi;
 #pragma unroll
-        for (int i = 0; i < DPL; ++i) {
-            int d = lane + 64 * i;
-            if (d < DH) {
-                const float g = a.gate[(long)b * a.bs + (long)n * a.rs + h * DH + d];
-                const float val = o[qi][i] * inv / (1.0f + expf(-g));
-                const long oo = (long)b * a.obs + (long)n * a.ors + h * DH + d;
-                if (a.out_hi) {
-                    bf16_t hh, ll;
-                    split1(val, hh, ll);
-                    a.out_hi[oo] = hh;
-                    if (a.out_lo) a.out_lo[oo] = ll;
-                } else {
-                    a.out[oo] = val;
+            for (int i = 0; i < DPL; ++i) {
+                const int d = lane + 64 * i;
+                gv[qi][i] = (n < N && d < DH) ? a.gate[(long)b * a.bs + (long)n * a.rs + h * DH + d] : 0.f;
+            }
+        }
+#pragma unroll
+        for (int qi = 0; qi < QW; ++qi) {
+            const int n = q0 + qi;
+            if (n >= N) continue;
+            const float inv = l_run[qi] > 0.f ? 1.0f / l_run[qi] : 0.f;
+#pragma unroll
+            for (int i = 0; i < DPL; ++i) {
+                const int d = lane + 64 * i;
+                if (d < DH) {
+                    const float val = o[qi][i] * inv * sigmoid_f(gv[qi][i]);
+                    const long oo = (long)b * a.obs + (long)n * a.ors + h * DH + d;
+                    if (a.out_hi) {
+                        bf16_t hh, ll;
+                        split1(val, hh, ll);
+                        a.out_hi[oo] = hh;
+                        if (a.out_lo) a.out_lo[oo] = ll;
+                    } else {
+                        a.out[oo] = val;
+                    }
                 }
             }
         }
     }
+}
+
+template <int DH>
+__global__ __launch_bounds__(256) void qk_prep_kernel(AttnArgs a) {
+    constexpr int DPL = (DH + 63) / 64;
+    const int lane = threadIdx.x & 63;
+    const long wid = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const long total = (long)a.B * a.N * a.H * 2;
+    if (wid >= total) return;
+    const int which = (int)(wid & 1);
+    long t = wid >> 1;
+    const int h = (int)(t % a.H); t /= a.H;
+    const int n = (int)(t % a.N);
+    const int b = (int)(t / a.N);
+    float* p = const_cast<float*>(which ? a.k : a.q) + (long)b * a.bs + (long)n * a.rs + h * DH;
+    const float* wgt = (which ? a.kw : a.qw) + h * DH;
+    float x[DPL];
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < DPL; ++i) {
+        int d = lane + 64 * i;
+        x[i] = d < DH ? p[d] : 0.f;
+        ss += x[i] * x[i];
+    }
+    ss = wave_sum(ss);
+    const float rstd = 1.0f / sqrtf(ss / (float)DH + a.eps);
+#pragma unroll
+    for (int i = 0; i < DPL; ++i) {
+        int d = lane + 64 * i;
+        float y = d < DH ? x[i] * rstd * wgt[d] : 0.f;
+        const float partner = __shfl_xor(y, 1, 64);
+        if (d < a.rot_dim) {
+            const float c = a.rope_cos[(long)n * a.rot_dim + d], s = a.rope_sin[(long)n * a.rot_dim + d];
+            y = (d & 1) ? (y * c + partner * s) : (y * c - partner * s);
+        }
+        if (d < DH) p[d] = y;
+    }
+}
+
+hipError_t launch_qk_prep(const AttnArgs& a, hipStream_t st) {
+    const long total = (long)a.B * a.N * a.H * 2;
+    if (total == 0) return hipSuccess;
+    ProfScope ps(st, "qk_prep", 8.0 * total * a.dh, 8.0 * total * a.dh);
+    dim3 grid((unsigned)((total + 3) / 4));
+    switch (a.dh) {
+        case 64: hipLaunchKernelGGL(qk_prep_kernel<64>, grid, dim3(256), 0, st, a); break;
+        case 120: hipLaunchKernelGGL(qk_prep_kernel<120>, grid, dim3(256), 0, st, a); break;
+        case 128: hipLaunchKernelGGL(qk_prep_kernel<128>, grid, dim3(256), 0, st, a); break;
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
 }
 
 template <int DH>

@@ -563,6 +563,8 @@ int Engine::run_encoder(hipStream_t st, const EncoderW& e, void* wsv, int B, int
         a.mask_self = key_mask;
         a.out = nullptr; a.out_hi = w.o.hi; a.out_lo = w.o.lo; a.obs = (long)S * D; a.ors = D;
         a.B = B; a.N = S; a.H = e.heads; a.dh = e.dh;
+        a.prenormed = 1;
+        HIPC(launch_qk_prep(a, st));
         HIPC(launch_attention(a, st));
         EpiResid<0> r1{w.x, rd, nullptr, nullptr, 0, 0, 0, 1, nullptr};
         HIPC(gemm3_resid(ops3(w.o, rd, b.wo, M), 0, r1, split_, st));
@@ -759,6 +761,8 @@ int Engine::denoise_core(hipStream_t st, const float* x_t, const uint8_t* mask, 
         a.mask_self = mask; a.mask_ref = ref_mask; a.mask_text = ph_mask;
         a.out = nullptr; a.out_hi = w.o.hi; a.out_lo = w.o.lo; a.obs = (long)N * kHidden; a.ors = kHidden;
         a.B = B; a.N = N; a.H = kHeads; a.dh = kDh;
+        a.prenormed = 1;
+        HIPC(launch_qk_prep(a, st));
         HIPC(launch_attention(a, st));
         // to_out + mask + gated residual (dit.py:117-118,198)
         EpiResid<0> r1{w.x, rh, nullptr, m + 2 * kHidden, kModLd, mod_row0, mod_rstride, N, mask};

@@ -37,11 +37,15 @@ struct AttnArgs {
     const uint8_t* mask_self;  // [B][N]  key validity (may be null = all valid)
     const uint8_t* mask_ref;   // [B][R]
     const uint8_t* mask_text;  // [B][P]
+    int prenormed;      // 1: q and k were already RMS-normalised + rotated in place by launch_qk_prep
     float* out; long obs, ors;  // out (b, n, h*dh + d)
     bf16_t* out_hi; bf16_t* out_lo;  // when out_hi != null the result is written as a split bf16 pair instead
     int B, N, H, dh;
 };
 hipError_t launch_attention(const AttnArgs& a, hipStream_t st);
+// In place on the packed projection buffer: q <- RoPE(RMSNorm_head(q) * qw), k <- RoPE(RMSNorm_head(k) * kw)
+// (dit.py:95-108); one wave per (row, head, q|k).  Uses the q/k/bs/rs/qw/kw/eps/rope/rot_dim/B/N/H/dh fields.
+hipError_t launch_qk_prep(const AttnArgs& a, hipStream_t st);
 
 // out[m][:] = table[ids[m]][:]  (phonemes.py:201)
 hipError_t launch_embedding(const int64_t* ids, const float* table, float* out, int M, int C, int vocab, hipStream_t st);
