@@ -510,6 +510,7 @@ static inline Gemm3Operands ops3(SplitBuf a, RowMap amap, const PW& w, int M, in
     g.a_z = 0;
     g.w_z = 0;
     g.w_zmod = 0;
+    g.ksplit_tiles = 0;
     return g;
 }
 static inline EpiStore<ACT_NONE> store_to(float* out, RowMap omap, const float* bias, float scale = 1.f,
@@ -526,6 +527,22 @@ static inline SplitBuf take_split(T& bump, size_t elems) {
     s.hi = bump.template take<bf16_t>(elems);
     s.lo = bump.template take<bf16_t>(elems);
     return s;
+}
+
+// Split-K residual GEMM for the small-M DiT projections (N = 960 gives only 150 tiles): the K range is cut into
+// `splits` slices (grid.z), each writes an fp32 partial, and one fused kernel reduces them in a fixed order and
+// applies bias / tanh-gate / row mask / residual add -> deterministic, unlike atomics.
+static hipError_t gemm3_resid_splitk(const Gemm3Operands& g0, const EpiResid<0>& r, float* partial, int splits, int split,
+                                     hipStream_t st) {
+    Gemm3Operands g = g0;
+    const int nk = g.K / 64;
+    g.ksplit_tiles = (nk + splits - 1) / splits;
+    const int used = (nk + g.ksplit_tiles - 1) / g.ksplit_tiles;
+    EpiStore<ACT_NONE> e{partial, rowmap_plain(g.N), (long)g.M * g.N, nullptr, 0, 1.f, nullptr, nullptr, nullptr};
+    hipError_t err = gemm3_store(g, ACT_NONE, e, used, split, st, G3_64x64);
+    if (err != hipSuccess) return err;
+    return launch_splitk_resid(partial, used, r.x, r.bias, r.gate, r.gld, r.grow0, r.grstride, r.rows_per_batch, r.rowmask,
+                               g.M, g.N, st);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -670,7 +687,7 @@ struct ModWs {
     }
 };
 struct CoreWs {
-    float *h, *x, *qkvg;
+    float *h, *x, *qkvg, *part;
     SplitBuf gm1, gm2, y, o, ffh;
     size_t gm_elems;
     void plan(Bump& b, int B, int N) {
@@ -679,6 +696,7 @@ struct CoreWs {
         h = b.take<float>(M * kHidden);
         x = b.take<float>(M * kHidden);
         qkvg = b.take<float>(M * 4 * kHidden);
+        part = b.take<float>(M * kHidden * kSplitK);
         gm1 = take_split(b, gm_elems);
         gm2 = take_split(b, gm_elems);
         y = take_split(b, M * kHidden);
@@ -766,14 +784,14 @@ int Engine::denoise_core(hipStream_t st, const float* x_t, const uint8_t* mask, 
         HIPC(launch_attention(a, st));
         // to_out + mask + gated residual (dit.py:117-118,198)
         EpiResid<0> r1{w.x, rh, nullptr, m + 2 * kHidden, kModLd, mod_row0, mod_rstride, N, mask};
-        HIPC(gemm3_resid(ops3(w.o, rh, b.out, M), 1, r1, split_, st));
+        HIPC(gemm3_resid_splitk(ops3(w.o, rh, b.out, M), r1, w.part, kSplitK, split_, st));
         // D7 feed-forward (dit.py:199-201)
         HIPC(launch_ln_modulate(w.x, nullptr, w.y.hi, w.y.lo, M, kHidden, 1e-6f, m + 3 * kHidden, m + 4 * kHidden, kModLd,
                                 mod_row0, mod_rstride, N, st));
         EpiSwiGLU sw{nullptr, kFFp, b.b1, b.b3, w.ffh.hi, w.ffh.lo};
         HIPC(gemm3_swiglu(ops3(w.y, rh, b.ff13, M), sw, split_, st));
         EpiResid<0> r2{w.x, rh, b.b2, m + 5 * kHidden, kModLd, mod_row0, mod_rstride, N, nullptr};
-        HIPC(gemm3_resid(ops3(w.ffh, rowmap_plain(kFFp), b.ff2, M), 1, r2, split_, st));
+        HIPC(gemm3_resid_splitk(ops3(w.ffh, rowmap_plain(kFFp), b.ff2, M), r2, w.part, kSplitK, split_, st));
     }
     // D8 final AdaLN (chunk order scale, shift: dit.py:37) + velocity head (model.py:100)
     const float* mf = mod + (long)kBlocks * kModPerBlock;
@@ -930,15 +948,23 @@ int Engine::sample(hipStream_t st, int mode, int n_steps, int cfg, float s_text,
 // front of each batch item implement the causal left padding of every conv, so strided / transposed /
 // k-tap convs all become plain GEMMs over overlapping rows.
 // ---------------------------------------------------------------------------------------------
-int Engine::codec_block(hipStream_t st, const CodecBlockW& w, float* x, float* nbuf, bf16_t* n2hi, bf16_t* n2lo,
-                        bf16_t* hhi, bf16_t* hlo, int B, int T, int C) {
+int Engine::codec_block(hipStream_t st, const CodecBlockW& w, float** xp, float** xaltp, float* nbuf, bf16_t* n2hi,
+                        bf16_t* n2lo, bf16_t* hhi, bf16_t* hlo, int B, int T, int C) {
     const int M = B * T, pad = kCodecPad;
+    float* x = *xp;
     const RowMap img = rowmap_batched(C, T, (long)(pad + T) * C, (long)pad * C);
     const int F = cspec_.ffn_mult * C;
     const RowMap rc = rowmap_plain(C), rf = rowmap_plain(F);
     // mixer: RMSNorm -> causal depthwise conv -> LayerScale residual
-    HIPC(launch_rmsnorm(x, img, nbuf, nullptr, nullptr, img, M, C, cspec_.eps, w.norm_w, st));
-    HIPC(launch_dwconv_resid(x, nbuf, w.dw_w, w.dw_b, w.gamma, B, T, C, cspec_.kernel, pad, st));
+    if (C <= 256 && 256 % (C / 4) == 0 && fused_ffn_) {  // narrow stages: one out-of-place kernel, then swap images
+        HIPC(launch_mixer_fused(x, *xaltp, w.norm_w, w.dw_w, w.dw_b, w.gamma, B, T, C, cspec_.kernel, pad, cspec_.eps, st));
+        *xp = *xaltp;
+        *xaltp = x;
+        x = *xp;
+    } else {
+        HIPC(launch_rmsnorm(x, img, nbuf, nullptr, nullptr, img, M, C, cspec_.eps, w.norm_w, st));
+        HIPC(launch_dwconv_resid(x, nbuf, w.dw_w, w.dw_b, w.gamma, B, T, C, cspec_.kernel, pad, st));
+    }
     // FFN: RMSNorm -> Linear 4x -> GELU -> Linear -> LayerScale residual
     if (w.w1f.N && fused_ffn_) {  // narrow stages: one fused kernel, hidden stays in LDS (codec_ffn.hip)
         HIPC(launch_codec_ffn_fused(x, img, w.ffn_norm_w, w.w1f.hi, w.w1f.lo, w.b1, w.w2f.hi, w.w2f.lo, w.b2, w.ffn_gamma, M,
@@ -1037,6 +1063,7 @@ int Engine::codec_decode(hipStream_t st, const float* latents, int B, int T, flo
     int Ti = T;
     int C = dec_.stages[0].C;
     HIPC(launch_zero_pad_frames(x, B, Ti, C, pad, st));
+    HIPC(launch_zero_pad_frames(xn, B, Ti, C, pad, st));
     HIPC(launch_zero_pad_frames(w.nb, B, Ti, C, pad, st));
     {
         RowMap am = rowmap_batched(L, Ti, (long)(pad + Ti) * L, (long)(pad - (Kc - 1)) * L);
@@ -1056,9 +1083,10 @@ int Engine::codec_decode(hipStream_t st, const float* latents, int B, int T, flo
             float* t = x; x = xn; xn = t;
             Ti = Tn;
             C = Cn;
+            HIPC(launch_zero_pad_frames(xn, B, Ti, C, pad, st));  // the ping-pong partner needs zero pads at this geometry too
         }
         for (const CodecBlockW& b : sg.blocks)
-            if (codec_block(st, b, x, w.nb, w.n2hi, w.n2lo, w.hhi, w.hlo, B, Ti, C)) return 1;
+            if (codec_block(st, b, &x, &xn, w.nb, w.n2hi, w.n2lo, w.hhi, w.hlo, B, Ti, C)) return 1;
     }
     HIPC(launch_head_conv(x, dec_.head_w, dec_.head_b_host, audio, B, Ti, C, Kc, pad, st));
     return 0;
@@ -1109,6 +1137,7 @@ int Engine::codec_encode(hipStream_t st, const float* audio, int B, int S_, floa
     int Ti = S_;
     int C = enc_.stages[0].C;
     HIPC(launch_zero_pad_frames(x, B, Ti, C, pad, st));
+    HIPC(launch_zero_pad_frames(xn, B, Ti, C, pad, st));
     HIPC(launch_zero_pad_frames(w.nb, B, Ti, C, pad, st));
     HIPC(launch_stem_conv1(audio, enc_.stem_w_raw, enc_.stem_b, x, B, Ti, C, Kc, pad, st));
     for (int i = 0; i < S; ++i) {
@@ -1124,9 +1153,10 @@ int Engine::codec_encode(hipStream_t st, const float* audio, int B, int S_, floa
             float* t = x; x = xn; xn = t;
             Ti = Tn;
             C = Cn;
+            HIPC(launch_zero_pad_frames(xn, B, Ti, C, pad, st));
         }
         for (const CodecBlockW& b : sg.blocks)
-            if (codec_block(st, b, x, w.nb, w.n2hi, w.n2lo, w.hhi, w.hlo, B, Ti, C)) return 1;
+            if (codec_block(st, b, &x, &xn, w.nb, w.n2hi, w.n2lo, w.hhi, w.hlo, B, Ti, C)) return 1;
     }
     RowMap am = rowmap_batched(C, Ti, (long)(pad + Ti) * C, (long)(pad - (Kc - 1)) * C);
     HIPC(gemm_store(ops(x, am, enc_.head, B * Ti), ACT_NONE, store_to(latents, rowmap_plain(s.latent_dim), enc_.head_b), 1,

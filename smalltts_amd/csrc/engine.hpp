@@ -157,8 +157,9 @@ class Engine {
                      const float* k_text, const float* v_text, const uint8_t* ph_mask, const float* rope, int B,
                      int N, int R, int P, float* velocity, char* ws);
     size_t denoise_core_bytes(int B, int N) const;
-    int codec_block(hipStream_t st, const CodecBlockW& w, float* x, float* nbuf, bf16_t* n2hi, bf16_t* n2lo, bf16_t* hhi,
-                    bf16_t* hlo, int B, int T, int C);
+    // runs one block; the result lives in *x on return (the fused mixer ping-pongs *x <-> *xalt)
+    int codec_block(hipStream_t st, const CodecBlockW& w, float** x, float** xalt, float* nbuf, bf16_t* n2hi, bf16_t* n2lo,
+                    bf16_t* hhi, bf16_t* hlo, int B, int T, int C);
 
     int device_;
     std::string err_;
@@ -189,6 +190,7 @@ void alpha_sigma_host(float t, float& a, float& s);
 
 static constexpr int kMaxPos = 4096;   // reference rope tables (dit.py:139, style.py:140)
 static constexpr int kHidden = 960, kHeads = 8, kDh = 120, kBlocks = 12, kFF = 2400, kLatent = 64;
+static constexpr int kSplitK = 4;   // K slices of the DiT out-proj / FF2 GEMMs
 static constexpr int kFFp = 2432;  // FF hidden row stride: 2400 padded to a multiple of 64 (zero tail) for the DMA GEMM
 static constexpr int kModPerBlock = 6 * kHidden;
 static constexpr long kModLd = (long)kBlocks * kModPerBlock + 2 * kHidden;  // 71040

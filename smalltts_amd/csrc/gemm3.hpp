@@ -23,6 +23,7 @@ struct Gemm3Operands {
     int M, N, K;
     long a_z, w_z;
     int w_zmod;
+    int ksplit_tiles;  // > 0: blockIdx.z is a split-K index; this launch slice covers k-tiles [z*ksplit_tiles, +ksplit_tiles)
 };
 
 template <int BM, int BN, int WM, int WN, int SPLIT, int S, class Epi>
@@ -62,7 +63,8 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm3_kernel(Gemm3Operands g, Epi
         vid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
     }
     const int m0 = (vid % Mt) * BM, n0 = (vid / Mt) * BN, z = blockIdx.z;
-    const long wz = (long)(g.w_zmod ? z % g.w_zmod : z) * g.w_z;
+    const int zb = g.ksplit_tiles ? 0 : z;  // batch index (split-K launches are unbatched)
+    const long wz = (long)(g.w_zmod ? zb % g.w_zmod : zb) * g.w_z;
 
     // ---- per-lane DMA sources: slot -> (array, 8-row block) --------------------------------------
     const bf16_t* src[PW];
@@ -77,7 +79,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm3_kernel(Gemm3Operands g, Epi
             const int c = p ^ ((r >> 1) & 7);
             int m = m0 + r;
             m = m < g.M ? m : g.M - 1;
-            src[i] = (arr ? g.Alo : g.Ahi) + (long)z * g.a_z + g.amap.at(m) + c * 8;
+            src[i] = (arr ? g.Alo : g.Ahi) + (long)zb * g.a_z + g.amap.at(m) + c * 8;
             dst[i] = arr * A_ARR + rb * 1024;
         } else {
             const int s2 = slot - NA;
@@ -104,7 +106,9 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm3_kernel(Gemm3Operands g, Epi
             : "memory");
     };
     const unsigned lds0 = (unsigned)(size_t)SM_LPTR(smem);
-    const int nk = g.K / BK;
+    const int nk_all = g.K / BK;
+    const int kt0 = g.ksplit_tiles ? z * g.ksplit_tiles : 0;
+    const int nk = g.ksplit_tiles ? (nk_all - kt0 < g.ksplit_tiles ? nk_all - kt0 : g.ksplit_tiles) : nk_all;
     const bf16_t* pf[PFN ? PFN : 1];
 #pragma unroll
     for (int i = 0; i < PFN; ++i) {
@@ -114,7 +118,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm3_kernel(Gemm3Operands g, Epi
             const int arr = L / BM;
             int m = m0 + L % BM;
             m = m < g.M ? m : g.M - 1;
-            pf[i] = (arr ? g.Alo : g.Ahi) + (long)z * g.a_z + g.amap.at(m);
+            pf[i] = (arr ? g.Alo : g.Ahi) + (long)zb * g.a_z + g.amap.at(m);
         } else {
             const int L2 = L - NARR * BM, arr = L2 / BN;
             int n = n0 + L2 % BN;
@@ -140,9 +144,9 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm3_kernel(Gemm3Operands g, Epi
         const unsigned st = lds0 + (unsigned)((kt % S) * STAGE);
 #pragma unroll
         for (int i = 0; i < PW; ++i)
-            dma16(src[i] + kt * BK, st + (unsigned)__builtin_amdgcn_readfirstlane((int)dst[i]));
-        int kp = kt + PFD;
-        kp = kp < nk ? kp : nk - 1;
+            dma16(src[i] + (kt0 + kt) * BK, st + (unsigned)__builtin_amdgcn_readfirstlane((int)dst[i]));
+        int kp = kt0 + kt + PFD;
+        kp = kp < nk_all ? kp : nk_all - 1;
 #pragma unroll
         for (int i = 0; i < PFN; ++i)
             touch4(pf[i] + kp * BK, lds0 + (unsigned)(S * STAGE));

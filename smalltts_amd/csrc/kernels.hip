@@ -569,3 +569,102 @@ hipError_t launch_rope_cossin(const float* ang, float* c, float* s, int n, hipSt
     hipLaunchKernelGGL(rope_cossin_kernel, dim3((n + 255) / 256), dim3(256), 0, st, ang, c, s, n);
     LAUNCH_CHECK();
 }
+
+__global__ __launch_bounds__(256) void splitk_resid_kernel(const float* __restrict__ part, int S, float* __restrict__ x,
+                                                           const float* __restrict__ bias, const float* __restrict__ gate,
+                                                           long gld, int grow0, int grstride, int rpb,
+                                                           const uint8_t* __restrict__ rowmask, int M, int N4) {
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)M * N4) return;
+    const int m = (int)(i / N4), c = (int)(i % N4);
+    if (rowmask && !rowmask[m]) return;
+    const long MN4 = (long)M * N4;
+    float4 acc = reinterpret_cast<const float4*>(part)[i];
+    for (int s = 1; s < S; ++s) {
+        const float4 p = reinterpret_cast<const float4*>(part)[s * MN4 + i];
+        acc.x += p.x; acc.y += p.y; acc.z += p.z; acc.w += p.w;
+    }
+    if (bias) {
+        const float4 b = reinterpret_cast<const float4*>(bias)[c];
+        acc.x += b.x; acc.y += b.y; acc.z += b.z; acc.w += b.w;
+    }
+    float4 g = make_float4(1.f, 1.f, 1.f, 1.f);
+    if (gate) g = reinterpret_cast<const float4*>(gate + (long)(grow0 + (m / rpb) * grstride) * gld)[c];
+    float4 xv = reinterpret_cast<float4*>(x)[i];
+    xv.x += g.x * acc.x; xv.y += g.y * acc.y; xv.z += g.z * acc.z; xv.w += g.w * acc.w;
+    reinterpret_cast<float4*>(x)[i] = xv;
+}
+hipError_t launch_splitk_resid(const float* part, int S, float* x, const float* bias, const float* gate, long gld,
+                               int grow0, int grstride, int rows_per_batch, const uint8_t* rowmask, int M, int N,
+                               hipStream_t st) {
+    if (N % 4 || gld % 4) return hipErrorInvalidValue;
+    long n = (long)M * (N / 4);
+    if (n == 0) return hipSuccess;
+    ProfScope ps(st, "splitk_resid", 1.0 * M * N * (S + 2), 4.0 * M * N * (S + 2));
+    hipLaunchKernelGGL(splitk_resid_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, part, S, x, bias, gate, gld,
+                       grow0, grstride, rows_per_batch, rowmask, M, N / 4);
+    LAUNCH_CHECK();
+}
+
+// ------------------------------------------------------------------------------------------
+// fused RMSNorm + causal depthwise conv + LayerScale residual (codec mixer), C <= 256, out of place
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void mixer_fused_kernel(const float* __restrict__ xin, float* __restrict__ xout,
+                                                          const float* __restrict__ norm_w, const float* __restrict__ w,
+                                                          const float* __restrict__ bias, const float* __restrict__ gamma,
+                                                          int T, int C, int K, int pad, float eps, int TT, int tiles_per_b) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int C4 = C >> 2, H = K - 1;
+    float* xs = sm;                         // [(TT + H)][C]
+    float* rs = sm + (size_t)(TT + H) * C;  // [(TT + H)] rstd per frame
+    const int b = blockIdx.x / tiles_per_b, t0 = (blockIdx.x % tiles_per_b) * TT;
+    const int nfr = (T - t0 < TT ? T - t0 : TT) + H;             // frames staged (incl. halo)
+    const long img0 = ((long)b * (pad + T) + pad + t0 - H) * C;  // first halo frame (inside the zero pad for t0 = 0)
+    const int tid = threadIdx.x;
+    // phase 1: stage frames, per-frame sum of squares (C4 lanes cooperate on one frame)
+    const int lpr = C4, fpp = 256 / lpr;
+    for (int f0 = 0; f0 < nfr; f0 += fpp) {
+        const int f = f0 + tid / lpr, c4 = tid % lpr;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (f < nfr) v = reinterpret_cast<const float4*>(xin + img0 + (long)f * C)[c4];
+        float ss = v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+        for (int o = lpr >> 1; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
+        if (f < nfr) {
+            reinterpret_cast<float4*>(xs + (size_t)f * C)[c4] = v;
+            if (c4 == 0) rs[f] = 1.0f / sqrtf(ss / (float)C + eps);
+        }
+    }
+    __syncthreads();
+    // phase 2: the tile's output frames
+    const int nout = nfr - H;
+    for (int i = tid; i < nout * C4; i += 256) {
+        const int t = i / C4, c4 = i % C4;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int k = 0; k < K; ++k) {
+            const float r = rs[t + k];
+            const float4 xv = reinterpret_cast<const float4*>(xs + (size_t)(t + k) * C)[c4];
+            const float4 wv = reinterpret_cast<const float4*>(w)[(long)k * C4 + c4];
+            acc.x += wv.x * r * xv.x; acc.y += wv.y * r * xv.y; acc.z += wv.z * r * xv.z; acc.w += wv.w * r * xv.w;
+        }
+        const float4 g = reinterpret_cast<const float4*>(norm_w)[c4];
+        const float4 bb = reinterpret_cast<const float4*>(bias)[c4];
+        const float4 gm = reinterpret_cast<const float4*>(gamma)[c4];
+        float4 xv = reinterpret_cast<const float4*>(xs + (size_t)(t + H) * C)[c4];
+        xv.x += gm.x * (g.x * acc.x + bb.x); xv.y += gm.y * (g.y * acc.y + bb.y);
+        xv.z += gm.z * (g.z * acc.z + bb.z); xv.w += gm.w * (g.w * acc.w + bb.w);
+        reinterpret_cast<float4*>(xout + img0 + (long)(t + H) * C)[c4] = xv;
+    }
+}
+hipError_t launch_mixer_fused(const float* xin, float* xout, const float* norm_w, const float* w, const float* bias,
+                              const float* gamma, int B, int T, int C, int K, int pad, float eps, hipStream_t st) {
+    if (C % 4 || C > 256 || (256 % (C / 4)) || pad < K - 1 || xin == xout) return hipErrorInvalidValue;
+    int TT = 8192 / C;
+    if (TT < 8) TT = 8;
+    const int tiles = (T + TT - 1) / TT;
+    const size_t lds = ((size_t)(TT + K - 1) * C + (TT + K - 1)) * sizeof(float);
+    if ((long)B * tiles == 0) return hipSuccess;
+    ProfScope ps(st, "mixer_fused", 2.0 * B * T * C * (K + 4), 8.0 * B * T * C);
+    hipLaunchKernelGGL(mixer_fused_kernel, dim3((unsigned)(B * tiles)), dim3(256), lds, st, xin, xout, norm_w, w, bias, gamma,
+                       T, C, K, pad, eps, TT, tiles);
+    LAUNCH_CHECK();
+}

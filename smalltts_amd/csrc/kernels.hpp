@@ -108,3 +108,16 @@ hipError_t launch_zero_pad_frames(float* x, int B, int T, int C, int pad, hipStr
 hipError_t launch_codec_ffn_fused(float* x, RowMap img, const float* norm_w, const bf16_t* w1hi, const bf16_t* w1lo,
                                   const float* b1, const bf16_t* w2hi, const bf16_t* w2lo, const float* b2,
                                   const float* gamma, int M, int C, int F, float eps, int split, hipStream_t st);
+
+// x[m][n] += mask(m) * gate[(grow0 + (m / rows_per_batch) * grstride) * gld + n] * (sum_s part[s][m][n] + bias[n])
+// (gate == null -> 1; fixed summation order s = 0..S-1).  Closes a split-K GEMM (see gemm3_resid_splitk).
+hipError_t launch_splitk_resid(const float* part, int S, float* x, const float* bias, const float* gate, long gld,
+                               int grow0, int grstride, int rows_per_batch, const uint8_t* rowmask, int M, int N,
+                               hipStream_t st);
+
+// Fused mixer for C <= 256 (out of place: tiles read K-1 halo frames that belong to the neighbouring tile, so the
+// update cannot be done in place):  xout[b][t][c] = xin + gamma[c] * (bias[c] + sum_k w[k][c] * n[t-(K-1)+k][c]) with
+// n = RMSNorm(xin; g, eps) recomputed in LDS for the tile + halo (x read once, written once).  Both images must have
+// zero pad frames.
+hipError_t launch_mixer_fused(const float* xin, float* xout, const float* norm_w, const float* w, const float* bias,
+                              const float* gamma, int B, int T, int C, int K, int pad, float eps, hipStream_t st);
