@@ -40,12 +40,33 @@ def make_inputs(device, rank):
     ids = torch.arange(1, P_TOK + 1)[None].repeat(B, 1)
     d = dict(ref=ref, ref_len=torch.full((B,), R_FRAMES, dtype=torch.int64), ids=ids,
              ph_mask=torch.ones(B, P_TOK, dtype=torch.bool), mask=torch.ones(B, N_FRAMES, dtype=torch.bool))
+    t = torch.arange(48000, dtype=torch.float32) / 24000.0                       # bench.rs:8-13: 2 s, 440 Hz unit sine
+    d["ref_wav"] = torch.sin(2 * np.pi * 440.0 * t)[None, None].repeat(B, 1, 1)
+    d["ref3"] = torch.cat([ref, ref, torch.zeros_like(ref)], 0)                   # CFG rows (distill.py:76-99)
+    d["len3"] = torch.cat([d["ref_len"], d["ref_len"], torch.zeros_like(d["ref_len"])], 0)
+    d["ids3"] = torch.cat([ids, torch.zeros_like(ids), ids], 0)
+    d["pm3"] = torch.cat([d["ph_mask"], torch.zeros_like(d["ph_mask"]), d["ph_mask"]], 0)
     return {k: v.to(device) for k, v in d.items()}
 
 
-def one_step(eng, inp, seed, gather=None):
-    cache = eng.cond_encode(inp["ref"], inp["ref_len"], inp["ids"], inp["ph_mask"])
-    x = eng.sample(cache, inp["mask"], num_steps=DMD_STEPS, seed=seed)
+WORKLOADS = {
+    "dmd4": "cond-encode + 4-step DMD sampler + codec decode",                                  # BASELINE configs[1]
+    "clone": "codec encode of a 2 s reference wav + cond-encode + 4-step DMD + codec decode",   # configs[2]
+    "teacher128": "cond-encode (3B CFG rows) + 128-step teacher ODE with CFG + codec decode",   # configs[4]
+}
+
+
+def one_step(eng, inp, seed, gather=None, workload="dmd4"):
+    if workload == "clone":      # reference bench.rs times the codec encode of the 2 s / 440 Hz sine in every call
+        ref = eng.codec_encode(inp["ref_wav"])
+        cache = eng.cond_encode(ref, inp["ref_len"], inp["ids"], inp["ph_mask"])
+        x = eng.sample(cache, inp["mask"], num_steps=DMD_STEPS, seed=seed)
+    elif workload == "teacher128":
+        cache = eng.cond_encode(inp["ref3"], inp["len3"], inp["ids3"], inp["pm3"])
+        x = eng.sample(cache, inp["mask"], num_steps=128, mode="ode", cfg=True, seed=seed)
+    else:
+        cache = eng.cond_encode(inp["ref"], inp["ref_len"], inp["ids"], inp["ph_mask"])
+        x = eng.sample(cache, inp["mask"], num_steps=DMD_STEPS, seed=seed)
     audio = eng.codec_decode(x)
     if gather is not None:
         import torch.distributed as dist
@@ -95,6 +116,8 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--precision", default="bf16x3", choices=["bf16x3", "bf16"])
+    ap.add_argument("--workload", default="dmd4", choices=list(WORKLOADS),
+                    help="dmd4 = the headline configuration; clone / teacher128 = BASELINE.json configs[2] / configs[4]")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
@@ -119,7 +142,7 @@ def main():
 
     from smalltts_amd.engine import HipEngine
     eng = HipEngine(local, args.precision)
-    eng.load_synthetic(SEED, parts=("dit", "decoder"))
+    eng.load_synthetic(SEED, parts=("dit", "decoder", "encoder") if args.workload == "clone" else ("dit", "decoder"))
     eng.finalize()
     inp = make_inputs(device, rank)
     gather = (torch.empty(world * B, 1, 3200 * N_FRAMES, device=device if backend == "nccl" else "cpu")
@@ -132,11 +155,11 @@ def main():
         torch.cuda.synchronize()
 
     for i in range(args.warmup):
-        one_step(eng, inp, i, gather)
+        one_step(eng, inp, i, gather, args.workload)
     barrier()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        out = one_step(eng, inp, 100 + i, gather)
+        out = one_step(eng, inp, 100 + i, gather, args.workload)
     barrier()
     dt = time.perf_counter() - t0
     if dist is not None:
@@ -154,9 +177,9 @@ def main():
         "dtype": "bf16 MFMA x3 split (fp32-class), fp32 accumulate/residual" if args.precision == "bf16x3" else "bf16",
         "data": "synthetic (seeded inputs + seeded random weights; no released weights offline)",
         "rtf": round(dt / audio_s, 7),
-        "config": {"workload": "cond-encode + 4-step DMD sampler + codec decode, B=8 x 10 s per GPU "
+        "config": {"workload": WORKLOADS[args.workload] + ", B=8 x 10 s per GPU "
                                "(N=75 frames, R=15 ref frames, P=30 tokens; reference bench.rs workload)",
-                   "global_batch": n_gpus * B, "utterance_seconds": AUDIO_SEC_PER_UTT, "sampler_steps": DMD_STEPS,
+                   "global_batch": n_gpus * B, "utterance_seconds": AUDIO_SEC_PER_UTT, "sampler_steps": 128 if args.workload == "teacher128" else DMD_STEPS,
                    "parallelism": f"dp{n_gpus} (utterance shards, waveform all-gather)" if n_gpus > 1 else "single GPU"},
     }
 
@@ -165,7 +188,7 @@ def main():
         eng.profile(True)
         reps = min(args.steps, 5)   # same workload as the timed region, events on the launch stream
         for i in range(reps):
-            one_step(eng, inp, 900 + i, None)
+            one_step(eng, inp, 900 + i, None, args.workload)
         torch.cuda.synchronize()
         rows = eng.profile_report()
         eng.profile(False)
@@ -187,11 +210,18 @@ def main():
             "share_of_kernel_time": round(top["ms"] / tot, 4),
             "note": "algorithmic flops (2MNK, counted once, not x3 for the split) and bytes per launch / HIP-event time",
         }
+        # HBM bytes per launch of that kernel from the PMC passes of tools/profile_round.sh (committed under profiles/)
+        tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
+        if os.path.exists(tpath):
+            with open(tpath) as f:
+                tk = json.load(f).get("by_prof_name", {})
+            if top["name"] in tk:
+                res["roofline"]["traffic"] = tk[top["name"]]
         res["kernel_breakdown"] = [
             {"name": r["name"], "launches_per_step": r["launches"] // reps, "ms_per_step": round(r["ms"] / reps, 4),
              "TFLOPs": round(r["flops"] / max(r["ms"], 1e-9) / 1e9, 2), "GBs": round(r["bytes"] / max(r["ms"], 1e-9) / 1e6, 1)}
             for r in rows[:12]]
-    if rank == 0 and n_gpus == 1 and not args.no_cpu_baseline:
+    if rank == 0 and n_gpus == 1 and not args.no_cpu_baseline and args.workload == "dmd4":
         try:
             avail = len(os.sched_getaffinity(0))
         except Exception:

@@ -1,0 +1,122 @@
+"""GPU: the drop-in Python surface (SmallTTS / Encoder / Decoder / CLIs) on the HIP engine, checked against the
+CPU oracle end to end (cond-encode -> sampler -> codec decode) with synthetic weights and a REDUCED codec spec so
+the CPU side stays fast. Mirrors how the reference is used (tryme.py / clone.py / SmallTTS.forward)."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import codec_oracle as CO
+from oracle import dit_oracle as O
+from smalltts_amd.weights import (CodecSpec, codec_decoder_param_specs, codec_encoder_param_specs, dit_param_specs,
+                                  synth_state_dict)
+from tests.conftest import rel_l2
+
+pytestmark = pytest.mark.gpu
+SPEC = CodecSpec(n_filters=8, ratios=(8, 5, 5, 4, 2, 2), dec_depths=(1, 1, 1, 1, 1, 1, 1))  # hop 3200, tiny channels
+SEED = 11
+
+
+def snr_db(got, ref):
+    got, ref = np.asarray(got, np.float64), np.asarray(ref, np.float64)
+    return 10 * np.log10((ref ** 2).sum() / max(((got - ref) ** 2).sum(), 1e-300))
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from smalltts_amd.engine import HipEngine
+    e = HipEngine(0)
+    e.load_synthetic(SEED, parts=("dit", "decoder", "encoder"), codec_spec=SPEC)
+    e.finalize()
+    return e
+
+
+@pytest.fixture(scope="module")
+def oracle_w():
+    return (O.to_torch(synth_state_dict(dit_param_specs(), SEED)),
+            O.to_torch(synth_state_dict(codec_decoder_param_specs(SPEC), SEED)),
+            O.to_torch(synth_state_dict(codec_encoder_param_specs(SPEC), SEED)))
+
+
+def test_synthesize_matches_oracle_end_to_end(eng, oracle_w):
+    from smalltts_amd.api import HOP_SIZE, SmallTTS
+    w, wd, _ = oracle_w
+    tts = SmallTTS(engine=eng, seed=0)
+    g = torch.Generator().manual_seed(0)
+    ref = torch.randn(6, 64, generator=g)
+    toks = [3, 17, 42, 99, 150, 7, 8]
+    dur = 1.7                                    # -> int(1.7 * 7.5) = 12 frames
+    N = 12
+    noise = torch.randn(4, 1, N, 64, generator=g)
+    audio, lat = tts.synthesize_batch([ref.numpy()], [toks], [dur], noise=noise.numpy(), return_latents=True)
+    assert audio[0].shape == (1, HOP_SIZE * N) and audio[0].dtype == np.float32
+    with torch.no_grad():
+        ids = torch.tensor([toks])
+        pm = torch.ones(1, len(toks), dtype=torch.bool)
+        cache = O.encode_conditions(w, ref[None], torch.tensor([6]), ids, pm)
+        x = O.sample_dmd(w, cache, pm, torch.ones(1, N, dtype=torch.bool), noise, 4)
+        wav = CO.decode(wd, x, SPEC)
+    assert rel_l2(lat[0], x[0].numpy()) < 1e-4
+    assert snr_db(audio[0], wav[0].numpy()) > 60.0
+
+
+def test_reference_api_shapes_and_batch_equals_single(eng):
+    from smalltts_amd.api import SmallTTS, estimate_duration
+    assert estimate_duration("x" * 23) == 2.0 and estimate_duration("") == 0.5 and estimate_duration("y" * 1000) == 30.0
+    tts = SmallTTS(engine=eng, seed=1)
+    g = np.random.default_rng(0)
+    refs = [g.standard_normal((r, 64)).astype(np.float32) for r in (5, 9, 7)]
+    toks = [[1, 2, 3, 4], [10, 20, 30, 40, 50, 60], [7] * 9]
+    durs = [1.0, 2.2, 1.5]
+    ns = [7, 16, 11]
+    noise = g.standard_normal((4, 3, 16, 64)).astype(np.float32)
+    outs = tts.synthesize_batch(refs, toks, durs, noise=noise)
+    assert [o.shape for o in outs] == [(1, 3200 * n) for n in ns]
+    for b in range(3):  # the padded batch must equal per-utterance synthesis (reference semantics: independent calls)
+        one = tts.synthesize_batch([refs[b]], [toks[b]], [durs[b]], noise=np.ascontiguousarray(noise[:, b:b + 1, :ns[b]]))[0]
+        assert snr_db(outs[b], one) > 80.0
+    # forward(): token lists instead of strings (no espeak offline); transcription tokens are prepended
+    res = tts.forward([torch.from_numpy(refs[0])], [[5, 6]], [[7, 8, 9]], duration_sec=1.0)
+    assert len(res) == 1 and isinstance(res[0], torch.Tensor) and tuple(res[0].shape) == (1, 3200 * 7)
+
+
+def test_codec_wrappers_roundtrip_shapes_and_oracle(eng, oracle_w):
+    from smalltts_amd.api import Decoder, Encoder
+    _, wd, we = oracle_w
+    enc, dec = Encoder(engine=eng), Decoder(engine=eng)
+    g = torch.Generator().manual_seed(2)
+    audio = torch.randn(2, 1, 3200 * 3 + 100, generator=g) * 0.2
+    lat = enc.encode(audio)
+    assert lat.device.type == "cpu" and tuple(lat.shape) == (2, 3, 64)
+    with torch.no_grad():
+        assert snr_db(lat.numpy(), CO.encode(we, audio, SPEC).numpy()) > 60.0
+    wav = dec.decode(lat)
+    assert wav.device.type == "cpu" and tuple(wav.shape) == (2, 1, 9600)
+    with torch.no_grad():
+        assert snr_db(wav.numpy(), CO.decode(wd, lat, SPEC).numpy()) > 60.0
+
+
+def test_clone_cli_end_to_end(tmp_path):
+    """clone.py surface: wav -> resample -> codec encode -> synthesize -> PCM16 wav (config 3 of BASELINE.json)."""
+    from smalltts_amd.audio import read_wav, write_wav_pcm16
+    sr = 16000
+    t = np.arange(int(0.9 * sr)) / sr
+    write_wav_pcm16(str(tmp_path / "ref.wav"), 0.5 * np.sin(2 * np.pi * 440 * t), sr)
+    out = tmp_path / "clone.wav"
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-m", "smalltts_amd.scripts.clone", "--wav", str(tmp_path / "ref.wav"), "--text",
+                        "hello there", "--tokens", "1,2,3,4,5,6,7,8", "--duration", "1.0", "--out", str(out), "--weights",
+                        "synthetic:3", "--seed", "0"], cwd=root, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    a, rate = read_wav(str(out))
+    assert rate == 24000 and a.shape == (3200 * 7,) and np.isfinite(a).all()
+
+
+def test_missing_weight_file_is_a_clear_error():
+    from smalltts_amd.api import SmallTTS
+    with pytest.raises(FileNotFoundError, match="synthetic"):
+        SmallTTS(weights="/nonexistent/weights.smtts")
