@@ -9,7 +9,9 @@
 // ------------------------------------------------------------------------------------------
 // AdaLN:  y = LN(x) * (1 + scale) + shift       one wave per row, row kept in registers
 // ------------------------------------------------------------------------------------------
-template <int MAXV>
+// One wave per row; each lane owns NV4 float4 columns (c4 = lane + 64*i).  x, shift and scale are all requested
+// before the first reduction so the row pays one memory round trip, and outputs go out as 8/16-byte stores.
+template <int NV4>
 __global__ __launch_bounds__(256) void ln_modulate_kernel(const float* __restrict__ x, float* __restrict__ y,
                                                           bf16_t* __restrict__ yhi, bf16_t* __restrict__ ylo, int M,
                                                           int C, float eps, const float* __restrict__ shift,
@@ -18,40 +20,44 @@ __global__ __launch_bounds__(256) void ln_modulate_kernel(const float* __restric
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (row >= M) return;
-    const float* xr = x + (long)row * C;
-    float v[MAXV];
+    const int C4 = C >> 2;
+    const float4* xr = reinterpret_cast<const float4*>(x + (long)row * C);
+    const long r = (long)(mod_row0 + (row / rpb) * mod_rstride) * mod_ld;
+    const float4* sh4 = reinterpret_cast<const float4*>(shift + r);
+    const float4* sc4 = reinterpret_cast<const float4*>(scale + r);
+    float4 v[NV4], sh[NV4], sc[NV4];
+#pragma unroll
+    for (int i = 0; i < NV4; ++i) {
+        const int c = lane + 64 * i;
+        const int cc = c < C4 ? c : 0;
+        v[i] = xr[cc];
+        sh[i] = sh4[cc];
+        sc[i] = sc4[cc];
+        if (c >= C4) v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
     float s = 0.f;
 #pragma unroll
-    for (int i = 0; i < MAXV; ++i) {
-        int c = lane + 64 * i;
-        v[i] = c < C ? xr[c] : 0.f;
-        s += v[i];
-    }
+    for (int i = 0; i < NV4; ++i) s += v[i].x + v[i].y + v[i].z + v[i].w;
     const float mean = wave_sum(s) / (float)C;
     float q = 0.f;
 #pragma unroll
-    for (int i = 0; i < MAXV; ++i) {
-        int c = lane + 64 * i;
-        float d = c < C ? v[i] - mean : 0.f;
-        q += d * d;
+    for (int i = 0; i < NV4; ++i) {
+        if (lane + 64 * i < C4) {
+            const float a = v[i].x - mean, b = v[i].y - mean, c = v[i].z - mean, d = v[i].w - mean;
+            q += a * a + b * b + c * c + d * d;
+        }
     }
     const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)C + eps);
-    const int b = row / rpb;
-    const long r = (long)(mod_row0 + b * mod_rstride) * mod_ld;
-    float* yr = y + (long)row * C;
 #pragma unroll
-    for (int i = 0; i < MAXV; ++i) {
-        int c = lane + 64 * i;
-        if (c < C) {
-            const float o = (v[i] - mean) * rstd * (1.0f + scale[r + c]) + shift[r + c];
-            if (yhi) {
-                bf16_t h, l;
-                split1(o, h, l);
-                yhi[(long)row * C + c] = h;
-                if (ylo) ylo[(long)row * C + c] = l;
-            } else {
-                yr[c] = o;
-            }
+    for (int i = 0; i < NV4; ++i) {
+        const int c = lane + 64 * i;
+        if (c < C4) {
+            const float4 o = make_float4((v[i].x - mean) * rstd * (1.0f + sc[i].x) + sh[i].x,
+                                         (v[i].y - mean) * rstd * (1.0f + sc[i].y) + sh[i].y,
+                                         (v[i].z - mean) * rstd * (1.0f + sc[i].z) + sh[i].z,
+                                         (v[i].w - mean) * rstd * (1.0f + sc[i].w) + sh[i].w);
+            if (yhi) store_split4(yhi, ylo, (long)row * C + c * 4, o);
+            else reinterpret_cast<float4*>(y + (long)row * C)[c] = o;
         }
     }
 }
@@ -59,10 +65,10 @@ __global__ __launch_bounds__(256) void ln_modulate_kernel(const float* __restric
 hipError_t launch_ln_modulate(const float* x, float* y, bf16_t* yhi, bf16_t* ylo, int M, int C, float eps,
                               const float* shift, const float* scale, long mod_ld, int mod_row0, int mod_rstride,
                               int rows_per_batch, hipStream_t st) {
-    if (C > 1024) return hipErrorInvalidValue;
+    if (C > 1024 || C % 4 || mod_ld % 4) return hipErrorInvalidValue;
     ProfScope ps(st, "ln_modulate", 8.0 * M * C, 8.0 * M * C);
     dim3 grid((M + 3) / 4), block(256);
-    hipLaunchKernelGGL(ln_modulate_kernel<16>, grid, block, 0, st, x, y, yhi, ylo, M, C, eps, shift, scale, mod_ld,
+    hipLaunchKernelGGL(ln_modulate_kernel<4>, grid, block, 0, st, x, y, yhi, ylo, M, C, eps, shift, scale, mod_ld,
                        mod_row0, mod_rstride, rows_per_batch);
     LAUNCH_CHECK();
 }

@@ -36,6 +36,8 @@ class HipEngine:
             raise RuntimeError("smtts_create: " + self.lib.smtts_last_error(None).decode())
         self.h = h
         self._ws: Optional[torch.Tensor] = None
+        self._ws_named: Dict[str, torch.Tensor] = {}
+        self._ws_slot: Optional[str] = None   # set via use_workspace(): separate scratch per concurrent stream
         self.codec_spec: CodecSpec = DEFAULT_CODEC
         self.set_precision(precision)
 
@@ -58,7 +60,17 @@ class HipEngine:
     def _stream(self):
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 
+    def use_workspace(self, slot: Optional[str]):
+        """Select a named scratch buffer for subsequent calls (ops running concurrently on different streams must
+        not share scratch). None = the default buffer."""
+        self._ws_slot = slot
+
     def _workspace(self, nbytes: int) -> torch.Tensor:
+        if self._ws_slot is not None:
+            w = self._ws_named.get(self._ws_slot)
+            if w is None or w.numel() < nbytes:
+                self._ws_named[self._ws_slot] = w = torch.empty(int(nbytes), dtype=torch.uint8, device=self.device)
+            return w
         if self._ws is None or self._ws.numel() < nbytes:
             self._ws = None
             self._ws = torch.empty(int(nbytes), dtype=torch.uint8, device=self.device)
