@@ -151,6 +151,10 @@ __global__ __launch_bounds__(256) void codec_ffn_kernel(FfnArgs a) {
     for (int j = 0; j < NJ; ++j) {
         const int buf = j & 1;
         wait_vmcnt<0>();                 // W1_j (the only DMA of this wave still in flight) has landed
+        // a raw s_barrier does not wait for this wave's own ds_writes (n tile in phase 0): drain lgkmcnt first,
+        // otherwise another wave can pass the barrier and read the tile before the writes land (seen as sparse
+        // run-to-run differences of ~1e-4)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();    // B1: n tile written (j = 0); GEMM2_{j-1} done -> h and W2 buffers free
         issue_w2(j);
         if (j + 1 < NJ) issue_w1(j + 1, buf ^ 1);
@@ -196,6 +200,7 @@ __global__ __launch_bounds__(256) void codec_ffn_kernel(FfnArgs a) {
             wait_vmcnt<W1_PW>();
         else
             wait_vmcnt<0>();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's h-tile ds_writes have landed
         __builtin_amdgcn_s_barrier();    // B2: h_j complete, everyone's W2_j landed
 
         // ---- GEMM2: out[64 x CP] += h_j[64 x 64] . W2_j[CP x 64]^T  (wave tile 32 x CP/2) ------------
