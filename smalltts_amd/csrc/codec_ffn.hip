@@ -11,6 +11,8 @@
 #include "kernels.hpp"
 #include "prof.hpp"
 
+int g_ffn_bm128 = 1;  // C = 128: 1 = 128-frame tiles / 8 waves (default), 0 = 64-frame tiles / 4 waves (A/B)
+
 struct FfnArgs {
     float* x;
     RowMap img;            // row m of x
@@ -26,28 +28,35 @@ struct FfnArgs {
     float eps;
 };
 
-template <int CP, int SPLIT>
-__global__ __launch_bounds__(256) void codec_ffn_kernel(FfnArgs a) {
+// BM = 64: 4 waves; BM = 128: 8 waves (two per SIMD) and half the L2 -> LDS weight traffic per frame.
+// W1B = 2: W1 double-buffered (W1_{j+1} loads during all of chunk j).  W1B = 1 (needed at CP = 128, BM = 128: 160 KiB
+// exactly): W1_{j+1} is issued once all waves left GEMM1_j (extra barrier) and streams in under GELU_j + GEMM2_j.
+template <int CP, int SPLIT, int BM, int W1B>
+__global__ __launch_bounds__(BM * 4) void codec_ffn_kernel(FfnArgs a) {
     constexpr int KT = CP / 64;                 // k-tiles of GEMM1
     constexpr int NARR = SPLIT == 3 ? 2 : 1;
-    constexpr int TILE = 64 * 128;              // bytes of one [64 rows][64 bf16] k-tile image
-    constexpr int N_ARR = KT * TILE;            // n tile, per array
+    constexpr int NWV = BM / 16;                // waves: (BM / 32) x 2
+    constexpr int NT = NWV * 64;
+    constexpr int TILE = 64 * 128;              // bytes of one [64 rows][64 bf16] k-tile image (weights)
+    constexpr int RT = BM * 128;                // bytes of one [BM rows][64 bf16] k-tile image (activations)
+    constexpr int N_ARR = KT * RT;              // n tile, per array
     constexpr int W1_ARR = KT * TILE;           // W1 chunk (64 hidden rows x CP), per array
-    constexpr int H_ARR = TILE;                 // h chunk (64 rows x 64 hidden), per array
+    constexpr int H_ARR = RT;                   // h chunk (BM rows x 64 hidden), per array
     constexpr int W2_ARR = CP * 128;            // W2 chunk (CP out rows x 64 k), per array
     constexpr int OFF_N = 0;
-    constexpr int OFF_W1 = OFF_N + NARR * N_ARR;           // two buffers
-    constexpr int OFF_H = OFF_W1 + 2 * NARR * W1_ARR;
+    constexpr int OFF_W1 = OFF_N + NARR * N_ARR;
+    constexpr int OFF_H = OFF_W1 + W1B * NARR * W1_ARR;
     constexpr int OFF_W2 = OFF_H + NARR * H_ARR;
     constexpr int TN2 = CP / 64;                // 32-col tiles per wave in GEMM2 (wave tile 32 x CP/2)
-    constexpr int W1_PW = (NARR * KT * 8) / 4;  // DMA slots per wave per W1 chunk
-    constexpr int W2_PW = (NARR * (CP / 8)) / 4;
+    constexpr int W1_PW = (NARR * KT * 8) / NWV;  // DMA slots per wave per W1 chunk
+    constexpr int W2_PW = (NARR * (CP / 8)) / NWV;
+    static_assert(W1_PW * NWV == NARR * KT * 8 && W2_PW * NWV == NARR * (CP / 8), "DMA slots must divide over the waves");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
-    const int m0 = blockIdx.x * 64;
+    const int m0 = blockIdx.x * BM;
     const int NJ = a.F / 64;
     const unsigned lds0 = (unsigned)(size_t)SM_LPTR(smem);
 
@@ -92,8 +101,8 @@ __global__ __launch_bounds__(256) void codec_ffn_kernel(FfnArgs a) {
     {
         const int C4 = a.C >> 2;                 // float4 per row (8, 16 or 32)
         const int lpr = C4;                      // lanes per row
-        const int rows_per_pass = 256 / lpr;
-        for (int r0 = 0; r0 < 64; r0 += rows_per_pass) {
+        const int rows_per_pass = NT / lpr;
+        for (int r0 = 0; r0 < BM; r0 += rows_per_pass) {
             const int r = r0 + tid / lpr, c4 = tid % lpr;
             const int m = m0 + r;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -110,12 +119,12 @@ __global__ __launch_bounds__(256) void codec_ffn_kernel(FfnArgs a) {
                 l[e] = (bf16_t)(o4[e] - (float)h[e]);
             }
             const int k = c4 * 4, kt = k >> 6, kc = (k & 63) >> 3;
-            const int off = kt * TILE + r * 128 + ((kc ^ ((r >> 1) & 7)) << 4) + (k & 7) * 2;
+            const int off = kt * RT + r * 128 + ((kc ^ ((r >> 1) & 7)) << 4) + (k & 7) * 2;
             *reinterpret_cast<bf16x4*>(smem + OFF_N + off) = h;
             if (SPLIT == 3) *reinterpret_cast<bf16x4*>(smem + OFF_N + N_ARR + off) = l;
         }
         if (a.C < CP) {  // zero the padded k columns [C, CP) of the n tile (C = 32 -> chunks 4..7 of every row)
-            for (int i = tid; i < 64 * 4; i += 256) {
+            for (int i = tid; i < BM * 4; i += NT) {
                 const int r = i >> 2, kc = 4 + (i & 3);
                 const int off = r * 128 + ((kc ^ ((r >> 1) & 7)) << 4);
                 *reinterpret_cast<uint4*>(smem + OFF_N + off) = make_uint4(0, 0, 0, 0);
@@ -149,7 +158,7 @@ __global__ __launch_bounds__(256) void codec_ffn_kernel(FfnArgs a) {
         for (int r = 0; r < 16; ++r) acc2[t][r] = 0.f;
 
     for (int j = 0; j < NJ; ++j) {
-        const int buf = j & 1;
+        const int buf = W1B == 2 ? (j & 1) : 0;
         wait_vmcnt<0>();                 // W1_j (the only DMA of this wave still in flight) has landed
         // a raw s_barrier does not wait for this wave's own ds_writes (n tile in phase 0): drain lgkmcnt first,
         // otherwise another wave can pass the barrier and read the tile before the writes land (seen as sparse
@@ -157,7 +166,7 @@ __global__ __launch_bounds__(256) void codec_ffn_kernel(FfnArgs a) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();    // B1: n tile written (j = 0); GEMM2_{j-1} done -> h and W2 buffers free
         issue_w2(j);
-        if (j + 1 < NJ) issue_w1(j + 1, buf ^ 1);
+        if (W1B == 2 && j + 1 < NJ) issue_w1(j + 1, buf ^ 1);
 
         // ---- GEMM1: h_j[64 x 64] = n[64 x CP] . W1_j[64 x CP]^T  (wave tile 32 x 32) -----------------
         floatx16 acc1;
@@ -169,16 +178,20 @@ __global__ __launch_bounds__(256) void codec_ffn_kernel(FfnArgs a) {
         for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) {
-                const bf16x8 ah = *reinterpret_cast<const bf16x8*>(nb + kt * TILE + a1_off[kk]);
+                const bf16x8 ah = *reinterpret_cast<const bf16x8*>(nb + kt * RT + a1_off[kk]);
                 const bf16x8 bh = *reinterpret_cast<const bf16x8*>(w1b + kt * TILE + b1_off[kk]);
                 if (SPLIT == 3) {
-                    const bf16x8 al = *reinterpret_cast<const bf16x8*>(nb + N_ARR + kt * TILE + a1_off[kk]);
+                    const bf16x8 al = *reinterpret_cast<const bf16x8*>(nb + N_ARR + kt * RT + a1_off[kk]);
                     const bf16x8 bl = *reinterpret_cast<const bf16x8*>(w1b + W1_ARR + kt * TILE + b1_off[kk]);
                     acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc1, 0, 0, 0);
                     acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc1, 0, 0, 0);
                 }
                 acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc1, 0, 0, 0);
             }
+        if (W1B == 1) {  // single W1 buffer: refill it as soon as every wave has left GEMM1_j (reads consumed by the MFMAs)
+            __builtin_amdgcn_s_barrier();
+            if (j + 1 < NJ) issue_w1(j + 1, 0);
+        }
         // ---- bias + GELU -> split bf16 -> h image (A operand of GEMM2): element (row, k = wn*32 + col) ----
         {
             const int k = wn * 32 + (lane & 31);
@@ -251,12 +264,12 @@ __global__ __launch_bounds__(256) void codec_ffn_kernel(FfnArgs a) {
     }
 }
 
-template <int CP, int SPLIT>
+template <int CP, int SPLIT, int BM, int W1B>
 static hipError_t ffn_go(const FfnArgs& a, hipStream_t st) {
-    constexpr int KT = CP / 64, NARR = SPLIT == 3 ? 2 : 1, TILE = 64 * 128;
-    constexpr size_t lds = (size_t)NARR * (KT * TILE + 2 * KT * TILE + TILE + CP * 128);
+    constexpr int KT = CP / 64, NARR = SPLIT == 3 ? 2 : 1, TILE = 64 * 128, RT = BM * 128;
+    constexpr size_t lds = (size_t)NARR * (KT * RT + W1B * KT * TILE + RT + CP * 128);
     static_assert(lds <= 160 * 1024, "fused FFN LDS budget");
-    auto kern = codec_ffn_kernel<CP, SPLIT>;
+    auto kern = codec_ffn_kernel<CP, SPLIT, BM, W1B>;
     static bool done = false;
     if (!done) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -264,7 +277,7 @@ static hipError_t ffn_go(const FfnArgs& a, hipStream_t st) {
         if (e != hipSuccess) return e;
         done = true;
     }
-    hipLaunchKernelGGL(kern, dim3((a.M + 63) / 64), dim3(256), lds, st, a);
+    hipLaunchKernelGGL(kern, dim3((a.M + BM - 1) / BM), dim3(BM * 4), lds, st, a);
     return hipGetLastError();
 }
 
@@ -278,6 +291,9 @@ hipError_t launch_codec_ffn_fused(float* x, RowMap img, const float* norm_w, con
     // algorithmic: two GEMMs; bytes: x read + written once, weights once
     ProfScope ps(st, C == 128 ? "codec_ffn_fused<128>" : C == 64 ? "codec_ffn_fused<64>" : "codec_ffn_fused<32>",
                  4.0 * M * (double)C * F, 8.0 * M * C + 8.0 * (double)C * F);
-    if (CP == 64) return split == 3 ? ffn_go<64, 3>(a, st) : ffn_go<64, 1>(a, st);
-    return split == 3 ? ffn_go<128, 3>(a, st) : ffn_go<128, 1>(a, st);
+    // CP = 64 (C = 64, 32): 64-frame tiles, two independent 4-wave workgroups per CU (80 KiB each) — measured faster
+    // than one 128-frame / 8-wave workgroup (1.59 vs 1.74 ms and 1.92 vs 2.17 ms per batch)
+    if (CP == 64) return split == 3 ? ffn_go<64, 3, 64, 2>(a, st) : ffn_go<64, 1, 64, 2>(a, st);
+    if (g_ffn_bm128) return split == 3 ? ffn_go<128, 3, 128, 1>(a, st) : ffn_go<128, 1, 128, 1>(a, st);
+    return split == 3 ? ffn_go<128, 3, 64, 2>(a, st) : ffn_go<128, 1, 64, 2>(a, st);
 }
