@@ -129,6 +129,14 @@ int smtts_test_attention(smtts_handle h, void* stream, const float* qkvg, const 
                          const float* k_text, const float* v_text, int P, const uint8_t* mask_self,
                          const uint8_t* mask_ref, const uint8_t* mask_text, int B, int N, int H, int dh, float* out);
 
+/* matrix-core attention (qk_prep + attention_mfma kernel), same contract as smtts_test_attention */
+int smtts_test_attention_mfma(smtts_handle h, void* stream, const float* qkvg, const float* qw, const float* kw, float eps,
+                              const float* rope, int rot_dim, const float* k_ref, const float* v_ref, int R,
+                              const float* k_text, const float* v_text, int P, const uint8_t* mask_self,
+                              const uint8_t* mask_ref, const uint8_t* mask_text, int B, int N, int H, int dh, float* out);
+/* engine-wide switch: 1 (default) = matrix-core attention, 0 = fp32 VALU attention kernel */
+int smtts_test_set_attention_mfma(smtts_handle h, int on);
+
 #ifdef __cplusplus
 }
 #endif

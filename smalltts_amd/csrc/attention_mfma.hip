@@ -1,0 +1,285 @@
+// Joint attention on the matrix cores (split-bf16, fp32-class), gfx950.
+//
+// One workgroup (4 waves) = 32 queries of one (batch, head); keys/values stream through LDS in 64-key chunks
+// with an online softmax, so Ktot is unbounded.  Inputs are the pre-normalised / pre-rotated q, k (qk_prep_kernel)
+// and v rows of the packed projection buffer plus the cross-KV cache.
+//
+//   S^T[key][query] = K . Q^T       A = K chunk  [64 keys][DHP dims]  (row-major, dims contiguous)
+//                                   B = Q tile   [32 queries][DHP]    -> every lane owns ONE query column,
+//                                   so max / sum over keys are in-lane (+ one exchange with lane^32).
+//   O^T[dim][query] = V^T . P^T     A = V^T chunk [DHP dims][64 keys]  (transposed while staging)
+//                                   B = P^T fragments built in registers from the S^T accumulators with
+//                                   v_permlane32_swap (no LDS round trip for P).
+// Every wave computes the full S^T chunk (cheap: 48 MFMAs) so the softmax state is wave-local, and owns one 32-dim
+// tile of O^T.  All operands are split into bf16 hi/lo and each product takes 3 MFMAs (lo*hi + hi*lo + hi*hi).
+// LDS images use 16-B chunks XOR-swizzled by row so ds_read_b128 fragment reads are conflict free.
+#include "kernels.hpp"
+#include "prof.hpp"
+
+template <int DH>
+__global__ __launch_bounds__(256) void attention_mfma_kernel(AttnArgs a) {
+    constexpr int DHP = DH <= 64 ? 64 : 128;  // padded head dim (K of QK^T), zero filled
+    constexpr int KC = 64, QT = 32;
+    constexpr int QPITCH = DHP * 2;            // bytes per row of the Q / K images
+    constexpr int CPR = QPITCH / 16;           // 16-B chunks per row (8 or 16)
+    constexpr int Q_ARR = QT * QPITCH, K_ARR = KC * QPITCH, V_ARR = DHP * 128;  // Vt rows: 64 keys x 2 B = 128 B
+    constexpr int OFF_Q = 0, OFF_K = OFF_Q + 2 * Q_ARR, OFF_V = OFF_K + 2 * K_ARR;
+    constexpr int NDT = DHP / 32;              // 32-dim tiles of O^T (2 or 4); wave w owns tile w (w < NDT)
+    constexpr int KS1 = DHP / 16;              // k16 steps of S^T
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int q0 = blockIdx.x * QT, h = blockIdx.y, b = blockIdx.z;
+    const int N = a.N, R = a.k_ref ? a.R : 0, P = a.k_text ? a.P : 0, Ktot = N + R + P;
+    const float sm_scale = 1.0f / sqrtf((float)DH);
+    const int fr = lane & 31, fh = lane >> 5;
+
+    auto swz = [](int row, int c) { return CPR == 16 ? (c ^ (row & 15)) : (c ^ ((row >> 1) & 7)); };
+
+    // ---- stage Q (pre-scaled), split hi/lo: thread -> (query, 4 dims) -----------------------------------
+    for (int i = tid; i < QT * (DHP / 4); i += 256) {
+        const int r = i / (DHP / 4), d4 = i % (DHP / 4), n = q0 + r, d = d4 * 4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (n < N && d < DH) v = *reinterpret_cast<const float4*>(a.q + (long)b * a.bs + (long)n * a.rs + h * DH + d);
+        const float f[4] = {v.x * sm_scale, v.y * sm_scale, v.z * sm_scale, v.w * sm_scale};
+        bf16x4 hh, ll;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { hh[e] = (bf16_t)f[e]; ll[e] = (bf16_t)(f[e] - (float)hh[e]); }
+        const int off = r * QPITCH + (swz(r, d >> 3) << 4) + (d & 7) * 2;
+        *reinterpret_cast<bf16x4*>(smem + OFF_Q + off) = hh;
+        *reinterpret_cast<bf16x4*>(smem + OFF_Q + Q_ARR + off) = ll;
+    }
+
+    float m_run = -INFINITY, l_run = 0.f;  // per query (lane & 31); both lane halves keep identical copies
+    floatx16 oacc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) oacc[r] = 0.f;
+
+    for (int c0 = 0; c0 < Ktot; c0 += KC) {
+        __syncthreads();  // previous chunk consumed (and Q image visible on the first pass)
+        // ---- stage K chunk [key][dim] and V^T chunk [dim][key], split hi/lo.  All global loads of the chunk are
+        // issued before the first LDS store (one memory round trip per chunk, not one per item). --------------------
+        {
+            constexpr int ITEMS = KC * (DHP / 4) / 256;  // float4 items per thread (4 or 8)
+            float4 kq[ITEMS], vq[ITEMS];
+#pragma unroll
+            for (int it = 0; it < ITEMS; ++it) {
+                const int i = it * 256 + tid;
+                const int r = i / (DHP / 4), d = (i % (DHP / 4)) * 4;
+                int gk = c0 + r;
+                gk = gk < Ktot ? gk : Ktot - 1;          // clamp: always a readable row; masked out by vmask
+                const int dc = d < DH ? d : DH - 4;      // clamp inside the row; pad dims are zeroed below
+                const float* kp;
+                const float* vp;
+                if (gk < N) {
+                    const long base = (long)b * a.bs + (long)gk * a.rs + h * DH + dc;
+                    kp = a.k + base; vp = a.v + base;
+                } else if (gk < N + R) {
+                    const long base = (((long)b * a.H + h) * R + (gk - N)) * DH + dc;
+                    kp = a.k_ref + base; vp = a.v_ref + base;
+                } else {
+                    const long base = (((long)b * a.H + h) * P + (gk - N - R)) * DH + dc;
+                    kp = a.k_text + base; vp = a.v_text + base;
+                }
+                kq[it] = *reinterpret_cast<const float4*>(kp);
+                vq[it] = *reinterpret_cast<const float4*>(vp);
+            }
+#pragma unroll
+            for (int it = 0; it < ITEMS; ++it) {
+                const int i = it * 256 + tid;
+                const int r = i / (DHP / 4), d = (i % (DHP / 4)) * 4;
+                const bool real = (c0 + r < Ktot) && d < DH;
+                const float kf[4] = {kq[it].x, kq[it].y, kq[it].z, kq[it].w};
+                const float vf[4] = {vq[it].x, vq[it].y, vq[it].z, vq[it].w};
+                bf16x4 kh, kl;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float kv = real ? kf[e] : 0.f;
+                    kh[e] = (bf16_t)kv;
+                    kl[e] = (bf16_t)(kv - (float)kh[e]);
+                }
+                const int koff = r * QPITCH + (swz(r, d >> 3) << 4) + (d & 7) * 2;
+                *reinterpret_cast<bf16x4*>(smem + OFF_K + koff) = kh;
+                *reinterpret_cast<bf16x4*>(smem + OFF_K + K_ARR + koff) = kl;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {  // transpose: Vt[dim][key]; 128-B rows, chunk = key >> 3
+                    const int dr = d + e;
+                    const float vv = real ? vf[e] : 0.f;
+                    const bf16_t vh = (bf16_t)vv, vl = (bf16_t)(vv - (float)vh);
+                    const int voff = dr * 128 + (((r >> 3) ^ ((dr >> 1) & 7)) << 4) + (r & 7) * 2;
+                    *reinterpret_cast<bf16_t*>(smem + OFF_V + voff) = vh;
+                    *reinterpret_cast<bf16_t*>(smem + OFF_V + V_ARR + voff) = vl;
+                }
+            }
+        }
+        // key validity of this chunk as a 64-bit mask (lane = key), identical in every wave
+        bool kval = false;
+        {
+            const int gk = c0 + lane;
+            if (gk < Ktot) {
+                const uint8_t* mk = gk < N ? a.mask_self : (gk < N + R ? a.mask_ref : a.mask_text);
+                const int mi = gk < N ? b * N + gk : (gk < N + R ? b * R + (gk - N) : b * P + (gk - N - R));
+                kval = !mk || mk[mi];
+            }
+        }
+        const unsigned long long vmask = __ballot(kval);
+        __syncthreads();
+
+        // ---- S^T chunk: 2 key tiles x 32 queries ----------------------------------------------------------------
+        floatx16 s[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[t][r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < KS1; ++ks) {
+            const int c = ks * 2 + fh;
+            const int qoff = OFF_Q + fr * QPITCH + (swz(fr, c) << 4);
+            const bf16x8 qh = *reinterpret_cast<const bf16x8*>(smem + qoff);
+            const bf16x8 ql = *reinterpret_cast<const bf16x8*>(smem + qoff + Q_ARR);
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int kr = t * 32 + fr;
+                const int koff = OFF_K + kr * QPITCH + (swz(kr, c) << 4);
+                const bf16x8 kh = *reinterpret_cast<const bf16x8*>(smem + koff);
+                const bf16x8 kl = *reinterpret_cast<const bf16x8*>(smem + koff + K_ARR);
+                s[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kl, qh, s[t], 0, 0, 0);
+                s[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, ql, s[t], 0, 0, 0);
+                s[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, qh, s[t], 0, 0, 0);
+            }
+        }
+        // ---- online softmax over keys for this lane's query: key(t, r) = 32 t + (r&3) + 8 (r>>2) + 4 fh ------------
+        float cm = -INFINITY;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * fh;
+                const bool ok = (vmask >> key) & 1ull;
+                s[t][r] = ok ? s[t][r] : -INFINITY;
+                cm = fmaxf(cm, s[t][r]);
+            }
+        cm = fmaxf(cm, __shfl_xor(cm, 32, 64));
+        const float m_new = fmaxf(m_run, cm);
+        float alpha = 1.f, csum = 0.f;
+        const bool live = m_new != -INFINITY;
+        if (live) alpha = (m_run == -INFINITY) ? 0.f : __expf(m_run - m_new);
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float p = (live && s[t][r] != -INFINITY) ? __expf(s[t][r] - m_new) : 0.f;
+                s[t][r] = p;
+                csum += p;
+            }
+        csum += __shfl_xor(csum, 32, 64);
+        l_run = l_run * alpha + csum;
+        m_run = m_new;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[r] *= alpha;
+
+        // ---- O^T tile w += V^T . P^T over the 64 keys (4 k16 steps) ---------------------------------------------
+        if (w < NDT) {
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const int t = ks >> 1, r0 = (ks & 1) * 8;
+                unsigned xh[2], yh[2], xl[2], yl[2];
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const float pa = s[t][r0 + 2 * e], pb = s[t][r0 + 2 * e + 1];
+                    const float pc = s[t][r0 + 4 + 2 * e], pd = s[t][r0 + 4 + 2 * e + 1];
+                    const bf16_t ah = (bf16_t)pa, bh = (bf16_t)pb, ch = (bf16_t)pc, dh_ = (bf16_t)pd;
+                    const bf16_t al = (bf16_t)(pa - (float)ah), bl = (bf16_t)(pb - (float)bh);
+                    const bf16_t cl = (bf16_t)(pc - (float)ch), dl = (bf16_t)(pd - (float)dh_);
+                    auto pk = [](bf16_t lo, bf16_t hi) {
+                        return (unsigned)__builtin_bit_cast(unsigned short, lo) |
+                               ((unsigned)__builtin_bit_cast(unsigned short, hi) << 16);
+                    };
+                    xh[e] = pk(ah, bh); yh[e] = pk(ch, dh_);
+                    xl[e] = pk(al, bl); yl[e] = pk(cl, dl);
+                }
+                // half 0 needs keys 0..7 of the step, half 1 keys 8..15: swap the upper half of X with the lower half of Y
+                unsigned fh_[4], fl_[4];
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    auto rh = __builtin_amdgcn_permlane32_swap(xh[e], yh[e], false, false);
+                    auto rl = __builtin_amdgcn_permlane32_swap(xl[e], yl[e], false, false);
+                    fh_[e] = rh[0]; fh_[2 + e] = rh[1];
+                    fl_[e] = rl[0]; fl_[2 + e] = rl[1];
+                }
+                const bf16x8 ph = __builtin_bit_cast(bf16x8, *reinterpret_cast<uint4*>(fh_));
+                const bf16x8 pl = __builtin_bit_cast(bf16x8, *reinterpret_cast<uint4*>(fl_));
+                const int vr = w * 32 + fr;
+                const int voff = OFF_V + vr * 128 + (((ks * 2 + fh) ^ ((vr >> 1) & 7)) << 4);
+                const bf16x8 vh = *reinterpret_cast<const bf16x8*>(smem + voff);
+                const bf16x8 vl = *reinterpret_cast<const bf16x8*>(smem + voff + V_ARR);
+                oacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vl, ph, oacc, 0, 0, 0);
+                oacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, pl, oacc, 0, 0, 0);
+                oacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, ph, oacc, 0, 0, 0);
+            }
+        }
+    }
+
+    // ---- normalise, gate, store: lane = query fr, rows = dims 32 w + (r&3) + 8 (r>>2) + 4 fh ---------------------------
+    const int n = q0 + fr;
+    if (w < NDT && n < N) {
+        const float inv = l_run > 0.f ? 1.0f / l_run : 0.f;
+        const long gbase = (long)b * a.bs + (long)n * a.rs + h * DH;
+        const long obase = (long)b * a.obs + (long)n * a.ors + h * DH;
+        float gv[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int d = 32 * w + (r & 3) + 8 * (r >> 2) + 4 * fh;
+            gv[r] = d < DH ? a.gate[gbase + d] : 0.f;
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int d = 32 * w + (r & 3) + 8 * (r >> 2) + 4 * fh;
+            if (d < DH) {
+                const float val = oacc[r] * inv * sigmoid_f(gv[r]);
+                if (a.out_hi) {
+                    bf16_t hh, ll;
+                    split1(val, hh, ll);
+                    a.out_hi[obase + d] = hh;
+                    if (a.out_lo) a.out_lo[obase + d] = ll;
+                } else {
+                    a.out[obase + d] = val;
+                }
+            }
+        }
+    }
+}
+
+template <int DH>
+static hipError_t attn_mfma_go(const AttnArgs& a, hipStream_t st) {
+    constexpr int DHP = DH <= 64 ? 64 : 128;
+    constexpr size_t lds = 2 * (32 * DHP * 2) + 2 * (64 * DHP * 2) + 2 * (DHP * 128);
+    auto kern = attention_mfma_kernel<DH>;
+    static bool done = false;
+    if (!done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)lds);
+        if (e != hipSuccess) return e;
+        done = true;
+    }
+    dim3 grid((a.N + 31) / 32, a.H, a.B);
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, a);
+    return hipGetLastError();
+}
+
+// requires a.prenormed (q, k already RMS-normalised + rotated by launch_qk_prep) and 16-B aligned rows
+hipError_t launch_attention_mfma(const AttnArgs& a, hipStream_t st) {
+    if (a.N <= 0 || a.B <= 0) return hipSuccess;
+    if (!a.prenormed || (a.rs % 4) || (a.bs % 4) || (a.dh % 4)) return hipErrorInvalidValue;
+    const double kt = a.N + (a.k_ref ? a.R : 0) + (a.k_text ? a.P : 0);
+    const double bh = (double)a.B * a.H;
+    ProfScope ps(st, a.dh == 120 ? "attention_mfma<120>" : a.dh == 64 ? "attention_mfma<64>" : "attention_mfma<128>",
+                 4.0 * bh * a.N * kt * a.dh, 4.0 * bh * a.dh * (5.0 * a.N + 2.0 * (kt - a.N)));
+    switch (a.dh) {
+        case 64: return attn_mfma_go<64>(a, st);
+        case 120: return attn_mfma_go<120>(a, st);
+        case 128: return attn_mfma_go<128>(a, st);
+    }
+    return hipErrorInvalidValue;
+}

@@ -136,6 +136,7 @@ int smtts_test_gemm3(smtts_handle h, void* stream, const float* A, const float* 
 }
 extern int g_ffn_bm128;
 int smtts_test_set_fused_ffn(smtts_handle h, int on) { E.set_fused_ffn((on & 1) != 0); g_ffn_bm128 = (on & 2) ? 0 : 1; return 0; }
+int smtts_test_set_attention_mfma(smtts_handle h, int on) { E.set_attn_mfma(on != 0); return 0; }
 int smtts_test_force_gemm_v1(int on) { g_gemm_force_v1 = on; return 0; }
 
 // ---- test hooks -------------------------------------------------------------------------------
@@ -171,6 +172,36 @@ int smtts_test_attention(smtts_handle h, void* stream, const float* qkvg, const 
     (void)hipFree(rc);
     (void)hipFree(rs);
     return e == hipSuccess ? 0 : E.fail_hip(e, "attention");
+}
+
+int smtts_test_attention_mfma(smtts_handle h, void* stream, const float* qkvg, const float* qw, const float* kw, float eps,
+                              const float* rope, int rot_dim, const float* k_ref, const float* v_ref, int R,
+                              const float* k_text, const float* v_text, int P, const uint8_t* mask_self,
+                              const uint8_t* mask_ref, const uint8_t* mask_text, int B, int N, int H, int dh, float* out) {
+    AttnArgs a{};
+    const int D = H * dh;
+    float *tmp = nullptr, *rc = nullptr, *rs = nullptr;
+    const size_t nq = (size_t)B * N * 4 * D;
+    const int nr = N * rot_dim;
+    if (hipMalloc(&tmp, nq * 4) != hipSuccess || hipMalloc(&rc, (size_t)nr * 4) != hipSuccess ||
+        hipMalloc(&rs, (size_t)nr * 4) != hipSuccess)
+        return E.fail("test_attention_mfma: alloc failed");
+    (void)hipMemcpyAsync(tmp, qkvg, nq * 4, hipMemcpyDeviceToDevice, ST(stream));  // qk_prep works in place
+    (void)launch_rope_cossin(rope, rc, rs, nr, ST(stream));
+    a.q = tmp; a.k = tmp + D; a.v = tmp + 2 * D; a.gate = tmp + 3 * D;
+    a.bs = (long)N * 4 * D; a.rs = 4 * D;
+    a.qw = qw; a.kw = kw; a.eps = eps; a.rope_cos = rc; a.rope_sin = rs; a.rot_dim = rot_dim;
+    a.k_ref = R > 0 ? k_ref : nullptr; a.v_ref = v_ref; a.R = R;
+    a.k_text = P > 0 ? k_text : nullptr; a.v_text = v_text; a.P = P;
+    a.mask_self = mask_self; a.mask_ref = mask_ref; a.mask_text = mask_text;
+    a.out = out; a.obs = (long)N * D; a.ors = D;
+    a.B = B; a.N = N; a.H = H; a.dh = dh;
+    a.prenormed = 1;
+    hipError_t e = launch_qk_prep(a, ST(stream));
+    if (e == hipSuccess) e = launch_attention_mfma(a, ST(stream));
+    (void)hipStreamSynchronize(ST(stream));
+    (void)hipFree(tmp); (void)hipFree(rc); (void)hipFree(rs);
+    return e == hipSuccess ? 0 : E.fail_hip(e, "attention_mfma");
 }
 
 }  // extern "C"

@@ -582,7 +582,7 @@ int Engine::run_encoder(hipStream_t st, const EncoderW& e, void* wsv, int B, int
         a.B = B; a.N = S; a.H = e.heads; a.dh = e.dh;
         a.prenormed = 1;
         HIPC(launch_qk_prep(a, st));
-        HIPC(launch_attention(a, st));
+        HIPC(attn_mfma_ ? launch_attention_mfma(a, st) : launch_attention(a, st));
         EpiResid<0> r1{w.x, rd, nullptr, nullptr, 0, 0, 0, 1, nullptr};
         HIPC(gemm3_resid(ops3(w.o, rd, b.wo, M), 0, r1, split_, st));
         HIPC(launch_rmsnorm(w.x, rd, nullptr, w.y.hi, w.y.lo, rd, M, D, e.eps, b.mn, st));
@@ -781,7 +781,7 @@ int Engine::denoise_core(hipStream_t st, const float* x_t, const uint8_t* mask, 
         a.B = B; a.N = N; a.H = kHeads; a.dh = kDh;
         a.prenormed = 1;
         HIPC(launch_qk_prep(a, st));
-        HIPC(launch_attention(a, st));
+        HIPC(attn_mfma_ ? launch_attention_mfma(a, st) : launch_attention(a, st));
         // to_out + mask + gated residual (dit.py:117-118,198)
         EpiResid<0> r1{w.x, rh, nullptr, m + 2 * kHidden, kModLd, mod_row0, mod_rstride, N, mask};
         HIPC(gemm3_resid_splitk(ops3(w.o, rh, b.out, M), r1, w.part, kSplitK, split_, st));

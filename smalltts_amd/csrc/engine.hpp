@@ -91,6 +91,7 @@ class Engine {
     bool has_encoder() const { return enc_.ready; }
     void set_precision(int split) { split_ = split == 1 ? 1 : 3; }
     void set_fused_ffn(bool on) { fused_ffn_ = on; }
+    void set_attn_mfma(bool on) { attn_mfma_ = on; }
     int precision() const { return split_; }
 
     // ---- operators (device pointers, async on `st`) ------------------------------------------
@@ -167,6 +168,7 @@ class Engine {
     std::vector<void*> allocs_;
     int split_ = 3;
     bool fused_ffn_ = true;  // test hook: smtts_test_set_fused_ffn
+    bool attn_mfma_ = true;  // matrix-core attention (attention_mfma.hip); false = fp32 VALU kernel (attention.hip)
     Profiler prof_;
     bool prof_on_ = false;
     bool finalized_ = false;

@@ -296,7 +296,7 @@ class HipEngine:
         return out
 
     def test_attention(self, qkvg, qw, kw, eps, rope, rot_dim, H, dh, k_ref=None, v_ref=None, k_text=None, v_text=None,
-                       mask_self=None, mask_ref=None, mask_text=None):
+                       mask_self=None, mask_ref=None, mask_text=None, mfma=False):
         qkvg = self._dev(qkvg, torch.float32)
         B, N, _ = qkvg.shape
         f = lambda x, dt=torch.float32: None if x is None else self._dev(x, dt)
@@ -305,7 +305,8 @@ class HipEngine:
         R = 0 if k_ref is None else k_ref.shape[2]
         P = 0 if k_text is None else k_text.shape[2]
         out = torch.empty(B, N, H * dh, device=self.device)
-        self._ck(self.lib.smtts_test_attention(self.h, self._stream(), _p(qkvg), _p(qw), _p(kw), eps, _p(rope), rot_dim,
+        fn = self.lib.smtts_test_attention_mfma if mfma else self.lib.smtts_test_attention
+        self._ck(fn(self.h, self._stream(), _p(qkvg), _p(qw), _p(kw), eps, _p(rope), rot_dim,
                                                _p(k_ref), _p(v_ref), R, _p(k_text), _p(v_text), P, _p(mask_self),
                                                _p(mask_ref), _p(mask_text), B, N, H, dh, _p(out)), "test_attention")
         return out
