@@ -119,7 +119,7 @@ int smtts_randn(smtts_handle h, void* stream, float* out, int64_t n, uint64_t se
 
 void smtts_alpha_sigma(float t, float* alpha, float* sigma) { alpha_sigma_host(t, *alpha, *sigma); }
 
-int smtts_profile_enable(smtts_handle h, int on) { E.profile_enable(on != 0); return 0; }
+int smtts_profile_enable(smtts_handle h, int on) { E.profile_enable(on); return 0; }
 int smtts_profile_report(smtts_handle h, char* buf, size_t cap) {
     std::string r = E.profile_report();
     if (r.size() + 1 > cap) return E.fail("profile_report: buffer too small");

@@ -28,14 +28,17 @@ inline std::string sidx(const std::string& a, int i, const std::string& b) { ret
 }  // namespace
 
 thread_local Profiler* g_prof = nullptr;
+thread_local const char* g_prof_tag = nullptr;
 int g_gemm_force_v1 = 1;  // fp32-A GEMMs (cold paths) use the register-staged v1 kernel; 0 routes them to the v2 DMA kernel
 
 Engine::Engine(int device) : device_(device) {}
 
-void Engine::profile_enable(bool on) {
+void Engine::profile_enable(int mode) {
+    const bool on = mode != 0;
     prof_on_ = on;
     prof_.reset();
     g_prof = on ? &prof_ : nullptr;
+    g_prof_tag = mode == 2 ? "" : nullptr;  // 2 = tagged: kernel names carry the pipeline phase
 }
 
 std::string Engine::profile_report() {
@@ -607,6 +610,7 @@ size_t Engine::cond_ws_bytes(int B, int R, int P) const {
 int Engine::cond_encode(hipStream_t st, const float* ref, const int64_t* ref_len, const int64_t* ids,
                         const uint8_t* ph_mask, int B, int R, int P, float* k_ref, float* v_ref, uint8_t* ref_mask,
                         float* k_text, float* v_text, void* ws, size_t ws_bytes, float* ref_seq_out, float* mem_out) {
+    ProfTag ptag("enc");
     if (!dit_ready_) return fail("cond_encode: DiT weights not finalized");
     if (R > kMaxPos || P > kMaxPos) return fail("cond_encode: sequence longer than the rope table (4096)");
     if (ws_bytes < cond_ws_bytes(B, R, P)) return fail("cond_encode: workspace too small");
@@ -658,6 +662,7 @@ int Engine::cond_encode(hipStream_t st, const float* ref, const int64_t* ref_len
 // ---------------------------------------------------------------------------------------------
 int Engine::modulation(hipStream_t st, const float* t_dev, int rows, float* sinb, float* t1, float* temb, float* e1,
                        float* semb, float* mod) {
+    ProfTag ptag("mod");
     HIPC(launch_time_sinusoid(t_dev, sinb, rows, st));
     HIPC(gemm_store(ops(sinb, rowmap_plain(256), time0_, rows), ACT_SILU,
                     store_to(t1, rowmap_plain(kHidden), rawp("time_embedding.mlp.0.bias")), 1, split_, st));
@@ -720,6 +725,7 @@ int Engine::denoise_core(hipStream_t st, const float* x_t, const uint8_t* mask, 
                          int mod_rstride, const float* k_ref, const float* v_ref, const uint8_t* ref_mask,
                          const float* k_text, const float* v_text, const uint8_t* ph_mask, const float* rope, int B,
                          int N, int R, int P, float* velocity, char* wsp) {
+    ProfTag ptag("dit");
     Bump bump(wsp);
     CoreWs w;
     w.plan(bump, B, N);
@@ -1070,7 +1076,9 @@ int Engine::codec_decode(hipStream_t st, const float* latents, int B, int T, flo
         RowMap om = rowmap_batched(C, Ti, (long)(pad + Ti) * C, (long)pad * C);
         HIPC(gemm_store(ops(w.lat, am, dec_.stem, B * Ti), ACT_NONE, store_to(x, om, dec_.stem_b), 1, split_, st));
     }
+    static const char* kDecTags[] = {"dec.s0", "dec.s1", "dec.s2", "dec.s3", "dec.s4", "dec.s5", "dec.s6", "dec.s7"};
     for (int i = 0; i < S; ++i) {
+        ProfTag ptag(kDecTags[i < 8 ? i : 7]);
         const CodecStageW& sg = dec_.stages[i];
         if (i > 0) {
             // ConvTranspose1d(k = 2r, stride r), causal trim: rows (x[t-1], x[t]) -> r output frames
@@ -1140,7 +1148,9 @@ int Engine::codec_encode(hipStream_t st, const float* audio, int B, int S_, floa
     HIPC(launch_zero_pad_frames(xn, B, Ti, C, pad, st));
     HIPC(launch_zero_pad_frames(w.nb, B, Ti, C, pad, st));
     HIPC(launch_stem_conv1(audio, enc_.stem_w_raw, enc_.stem_b, x, B, Ti, C, Kc, pad, st));
+    static const char* kEncTags[] = {"cenc.s0", "cenc.s1", "cenc.s2", "cenc.s3", "cenc.s4", "cenc.s5", "cenc.s6", "cenc.s7"};
     for (int i = 0; i < S; ++i) {
+        ProfTag ptag(kEncTags[i < 8 ? i : 7]);
         const CodecStageW& sg = enc_.stages[i];
         if (i > 0) {
             // Conv1d(k = 2r, stride r), causal left pad r: out[t] reads frames [(t-1) r, (t+1) r)

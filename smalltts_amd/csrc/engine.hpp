@@ -122,7 +122,7 @@ class Engine {
 
     const CodecSpecC& codec_spec() const { return cspec_; }
     // per-kernel HIP-event timing (bench.py); report = JSON array, valid after the stream is synchronised
-    void profile_enable(bool on);
+    void profile_enable(int mode);  // 0 off, 1 per-kernel, 2 per-kernel prefixed with the pipeline phase
     std::string profile_report();
     // single-kernel hooks for tests (W* are fp32 [N][K] on the device; split here, freed after the call)
     int test_gemm(hipStream_t st, const float* A, int lda, const float* W, const float* bias, int M, int N, int K,

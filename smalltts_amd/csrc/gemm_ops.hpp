@@ -37,9 +37,14 @@ static inline std::string gemm3_prof_name(const Gemm3Operands& g, bool paired, i
     static const char* tiles[] = {"64x128", "128x128", "64x64", "128x64", "128x32"};
     return std::string("gemm3<") + tiles[cfg] + ",s" + std::to_string(split) + "," + epi + ">";
 }
-static inline double gemm3_flops(const Gemm3Operands& g, int Z) { return 2.0 * g.M * (double)g.N * g.K * Z; }
+// split-K launches (ksplit_tiles > 0) use blockIdx.z for K slices of ONE product: the work is counted once
+static inline double gemm3_flops(const Gemm3Operands& g, int Z) {
+    return 2.0 * g.M * (double)g.N * g.K * (g.ksplit_tiles ? 1 : Z);
+}
 static inline double gemm3_bytes(const Gemm3Operands& g, int Z, int split, double c_bytes_per_out, bool w_shared = false) {
     const double e = split == 3 ? 4.0 : 2.0;
+    if (g.ksplit_tiles)  // operands once, Z fp32 partial outputs
+        return (double)g.M * g.K * e + (double)g.N * g.K * e + Z * (double)g.M * g.N * c_bytes_per_out;
     return Z * ((double)g.M * g.K * e + (double)g.M * g.N * c_bytes_per_out) + (double)g.N * g.K * e * (w_shared ? 1 : Z);
 }
 hipError_t gemm3_store(const Gemm3Operands& g, int act, const EpiStore<ACT_NONE>& p, int Z, int split, hipStream_t st, int cfg = -1);

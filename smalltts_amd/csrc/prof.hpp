@@ -7,6 +7,8 @@
 #include <string>
 #include <vector>
 
+extern thread_local const char* g_prof_tag;
+
 struct ProfAgg {
     long launches = 0;
     double ms = 0, flops = 0, bytes = 0;
@@ -17,7 +19,8 @@ class Profiler {
     ~Profiler() { reset(); }
     void begin(hipStream_t st, const std::string& name, double flops, double bytes) {
         Rec r;
-        r.name = name; r.flops = flops; r.bytes = bytes;
+        r.name = (g_prof_tag && *g_prof_tag) ? std::string(g_prof_tag) + "/" + name : name;
+        r.flops = flops; r.bytes = bytes;
         (void)hipEventCreate(&r.a);
         (void)hipEventCreate(&r.b);
         (void)hipEventRecord(r.a, st);
@@ -49,6 +52,12 @@ class Profiler {
 };
 
 extern thread_local Profiler* g_prof;  // set by Engine while profiling is enabled
+extern thread_local const char* g_prof_tag;  // non-null in tagged mode: pipeline phase prefixed to every kernel name
+struct ProfTag {  // scoped phase label ("enc", "dit", "dec.s3" ...); no effect unless tagged mode is on
+    const char* prev;
+    explicit ProfTag(const char* t) : prev(g_prof_tag) { if (g_prof_tag) g_prof_tag = t; }
+    ~ProfTag() { if (g_prof_tag) g_prof_tag = prev; }
+};
 
 struct ProfScope {
     hipStream_t st;

@@ -247,8 +247,9 @@ class HipEngine:
         self._ck(self.lib.smtts_randn(self.h, self._stream(), _p(out), n, C.c_uint64(seed), C.c_uint64(stream_id)), "randn")
         return out
 
-    def profile(self, on: bool):
-        self._ck(self.lib.smtts_profile_enable(self.h, int(on)), "profile_enable")
+    def profile(self, on, tagged: bool = False):
+        """on: False/True; tagged=True prefixes kernel names with the pipeline phase (enc, mod, dit, dec.s<i> ...)."""
+        self._ck(self.lib.smtts_profile_enable(self.h, (2 if tagged else 1) if on else 0), "profile_enable")
 
     def profile_report(self):
         import json
