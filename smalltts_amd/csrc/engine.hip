@@ -31,7 +31,12 @@ thread_local Profiler* g_prof = nullptr;
 thread_local const char* g_prof_tag = nullptr;
 int g_gemm_force_v1 = 1;  // fp32-A GEMMs (cold paths) use the register-staged v1 kernel; 0 routes them to the v2 DMA kernel
 
-Engine::Engine(int device) : device_(device) {}
+Engine::Engine(int device) : device_(device) {
+    const char* s = getenv("SMTTS_SINGLE_STREAM");
+    if (s && *s == '1') dual_stream_ = false;
+    if ((s = getenv("SMTTS_KSPLIT_OUT")) && atoi(s) >= 1 && atoi(s) <= kSplitK) ksplit_out_ = atoi(s);
+    if ((s = getenv("SMTTS_KSPLIT_FF2")) && atoi(s) >= 1 && atoi(s) <= kSplitK) ksplit_ff2_ = atoi(s);
+}
 
 void Engine::profile_enable(int mode) {
     const bool on = mode != 0;
@@ -61,6 +66,9 @@ std::string Engine::profile_report() {
 Engine::~Engine() {
     if (g_prof == &prof_) g_prof = nullptr;
     (void)hipSetDevice(device_);
+    if (aux_) (void)hipStreamDestroy(aux_);
+    if (ev_fork_) (void)hipEventDestroy(ev_fork_);
+    if (ev_join_) (void)hipEventDestroy(ev_join_);
     for (void* p : allocs_) (void)hipFree(p);
 }
 
@@ -535,8 +543,14 @@ static inline SplitBuf take_split(T& bump, size_t elems) {
 // Split-K residual GEMM for the small-M DiT projections (N = 960 gives only 150 tiles): the K range is cut into
 // `splits` slices (grid.z), each writes an fp32 partial, and one fused kernel reduces them in a fixed order and
 // applies bias / tanh-gate / row mask / residual add -> deterministic, unlike atomics.
+struct NextLN {  // optional: the AdaLN that follows the residual, fused into the split-K reduction kernel
+    const float* shift = nullptr;
+    const float* scale = nullptr;
+    bf16_t* yhi = nullptr;
+    bf16_t* ylo = nullptr;
+};
 static hipError_t gemm3_resid_splitk(const Gemm3Operands& g0, const EpiResid<0>& r, float* partial, int splits, int split,
-                                     hipStream_t st) {
+                                     hipStream_t st, const NextLN& ln = NextLN()) {
     Gemm3Operands g = g0;
     const int nk = g.K / 64;
     g.ksplit_tiles = (nk + splits - 1) / splits;
@@ -544,6 +558,9 @@ static hipError_t gemm3_resid_splitk(const Gemm3Operands& g0, const EpiResid<0>&
     EpiStore<ACT_NONE> e{partial, rowmap_plain(g.N), (long)g.M * g.N, nullptr, 0, 1.f, nullptr, nullptr, nullptr};
     hipError_t err = gemm3_store(g, ACT_NONE, e, used, split, st, G3_64x64);
     if (err != hipSuccess) return err;
+    if (ln.shift)
+        return launch_splitk_resid_ln(partial, used, r.x, r.bias, r.gate, r.gld, r.grow0, r.grstride, r.rows_per_batch,
+                                      r.rowmask, g.M, g.N, 1e-6f, ln.shift, ln.scale, ln.yhi, ln.ylo, st);
     return launch_splitk_resid(partial, used, r.x, r.bias, r.gate, r.gld, r.grow0, r.grstride, r.rows_per_batch, r.rowmask,
                                g.M, g.N, st);
 }
@@ -601,10 +618,21 @@ int Engine::run_encoder(hipStream_t st, const EncoderW& e, void* wsv, int B, int
 // ---------------------------------------------------------------------------------------------
 size_t Engine::cond_ws_bytes(int B, int R, int P) const {
     Bump b(nullptr);
-    EncWs w;
-    int Mx = B * (R > P ? R : P);
-    w.plan(b, Mx > 0 ? Mx : 1);
+    EncWs ws, wt;  // the style and the text encoder run concurrently: one workspace each
+    ws.plan(b, B * R > 0 ? B * R : 1);
+    wt.plan(b, B * P > 0 ? B * P : 1);
     return b.off + 256;
+}
+
+// Side stream for the text-encoder half of cond_encode: forked from / joined into the caller's stream with
+// events, so the caller still sees a single-stream operator.  Both encoders are tiny-M launch chains (120 / 240
+// rows) that each fill a fraction of the chip; run side by side they overlap almost completely.
+int Engine::ensure_aux() {
+    if (aux_) return 0;
+    HIPC(hipStreamCreateWithFlags(&aux_, hipStreamNonBlocking));
+    HIPC(hipEventCreateWithFlags(&ev_fork_, hipEventDisableTiming));
+    HIPC(hipEventCreateWithFlags(&ev_join_, hipEventDisableTiming));
+    return 0;
 }
 
 int Engine::cond_encode(hipStream_t st, const float* ref, const int64_t* ref_len, const int64_t* ids,
@@ -616,10 +644,34 @@ int Engine::cond_encode(hipStream_t st, const float* ref, const int64_t* ref_len
     if (ws_bytes < cond_ws_bytes(B, R, P)) return fail("cond_encode: workspace too small");
     HIPC(hipSetDevice(device_));
     Bump bump(ws);
-    EncWs w;
-    w.plan(bump, B * (R > P ? R : P) > 0 ? B * (R > P ? R : P) : 1);
+    EncWs w, wt;
+    w.plan(bump, B * R > 0 ? B * R : 1);
+    wt.plan(bump, B * P > 0 ? B * P : 1);
     const RowMap r512 = rowmap_plain(512), rh = rowmap_plain(kHidden);
+    const bool fork = dual_stream_ && R > 0 && P > 0;
+    hipStream_t stt = st;  // stream of the text half
+    if (fork) {
+        if (ensure_aux()) return 1;
+        HIPC(hipEventRecord(ev_fork_, st));  // inputs produced on the caller's stream are visible to the side stream
+        HIPC(hipStreamWaitEvent(aux_, ev_fork_, 0));
+        stt = aux_;
+    }
 
+    // ---- E2 text encoder (phonemes.py:200-207) + phoneme_proj (dit.py:293-298) ---------------
+    if (P > 0) {
+        const int M = B * P;
+        HIPC(launch_embedding(ids, rawp("phoneme_embedding.text_embedding.weight"), wt.x, M, 512, 198, stt));
+        if (run_encoder(stt, text_, &wt, B, P, ph_mask)) return 1;
+        HIPC(launch_rmsnorm(wt.x, r512, nullptr, wt.y.hi, wt.y.lo, r512, M, 512, text_.eps, text_.final_norm, stt));
+        float* mem = mem_out ? mem_out : wt.seq;
+        HIPC(gemm3_store(ops3(wt.y, r512, phproj_, M), ACT_NONE,
+                         store_to(mem, rh, rawp("dit.phoneme_proj.bias"), 1.f, ph_mask), 1, split_, stt));
+        HIPC(launch_to_split(mem, rh, wt.seqs.hi, wt.seqs.lo, rh, M, kHidden, stt));
+        EpiKV kv{k_text, v_text, kvtext_b_, B, kHeads, kDh, P};
+        HIPC(gemm3_kv(ops3(wt.seqs, rh, kvtext_, M), kv, split_, stt));
+        HIPC(launch_headnorm(k_text, kBlocks, B, kHeads, P, kDh, 1e-6f, knc_, stt));
+    }
+    if (fork) HIPC(hipEventRecord(ev_join_, aux_));
     // ---- E1 style encoder (style.py:144-174) -------------------------------------------------
     if (R > 0) {
         const int M = B * R;
@@ -637,20 +689,7 @@ int Engine::cond_encode(hipStream_t st, const float* ref, const int64_t* ref_len
         HIPC(gemm3_kv(ops3(w.seqs, rh, kvref_, M), kv, split_, st));
         HIPC(launch_headnorm(k_ref, kBlocks, B, kHeads, R, kDh, 1e-6f, knc_, st));
     }
-    // ---- E2 text encoder (phonemes.py:200-207) + phoneme_proj (dit.py:293-298) ---------------
-    if (P > 0) {
-        const int M = B * P;
-        HIPC(launch_embedding(ids, rawp("phoneme_embedding.text_embedding.weight"), w.x, M, 512, 198, st));
-        if (run_encoder(st, text_, &w, B, P, ph_mask)) return 1;
-        HIPC(launch_rmsnorm(w.x, r512, nullptr, w.y.hi, w.y.lo, r512, M, 512, text_.eps, text_.final_norm, st));
-        float* mem = mem_out ? mem_out : w.seq;
-        HIPC(gemm3_store(ops3(w.y, r512, phproj_, M), ACT_NONE,
-                         store_to(mem, rh, rawp("dit.phoneme_proj.bias"), 1.f, ph_mask), 1, split_, st));
-        HIPC(launch_to_split(mem, rh, w.seqs.hi, w.seqs.lo, rh, M, kHidden, st));
-        EpiKV kv{k_text, v_text, kvtext_b_, B, kHeads, kDh, P};
-        HIPC(gemm3_kv(ops3(w.seqs, rh, kvtext_, M), kv, split_, st));
-        HIPC(launch_headnorm(k_text, kBlocks, B, kHeads, P, kDh, 1e-6f, knc_, st));
-    }
+    if (fork) HIPC(hipStreamWaitEvent(st, ev_join_, 0));  // join: everything after cond_encode sees both halves
     return 0;
 }
 
@@ -765,13 +804,14 @@ int Engine::denoise_core(hipStream_t st, const float* x_t, const uint8_t* mask, 
         rc = rope_tmp_cos_;
         rs = rope_tmp_sin_;
     }
+    // The AdaLN in front of each GEMM is fused into the kernel that produced the residual stream it normalises
+    // (split-K reduction + gated residual + LayerNorm-modulate in one pass); only the very first one runs alone.
+    HIPC(launch_ln_modulate(w.x, nullptr, w.y.hi, w.y.lo, M, kHidden, 1e-6f, mod + 0 * kHidden, mod + 1 * kHidden, kModLd,
+                            mod_row0, mod_rstride, N, st));
     for (int l = 0; l < kBlocks; ++l) {
         const DitBlockW& b = blocks_[l];
         const float* m = mod + (long)l * kModPerBlock;
-        // D5 AdaLN-Zero (dit.py:19-25)
-        HIPC(launch_ln_modulate(w.x, nullptr, w.y.hi, w.y.lo, M, kHidden, 1e-6f, m + 0 * kHidden, m + 1 * kHidden, kModLd,
-                                mod_row0, mod_rstride, N, st));
-        // D6 joint attention (dit.py:95-135)
+        // D5 AdaLN-Zero (dit.py:19-25) already in w.y; D6 joint attention (dit.py:95-135)
         HIPC(gemm3_store(ops3(w.y, rh, b.qkvg, M), ACT_NONE, store_to(w.qkvg, rowmap_plain(4 * kHidden), b.b_qkvg), 1,
                          split_, st));
         AttnArgs a{};
@@ -788,21 +828,34 @@ int Engine::denoise_core(hipStream_t st, const float* x_t, const uint8_t* mask, 
         a.prenormed = 1;
         HIPC(launch_qk_prep(a, st));
         HIPC(attn_mfma_ ? launch_attention_mfma(a, st) : launch_attention(a, st));
-        // to_out + mask + gated residual (dit.py:117-118,198)
+        // to_out + mask + gated residual (dit.py:117-118,198), then the MLP AdaLN (dit.py:199)
         EpiResid<0> r1{w.x, rh, nullptr, m + 2 * kHidden, kModLd, mod_row0, mod_rstride, N, mask};
-        HIPC(gemm3_resid_splitk(ops3(w.o, rh, b.out, M), r1, w.part, kSplitK, split_, st));
+        NextLN ln1{m + 3 * kHidden, m + 4 * kHidden, w.y.hi, w.y.lo};
+        if (ksplit_out_ > 1) {
+            HIPC(gemm3_resid_splitk(ops3(w.o, rh, b.out, M), r1, w.part, ksplit_out_, split_, st, ln1));
+        } else {
+            HIPC(gemm3_resid(ops3(w.o, rh, b.out, M), 1, r1, split_, st));
+            HIPC(launch_ln_modulate(w.x, nullptr, w.y.hi, w.y.lo, M, kHidden, 1e-6f, ln1.shift, ln1.scale, kModLd, mod_row0,
+                                    mod_rstride, N, st));
+        }
         // D7 feed-forward (dit.py:199-201)
-        HIPC(launch_ln_modulate(w.x, nullptr, w.y.hi, w.y.lo, M, kHidden, 1e-6f, m + 3 * kHidden, m + 4 * kHidden, kModLd,
-                                mod_row0, mod_rstride, N, st));
         EpiSwiGLU sw{nullptr, kFFp, b.b1, b.b3, w.ffh.hi, w.ffh.lo};
         HIPC(gemm3_swiglu(ops3(w.y, rh, b.ff13, M), sw, split_, st));
+        // w2 + gated residual, then the next block's attention AdaLN — or D8's final AdaLN (chunk order scale, shift:
+        // dit.py:37) after the last block
         EpiResid<0> r2{w.x, rh, b.b2, m + 5 * kHidden, kModLd, mod_row0, mod_rstride, N, nullptr};
-        HIPC(gemm3_resid_splitk(ops3(w.ffh, rowmap_plain(kFFp), b.ff2, M), r2, w.part, kSplitK, split_, st));
+        const float* mn = m + kModPerBlock;  // next block's modulation (or the final norm's [scale | shift])
+        NextLN ln2 = l + 1 < kBlocks ? NextLN{mn + 0 * kHidden, mn + 1 * kHidden, w.y.hi, w.y.lo}
+                                     : NextLN{mn + kHidden, mn, w.y.hi, w.y.lo};
+        if (ksplit_ff2_ > 1) {
+            HIPC(gemm3_resid_splitk(ops3(w.ffh, rowmap_plain(kFFp), b.ff2, M), r2, w.part, ksplit_ff2_, split_, st, ln2));
+        } else {
+            HIPC(gemm3_resid(ops3(w.ffh, rowmap_plain(kFFp), b.ff2, M), 1, r2, split_, st));
+            HIPC(launch_ln_modulate(w.x, nullptr, w.y.hi, w.y.lo, M, kHidden, 1e-6f, ln2.shift, ln2.scale, kModLd, mod_row0,
+                                    mod_rstride, N, st));
+        }
     }
-    // D8 final AdaLN (chunk order scale, shift: dit.py:37) + velocity head (model.py:100)
-    const float* mf = mod + (long)kBlocks * kModPerBlock;
-    HIPC(launch_ln_modulate(w.x, nullptr, w.y.hi, w.y.lo, M, kHidden, 1e-6f, mf + kHidden, mf, kModLd, mod_row0,
-                            mod_rstride, N, st));
+    // velocity head (model.py:100) on the final AdaLN output
     HIPC(gemm3_store(ops3(w.y, rh, velocity_, M), ACT_NONE, store_to(velocity, rowmap_plain(kLatent), rawp("velocity.bias")),
                      1, split_, st));
     return 0;

@@ -168,6 +168,11 @@ class Engine {
     std::vector<void*> allocs_;
     int split_ = 3;
     bool fused_ffn_ = true;  // test hook: smtts_test_set_fused_ffn
+    int ksplit_out_ = 3, ksplit_ff2_ = 3;  // (<= kSplitK; 150 tiles x 3 = 450 workgroups = one round at 2 per CU) split-K factors of the two N = 960 DiT projections (1 = fused epilogue)
+    bool dual_stream_ = true;  // cond_encode: text encoder on a side stream (SMTTS_SINGLE_STREAM=1 turns it off)
+    hipStream_t aux_ = nullptr;
+    hipEvent_t ev_fork_ = nullptr, ev_join_ = nullptr;
+    int ensure_aux();
     bool attn_mfma_ = true;  // matrix-core attention (attention_mfma.hip); false = fp32 VALU kernel (attention.hip)
     Profiler prof_;
     bool prof_on_ = false;

@@ -600,6 +600,93 @@ __global__ __launch_bounds__(256) void splitk_resid_kernel(const float* __restri
     xv.x += g.x * acc.x; xv.y += g.y * acc.y; xv.z += g.z * acc.z; xv.w += g.w * acc.w;
     reinterpret_cast<float4*>(x)[i] = xv;
 }
+// splitk_resid followed by the NEXT AdaLN (ln_modulate) in one pass over the row: one wave per row, the updated
+// residual row stays in registers for the LayerNorm.  Same arithmetic order as the two separate kernels.
+template <int NV4>
+__global__ __launch_bounds__(256) void splitk_resid_ln_kernel(const float* __restrict__ part, int S, float* __restrict__ x,
+                                                              const float* __restrict__ bias, const float* __restrict__ gate,
+                                                              long gld, int grow0, int grstride, int rpb,
+                                                              const uint8_t* __restrict__ rowmask, int M, int C, float eps,
+                                                              const float* __restrict__ shift, const float* __restrict__ scale,
+                                                              bf16_t* __restrict__ yhi, bf16_t* __restrict__ ylo) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const int C4 = C >> 2;
+    const long MN4 = (long)M * C4;
+    const long mrow = (long)(grow0 + (row / rpb) * grstride) * gld;
+    float4* xr = reinterpret_cast<float4*>(x + (long)row * C);
+    const float4* sh4 = reinterpret_cast<const float4*>(shift + mrow);
+    const float4* sc4 = reinterpret_cast<const float4*>(scale + mrow);
+    // every load of the row is issued up front and unconditionally (the row-mask byte only selects afterwards), so
+    // the kernel is one memory round trip + two wave reductions
+    const uint8_t mk = rowmask ? rowmask[row] : (uint8_t)1;
+    float4 v[NV4], sh[NV4], sc[NV4], acc[NV4], g[NV4];
+#pragma unroll
+    for (int i = 0; i < NV4; ++i) {
+        const int c = lane + 64 * i;
+        const int cc = c < C4 ? c : 0;
+        v[i] = xr[cc];
+        sh[i] = sh4[cc];
+        sc[i] = sc4[cc];
+        const float4* pr = reinterpret_cast<const float4*>(part) + (long)row * C4 + cc;
+        acc[i] = pr[0];
+        for (int s = 1; s < S; ++s) {
+            const float4 p = pr[s * MN4];
+            acc[i].x += p.x; acc[i].y += p.y; acc[i].z += p.z; acc[i].w += p.w;
+        }
+        if (bias) {
+            const float4 b = reinterpret_cast<const float4*>(bias)[cc];
+            acc[i].x += b.x; acc[i].y += b.y; acc[i].z += b.z; acc[i].w += b.w;
+        }
+        g[i] = gate ? reinterpret_cast<const float4*>(gate + mrow)[cc] : make_float4(1.f, 1.f, 1.f, 1.f);
+    }
+    const bool live = mk != 0;
+#pragma unroll
+    for (int i = 0; i < NV4; ++i) {
+        const int c = lane + 64 * i;
+        if (live) {
+            v[i].x += g[i].x * acc[i].x; v[i].y += g[i].y * acc[i].y; v[i].z += g[i].z * acc[i].z; v[i].w += g[i].w * acc[i].w;
+            if (c < C4) xr[c] = v[i];
+        }
+        if (c >= C4) v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV4; ++i) s += v[i].x + v[i].y + v[i].z + v[i].w;
+    const float mean = wave_sum(s) / (float)C;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV4; ++i) {
+        if (lane + 64 * i < C4) {
+            const float a = v[i].x - mean, b = v[i].y - mean, c = v[i].z - mean, d = v[i].w - mean;
+            q += a * a + b * b + c * c + d * d;
+        }
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)C + eps);
+#pragma unroll
+    for (int i = 0; i < NV4; ++i) {
+        const int c = lane + 64 * i;
+        if (c < C4) {
+            const float4 o = make_float4((v[i].x - mean) * rstd * (1.0f + sc[i].x) + sh[i].x,
+                                         (v[i].y - mean) * rstd * (1.0f + sc[i].y) + sh[i].y,
+                                         (v[i].z - mean) * rstd * (1.0f + sc[i].z) + sh[i].z,
+                                         (v[i].w - mean) * rstd * (1.0f + sc[i].w) + sh[i].w);
+            store_split4(yhi, ylo, (long)row * C + c * 4, o);
+        }
+    }
+}
+
+hipError_t launch_splitk_resid_ln(const float* part, int S, float* x, const float* bias, const float* gate, long gld,
+                                  int grow0, int grstride, int rows_per_batch, const uint8_t* rowmask, int M, int N, float eps,
+                                  const float* shift, const float* scale, bf16_t* yhi, bf16_t* ylo, hipStream_t st) {
+    if (N > 1024 || N % 4 || gld % 4) return hipErrorInvalidValue;
+    ProfScope ps(st, "splitk_resid_ln", 1.0 * M * N * (S + 10), 4.0 * M * N * (S + 3));
+    hipLaunchKernelGGL(splitk_resid_ln_kernel<4>, dim3((M + 3) / 4), dim3(256), 0, st, part, S, x, bias, gate, gld, grow0,
+                       grstride, rows_per_batch, rowmask, M, N, eps, shift, scale, yhi, ylo);
+    LAUNCH_CHECK();
+}
+
 hipError_t launch_splitk_resid(const float* part, int S, float* x, const float* bias, const float* gate, long gld,
                                int grow0, int grstride, int rows_per_batch, const uint8_t* rowmask, int M, int N,
                                hipStream_t st) {

@@ -113,6 +113,10 @@ hipError_t launch_codec_ffn_fused(float* x, RowMap img, const float* norm_w, con
 
 // x[m][n] += mask(m) * gate[(grow0 + (m / rows_per_batch) * grstride) * gld + n] * (sum_s part[s][m][n] + bias[n])
 // (gate == null -> 1; fixed summation order s = 0..S-1).  Closes a split-K GEMM (see gemm3_resid_splitk).
+// split-K reduce + gated residual, then LayerNorm * (1 + scale) + shift of the updated row -> split bf16 (the next AdaLN)
+hipError_t launch_splitk_resid_ln(const float* part, int S, float* x, const float* bias, const float* gate, long gld,
+                                  int grow0, int grstride, int rows_per_batch, const uint8_t* rowmask, int M, int N, float eps,
+                                  const float* shift, const float* scale, bf16_t* yhi, bf16_t* ylo, hipStream_t st);
 hipError_t launch_splitk_resid(const float* part, int S, float* x, const float* bias, const float* gate, long gld,
                                int grow0, int grstride, int rows_per_batch, const uint8_t* rowmask, int M, int N,
                                hipStream_t st);
