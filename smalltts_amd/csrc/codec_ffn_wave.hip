@@ -1,0 +1,285 @@
+// Wave-autonomous fused codec FFN for the narrowest stages (C = 32, 64), gfx950:
+//     x += ffn_gamma * ( W2 . gelu( W1 . RMSNorm(x; g, eps) + b1 ) + b2 )
+//
+// At C <= 64 both weight matrices fit in LDS as split bf16 (16 C^2 bytes: 16 / 64 ... 128 KiB), so nothing is
+// streamed: a persistent workgroup loads them once and then every WAVE runs on its own — 32 frames at a time, no
+// workgroup barrier, no LDS traffic for activations:
+//   H^T[hidden][frame] = W1 . N^T    A = W1 fragments (LDS), B = the wave's normalised frames, built in registers
+//                                    straight from global x (lane = frame, 8 consecutive channels per k16 half);
+//   GELU on the accumulators; because the product is transposed every lane owns ONE frame column, and the
+//   accumulator rows it holds are exactly what v_permlane32_swap turns into the B fragments of the second product
+//   (same trick as attention_mfma.hip), so the 4C-wide hidden never leaves the register file;
+//   Out^T[channel][frame] += W2 . H^T   A = W2 fragments (LDS), one 32-row hidden tile at a time.
+// The waves of a CU drift apart, so one wave's GELU (VALU) overlaps another's MFMAs without any scheduling effort.
+// Replaces codec_ffn_kernel<64> (C = 64 and the zero-padded C = 32 case, which wasted half of every MFMA).
+#include "gemm3.hpp"
+#include "kernels.hpp"
+#include "prof.hpp"
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// exact-erf GELU (same A&S 7.1.26 form as gelu_f) on two values at once: the polynomial runs on v_pk_* ops
+__device__ __forceinline__ f32x2 gelu2(f32x2 x) {
+    const f32x2 z = __builtin_elementwise_abs(x) * 0.70710678118654752f;
+    const f32x2 d = 1.0f + 0.3275911f * z;
+    f32x2 t;
+    t.x = fast_rcp(d.x);
+    t.y = fast_rcp(d.y);
+    const f32x2 poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+    const f32x2 ea = (z * z) * -1.4426950408889634f;  // exp(-z^2) = exp2(-z^2 log2 e)
+    f32x2 e;
+    e.x = __builtin_amdgcn_exp2f(ea.x);
+    e.y = __builtin_amdgcn_exp2f(ea.y);
+    const f32x2 q = poly * e;  // erfc(z)
+    f32x2 s;
+    s.x = x.x > 0.f ? 2.0f - q.x : q.x;
+    s.y = x.y > 0.f ? 2.0f - q.y : q.y;
+    return (0.5f * x) * s;
+}
+
+struct FfnWaveArgs {
+    float* x;
+    RowMap img;            // row m of x
+    const float* norm_w;   // [C]
+    const bf16_t* w1hi;    // [F][ld1]  (first C columns used)
+    const bf16_t* w1lo;
+    int ld1;
+    const float* b1;       // [F]
+    const bf16_t* w2hi;    // [>= C][F]
+    const bf16_t* w2lo;
+    const float* b2;       // [C]
+    const float* gamma;    // [C]
+    int M;
+    float eps;
+};
+
+template <int C, int SPLIT>
+__global__ __launch_bounds__(512) void codec_ffn_wave_kernel(FfnWaveArgs a) {
+    constexpr int F = 4 * C;
+    constexpr int KK1 = C / 16;            // k16 steps of the first product
+    constexpr int NT1 = F / 32;            // 32-row hidden tiles
+    constexpr int NOT = C / 32;            // 32-row output (channel) tiles
+    constexpr int RB1 = 2 * C;             // bytes per W1 row image (64 or 128)
+    constexpr int RB2 = 2 * F;             // bytes per W2 row image (256 or 512)
+    constexpr int NARR = SPLIT == 3 ? 2 : 1;
+    constexpr int W_ARR = F * RB1;         // = C * RB2 = 8 C^2
+    constexpr int OFF_W1 = 0, OFF_W2 = NARR * W_ARR, OFF_V = 2 * NARR * W_ARR;  // then b1[F] b2[C] gamma[C] norm_w[C] (fp32)
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fr = lane & 31, fh = lane >> 5;
+
+    auto swz1 = [](int r) { return RB1 == 128 ? ((r >> 1) & 7) : ((r >> 2) & 3); };
+    // ---- one-time: weight images into LDS (16-B chunks XOR-swizzled so every fragment read is conflict free) ----
+    for (int i = tid; i < F * (C / 8); i += 512) {
+        const int r = i / (C / 8), ch = i % (C / 8);
+        const int dst = r * RB1 + ((ch ^ swz1(r)) << 4);
+        *reinterpret_cast<uint4*>(smem + OFF_W1 + dst) = *reinterpret_cast<const uint4*>(a.w1hi + (long)r * a.ld1 + ch * 8);
+        if (SPLIT == 3)
+            *reinterpret_cast<uint4*>(smem + OFF_W1 + W_ARR + dst) = *reinterpret_cast<const uint4*>(a.w1lo + (long)r * a.ld1 + ch * 8);
+    }
+    for (int i = tid; i < C * (F / 8); i += 512) {
+        const int r = i / (F / 8), ch = i % (F / 8);
+        const int dst = r * RB2 + (((ch & ~15) | ((ch ^ r) & 15)) << 4);
+        *reinterpret_cast<uint4*>(smem + OFF_W2 + dst) = *reinterpret_cast<const uint4*>(a.w2hi + (long)r * F + ch * 8);
+        if (SPLIT == 3)
+            *reinterpret_cast<uint4*>(smem + OFF_W2 + W_ARR + dst) = *reinterpret_cast<const uint4*>(a.w2lo + (long)r * F + ch * 8);
+    }
+    float* vb1 = reinterpret_cast<float*>(smem + OFF_V);
+    float* vb2 = vb1 + F;
+    float* vga = vb2 + C;
+    float* vnw = vga + C;
+    for (int i = tid; i < F; i += 512) vb1[i] = a.b1[i];
+    for (int i = tid; i < C; i += 512) { vb2[i] = a.b2[i]; vga[i] = a.gamma[i]; vnw[i] = a.norm_w[i]; }
+    __syncthreads();
+
+    // fragment byte offsets (constant for the kernel)
+    int w1_off[KK1];
+#pragma unroll
+    for (int kk = 0; kk < KK1; ++kk) w1_off[kk] = fr * RB1 + (((2 * kk + fh) ^ swz1(fr)) << 4);  // + t * 32 * RB1 (swz unchanged)
+    // W2 fragment: row 32*ot + fr, chunk c = 2*g + fh (g = global k16 step) -> ((c & ~15) | ((c ^ row) & 15)) << 4
+
+    const int ntiles = (a.M + 31) / 32;
+    const int wg = blockIdx.x * 8 + wave, nwg = gridDim.x * 8;
+
+    // channel of element e (0..7) of k16 step kk in this lane's B fragment: 16 kk + 8 fh + e
+    float4 xa[KK1][2];  // raw x of the tile being prefetched / computed
+    auto load_tile = [&](int wt) {
+        int m = wt * 32 + fr;
+        m = m < a.M ? m : a.M - 1;
+        const float* xr = a.x + a.img.at(m);
+#pragma unroll
+        for (int kk = 0; kk < KK1; ++kk) {
+            xa[kk][0] = *reinterpret_cast<const float4*>(xr + 16 * kk + 8 * fh);
+            xa[kk][1] = *reinterpret_cast<const float4*>(xr + 16 * kk + 8 * fh + 4);
+        }
+    };
+    if (wg < ntiles) load_tile(wg);
+
+#pragma unroll 1
+    for (int wt = wg; wt < ntiles; wt += nwg) {
+        // ---- RMSNorm of the lane's frame (channels split over the two lane halves) -> split bf16 B fragments ----
+        float ss = 0.f;
+#pragma unroll
+        for (int kk = 0; kk < KK1; ++kk)
+#pragma unroll
+            for (int h2 = 0; h2 < 2; ++h2)
+                ss += xa[kk][h2].x * xa[kk][h2].x + xa[kk][h2].y * xa[kk][h2].y + xa[kk][h2].z * xa[kk][h2].z + xa[kk][h2].w * xa[kk][h2].w;
+        ss += __shfl_xor(ss, 32, 64);
+        const float rstd = 1.0f / sqrtf(ss / (float)C + a.eps);
+        bf16x8 nh[KK1], nl[KK1];
+#pragma unroll
+        for (int kk = 0; kk < KK1; ++kk) {
+            const float4 g0 = *reinterpret_cast<const float4*>(vnw + 16 * kk + 8 * fh);
+            const float4 g1 = *reinterpret_cast<const float4*>(vnw + 16 * kk + 8 * fh + 4);
+            const float v[8] = {xa[kk][0].x * rstd * g0.x, xa[kk][0].y * rstd * g0.y, xa[kk][0].z * rstd * g0.z, xa[kk][0].w * rstd * g0.w,
+                                xa[kk][1].x * rstd * g1.x, xa[kk][1].y * rstd * g1.y, xa[kk][1].z * rstd * g1.z, xa[kk][1].w * rstd * g1.w};
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                nh[kk][e] = (bf16_t)v[e];
+                nl[kk][e] = (bf16_t)(v[e] - (float)nh[kk][e]);
+            }
+        }
+        const int m_cur = wt * 32 + fr;
+        if (wt + nwg < ntiles) load_tile(wt + nwg);  // next tile's x arrives under this tile's MFMA / GELU work
+
+        floatx16 acc2[NOT];
+#pragma unroll
+        for (int ot = 0; ot < NOT; ++ot)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc2[ot][r] = 0.f;
+
+#pragma unroll 1
+        for (int t = 0; t < NT1; ++t) {  // not unrolled: keeps the weight-fragment reads of different tiles from piling up in VGPRs
+            // ---- H^T tile t: hidden rows 32 t .. +32, this wave's 32 frames -------------------------------------
+            floatx16 acc1;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc1[r] = 0.f;
+#pragma unroll
+            for (int kk = 0; kk < KK1; ++kk) {
+                const bf16x8 wh = *reinterpret_cast<const bf16x8*>(smem + OFF_W1 + t * 32 * RB1 + w1_off[kk]);
+                if (SPLIT == 3) {
+                    const bf16x8 wl = *reinterpret_cast<const bf16x8*>(smem + OFF_W1 + W_ARR + t * 32 * RB1 + w1_off[kk]);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl, nh[kk], acc1, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, nl[kk], acc1, 0, 0, 0);
+                }
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, nh[kk], acc1, 0, 0, 0);
+            }
+            // ---- bias + GELU in place: row(r) = hidden 32 t + (r & 3) + 8 (r >> 2) + 4 fh -----------------------
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 bv = *reinterpret_cast<const float4*>(vb1 + 32 * t + 8 * q + 4 * fh);
+                f32x2 u0, u1;
+                u0.x = acc1[4 * q + 0] + bv.x; u0.y = acc1[4 * q + 1] + bv.y;
+                u1.x = acc1[4 * q + 2] + bv.z; u1.y = acc1[4 * q + 3] + bv.w;
+                u0 = gelu2(u0);
+                u1 = gelu2(u1);
+                acc1[4 * q + 0] = u0.x; acc1[4 * q + 1] = u0.y; acc1[4 * q + 2] = u1.x; acc1[4 * q + 3] = u1.y;
+            }
+            // ---- Out^T += W2[:, hidden tile t] . H^T tile: two k16 steps ---------------------------------------------
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const int r0 = 8 * s;
+                unsigned xh[2], yh[2], xl[2], yl[2];
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const float pa = acc1[r0 + 2 * e], pb = acc1[r0 + 2 * e + 1];
+                    const float pc = acc1[r0 + 4 + 2 * e], pd = acc1[r0 + 4 + 2 * e + 1];
+                    const bf16_t ah = (bf16_t)pa, bh = (bf16_t)pb, ch = (bf16_t)pc, dh = (bf16_t)pd;
+                    const bf16_t al = (bf16_t)(pa - (float)ah), bl = (bf16_t)(pb - (float)bh);
+                    const bf16_t cl = (bf16_t)(pc - (float)ch), dl = (bf16_t)(pd - (float)dh);
+                    auto pk = [](bf16_t lo, bf16_t hi) {
+                        return (unsigned)__builtin_bit_cast(unsigned short, lo) | ((unsigned)__builtin_bit_cast(unsigned short, hi) << 16);
+                    };
+                    xh[e] = pk(ah, bh); yh[e] = pk(ch, dh);
+                    xl[e] = pk(al, bl); yl[e] = pk(cl, dl);
+                }
+                // lane half 0 needs hidden 0..7 of the step, half 1 hidden 8..15: swap upper half of X with lower half of Y
+                unsigned fhh[4], fll[4];
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    auto rh = __builtin_amdgcn_permlane32_swap(xh[e], yh[e], false, false);
+                    fhh[e] = rh[0]; fhh[2 + e] = rh[1];
+                    if (SPLIT == 3) {
+                        auto rl = __builtin_amdgcn_permlane32_swap(xl[e], yl[e], false, false);
+                        fll[e] = rl[0]; fll[2 + e] = rl[1];
+                    }
+                }
+                const bf16x8 ph = __builtin_bit_cast(bf16x8, *reinterpret_cast<uint4*>(fhh));
+                bf16x8 pl;
+                if (SPLIT == 3) pl = __builtin_bit_cast(bf16x8, *reinterpret_cast<uint4*>(fll));
+                const int c = 2 * (2 * t + s) + fh;  // 16-B chunk index along the hidden (k) axis of W2
+#pragma unroll
+                for (int ot = 0; ot < NOT; ++ot) {
+                    const int row = 32 * ot + fr;
+                    const int off = OFF_W2 + row * RB2 + (((c & ~15) | ((c ^ row) & 15)) << 4);
+                    const bf16x8 wh = *reinterpret_cast<const bf16x8*>(smem + off);
+                    if (SPLIT == 3) {
+                        const bf16x8 wl = *reinterpret_cast<const bf16x8*>(smem + off + W_ARR);
+                        acc2[ot] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl, ph, acc2[ot], 0, 0, 0);
+                        acc2[ot] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, pl, acc2[ot], 0, 0, 0);
+                    }
+                    acc2[ot] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, ph, acc2[ot], 0, 0, 0);
+                }
+            }
+        }
+        // ---- epilogue: x[frame][c] += gamma[c] (out + b2[c]); channel(r) = 32 ot + (r & 3) + 8 (r >> 2) + 4 fh -------
+        if (m_cur < a.M) {
+            float* xr = a.x + a.img.at(m_cur);
+            float4 xo[NOT][4];
+#pragma unroll
+            for (int ot = 0; ot < NOT; ++ot)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) xo[ot][q] = *reinterpret_cast<const float4*>(xr + 32 * ot + 8 * q + 4 * fh);
+#pragma unroll
+            for (int ot = 0; ot < NOT; ++ot)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int c0 = 32 * ot + 8 * q + 4 * fh;
+                    const float4 bv = *reinterpret_cast<const float4*>(vb2 + c0);
+                    const float4 gv = *reinterpret_cast<const float4*>(vga + c0);
+                    float4 o = xo[ot][q];
+                    o.x += gv.x * (acc2[ot][4 * q + 0] + bv.x);
+                    o.y += gv.y * (acc2[ot][4 * q + 1] + bv.y);
+                    o.z += gv.z * (acc2[ot][4 * q + 2] + bv.z);
+                    o.w += gv.w * (acc2[ot][4 * q + 3] + bv.w);
+                    *reinterpret_cast<float4*>(xr + c0) = o;
+                }
+        }
+    }
+}
+
+template <int C, int SPLIT>
+static hipError_t ffn_wave_go(const FfnWaveArgs& a, hipStream_t st) {
+    constexpr size_t lds = (size_t)(SPLIT == 3 ? 2 : 1) * 2 * (8 * C * C) + (size_t)(4 * C + 3 * C) * 4;
+    static_assert(lds <= 160 * 1024, "weights must fit LDS");
+    auto kern = codec_ffn_wave_kernel<C, SPLIT>;
+    static bool done = false;
+    static int cus = 256;
+    if (!done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0)
+            cus = n;
+        done = true;
+    }
+    const int ntiles = (a.M + 31) / 32;
+    const int per_cu = lds * 2 <= 160 * 1024 ? 2 : 1;  // persistent: as many workgroups as fit, each wave walks tiles
+    int grid = (ntiles + 7) / 8;
+    grid = grid < cus * per_cu ? grid : cus * per_cu;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, a);
+    return hipGetLastError();
+}
+
+// C in {32, 64}; w1 [F][ld1] (ld1 >= C, K possibly zero-padded), w2 [>= C][F]
+hipError_t launch_codec_ffn_wave(float* x, RowMap img, const float* norm_w, const bf16_t* w1hi, const bf16_t* w1lo, int ld1,
+                                 const float* b1, const bf16_t* w2hi, const bf16_t* w2lo, const float* b2, const float* gamma,
+                                 int M, int C, int F, float eps, int split, hipStream_t st) {
+    if (!(C == 32 || C == 64) || F != 4 * C || img.ld % 4 || img.off % 4 || ld1 % 8 || (img.rpb && img.bstride % 4)) return hipErrorInvalidValue;
+    if (M <= 0) return hipSuccess;
+    FfnWaveArgs a{x, img, norm_w, w1hi, w1lo, ld1, b1, w2hi, w2lo, b2, gamma, M, eps};
+    ProfScope ps(st, C == 64 ? "codec_ffn_wave<64>" : "codec_ffn_wave<32>", 4.0 * M * (double)C * F, 8.0 * M * C + 8.0 * (double)C * F);
+    if (C == 64) return split == 3 ? ffn_wave_go<64, 3>(a, st) : ffn_wave_go<64, 1>(a, st);
+    return split == 3 ? ffn_wave_go<32, 3>(a, st) : ffn_wave_go<32, 1>(a, st);
+}

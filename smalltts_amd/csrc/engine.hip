@@ -29,6 +29,7 @@ inline std::string sidx(const std::string& a, int i, const std::string& b) { ret
 
 thread_local Profiler* g_prof = nullptr;
 thread_local const char* g_prof_tag = nullptr;
+int g_codec_wave_ffn = 1;  // C <= 64 codec FFN: 1 = wave-autonomous kernel (codec_ffn_wave.hip), 0 = codec_ffn_kernel
 int g_gemm_force_v1 = 1;  // fp32-A GEMMs (cold paths) use the register-staged v1 kernel; 0 routes them to the v2 DMA kernel
 
 Engine::Engine(int device) : device_(device) {
@@ -1025,6 +1026,12 @@ int Engine::codec_block(hipStream_t st, const CodecBlockW& w, float** xp, float*
         HIPC(launch_dwconv_resid(x, nbuf, w.dw_w, w.dw_b, w.gamma, B, T, C, cspec_.kernel, pad, st));
     }
     // FFN: RMSNorm -> Linear 4x -> GELU -> Linear -> LayerScale residual
+    if (w.w1f.N && fused_ffn_ && g_codec_wave_ffn && (C == 32 || C == 64) && F == 4 * C) {
+        // narrowest stages: all weights LDS-resident, one wave per 32 frames, hidden stays in registers (codec_ffn_wave.hip)
+        HIPC(launch_codec_ffn_wave(x, img, w.ffn_norm_w, w.w1f.hi, w.w1f.lo, w.w1f.K, w.b1, w.w2f.hi, w.w2f.lo, w.b2,
+                                   w.ffn_gamma, M, C, F, cspec_.eps, split_, st));
+        return 0;
+    }
     if (w.w1f.N && fused_ffn_) {  // narrow stages: one fused kernel, hidden stays in LDS (codec_ffn.hip)
         HIPC(launch_codec_ffn_fused(x, img, w.ffn_norm_w, w.w1f.hi, w.w1f.lo, w.b1, w.w2f.hi, w.w2f.lo, w.b2, w.ffn_gamma, M,
                                     C, F, cspec_.eps, split_, st));

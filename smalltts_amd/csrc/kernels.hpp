@@ -107,6 +107,11 @@ hipError_t launch_zero_pad_frames(float* x, int B, int T, int C, int pad, hipStr
 
 // Fused codec FFN block for C in {32, 64, 128}: x += gamma * (W2 gelu(W1 rmsnorm(x) + b1) + b2), hidden kept in LDS.
 // w1 packed [F][CP], w2 packed [CP][F] with CP = max(C, 64) (zero padded).  (codec_ffn.hip)
+// C in {32, 64}: weights LDS-resident, wave-autonomous (codec_ffn_wave.hip); w1 [F][ld1], w2 [>= C][F]
+hipError_t launch_codec_ffn_wave(float* x, RowMap img, const float* norm_w, const bf16_t* w1hi, const bf16_t* w1lo, int ld1,
+                                 const float* b1, const bf16_t* w2hi, const bf16_t* w2lo, const float* b2, const float* gamma,
+                                 int M, int C, int F, float eps, int split, hipStream_t st);
+extern int g_codec_wave_ffn;
 hipError_t launch_codec_ffn_fused(float* x, RowMap img, const float* norm_w, const bf16_t* w1hi, const bf16_t* w1lo,
                                   const float* b1, const bf16_t* w2hi, const bf16_t* w2lo, const float* b2,
                                   const float* gamma, int M, int C, int F, float eps, int split, hipStream_t st);
