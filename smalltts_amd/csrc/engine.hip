@@ -1016,7 +1016,7 @@ int Engine::codec_block(hipStream_t st, const CodecBlockW& w, float** xp, float*
     const int F = cspec_.ffn_mult * C;
     const RowMap rc = rowmap_plain(C), rf = rowmap_plain(F);
     // mixer: RMSNorm -> causal depthwise conv -> LayerScale residual
-    if (C <= 256 && 256 % (C / 4) == 0 && fused_ffn_) {  // narrow stages: one out-of-place kernel, then swap images
+    if (C <= 256 && 256 % (C / 4) == 0 && cspec_.kernel <= 7 && fused_ffn_) {  // narrow stages: one out-of-place kernel, then swap images
         HIPC(launch_mixer_fused(x, *xaltp, w.norm_w, w.dw_w, w.dw_b, w.gamma, B, T, C, cspec_.kernel, pad, cspec_.eps, st));
         *xp = *xaltp;
         *xaltp = x;

@@ -714,12 +714,21 @@ __global__ __launch_bounds__(256) void mixer_fused_kernel(const float* __restric
     const int nfr = (T - t0 < TT ? T - t0 : TT) + H;             // frames staged (incl. halo)
     const long img0 = ((long)b * (pad + T) + pad + t0 - H) * C;  // first halo frame (inside the zero pad for t0 = 0)
     const int tid = threadIdx.x;
-    // phase 1: stage frames, per-frame sum of squares (C4 lanes cooperate on one frame)
+    // phase 1: stage frames, per-frame sum of squares (C4 lanes cooperate on one frame).  All global loads of the tile
+    // are issued before the first reduction / LDS store: one memory round trip per workgroup instead of one per pass.
     const int lpr = C4, fpp = 256 / lpr;
-    for (int f0 = 0; f0 < nfr; f0 += fpp) {
-        const int f = f0 + tid / lpr, c4 = tid % lpr;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (f < nfr) v = reinterpret_cast<const float4*>(xin + img0 + (long)f * C)[c4];
+    constexpr int NI = 10;  // (TT + H) * C4 <= 256 * NI for TT * C = 8192, H <= 6 (checked by the launcher)
+    float4 stg[NI];
+#pragma unroll
+    for (int it = 0; it < NI; ++it) {
+        const int f = it * fpp + tid / lpr, c4 = tid % lpr;
+        stg[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (f < nfr) stg[it] = reinterpret_cast<const float4*>(xin + img0 + (long)f * C)[c4];
+    }
+#pragma unroll
+    for (int it = 0; it < NI; ++it) {
+        const int f = it * fpp + tid / lpr, c4 = tid % lpr;
+        const float4 v = stg[it];
         float ss = v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
         for (int o = lpr >> 1; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
         if (f < nfr) {
@@ -727,21 +736,27 @@ __global__ __launch_bounds__(256) void mixer_fused_kernel(const float* __restric
             if (c4 == 0) rs[f] = 1.0f / sqrtf(ss / (float)C + eps);
         }
     }
+    // per-thread constants: 256 % C4 == 0, so a thread always works on the same 4 channels
+    const int c4 = tid % C4;
+    float4 wv[7];
+#pragma unroll
+    for (int k = 0; k < 7; ++k) wv[k] = k < K ? reinterpret_cast<const float4*>(w)[(long)k * C4 + c4] : make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4 g = reinterpret_cast<const float4*>(norm_w)[c4];
+    const float4 bb = reinterpret_cast<const float4*>(bias)[c4];
+    const float4 gm = reinterpret_cast<const float4*>(gamma)[c4];
     __syncthreads();
     // phase 2: the tile's output frames
     const int nout = nfr - H;
-    for (int i = tid; i < nout * C4; i += 256) {
-        const int t = i / C4, c4 = i % C4;
+    for (int t = tid / C4; t < nout; t += fpp) {
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int k = 0; k < K; ++k) {
-            const float r = rs[t + k];
-            const float4 xv = reinterpret_cast<const float4*>(xs + (size_t)(t + k) * C)[c4];
-            const float4 wv = reinterpret_cast<const float4*>(w)[(long)k * C4 + c4];
-            acc.x += wv.x * r * xv.x; acc.y += wv.y * r * xv.y; acc.z += wv.z * r * xv.z; acc.w += wv.w * r * xv.w;
+#pragma unroll
+        for (int k = 0; k < 7; ++k) {
+            if (k < K) {
+                const float r = rs[t + k];
+                const float4 xv = reinterpret_cast<const float4*>(xs + (size_t)(t + k) * C)[c4];
+                acc.x += wv[k].x * r * xv.x; acc.y += wv[k].y * r * xv.y; acc.z += wv[k].z * r * xv.z; acc.w += wv[k].w * r * xv.w;
+            }
         }
-        const float4 g = reinterpret_cast<const float4*>(norm_w)[c4];
-        const float4 bb = reinterpret_cast<const float4*>(bias)[c4];
-        const float4 gm = reinterpret_cast<const float4*>(gamma)[c4];
         float4 xv = reinterpret_cast<const float4*>(xs + (size_t)(t + H) * C)[c4];
         xv.x += gm.x * (g.x * acc.x + bb.x); xv.y += gm.y * (g.y * acc.y + bb.y);
         xv.z += gm.z * (g.z * acc.z + bb.z); xv.w += gm.w * (g.w * acc.w + bb.w);
@@ -750,9 +765,10 @@ __global__ __launch_bounds__(256) void mixer_fused_kernel(const float* __restric
 }
 hipError_t launch_mixer_fused(const float* xin, float* xout, const float* norm_w, const float* w, const float* bias,
                               const float* gamma, int B, int T, int C, int K, int pad, float eps, hipStream_t st) {
-    if (C % 4 || C > 256 || (256 % (C / 4)) || pad < K - 1 || xin == xout) return hipErrorInvalidValue;
+    if (C % 4 || C > 256 || (256 % (C / 4)) || pad < K - 1 || xin == xout || K > 7) return hipErrorInvalidValue;
     int TT = 8192 / C;
     if (TT < 8) TT = 8;
+    if ((long)(TT + K - 1) * (C / 4) > 2560) return hipErrorInvalidValue;  // staging registers of the kernel (NI = 10)
     const int tiles = (T + TT - 1) / TT;
     const size_t lds = ((size_t)(TT + K - 1) * C + (TT + K - 1)) * sizeof(float);
     if ((long)B * tiles == 0) return hipSuccess;
