@@ -139,6 +139,7 @@ int smtts_test_set_fused_ffn(smtts_handle h, int on) {
     E.set_fused_ffn((on & 1) != 0);
     g_ffn_bm128 = (on & 2) ? 0 : 1;
     g_codec_wave_ffn = (on & 4) ? 0 : 1;
+    g_codec_stream_ffn = (on & 8) ? 0 : 1;
     return 0;
 }
 int smtts_test_set_attention_mfma(smtts_handle h, int on) { E.set_attn_mfma(on != 0); return 0; }

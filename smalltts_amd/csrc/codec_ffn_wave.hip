@@ -155,16 +155,36 @@ __global__ __launch_bounds__(512) void codec_ffn_wave_kernel(FfnWaveArgs a) {
             floatx16 acc1;
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc1[r] = 0.f;
+            // fragment reads run one k16 step ahead of the MFMAs that consume them (the compiler keeps this order and counts
+            // lgkmcnt, so the LDS latency of step kk+1 hides under the three MFMAs of step kk)
+            bf16x8 wh = *reinterpret_cast<const bf16x8*>(smem + OFF_W1 + t * 32 * RB1 + w1_off[0]), wl;
+            if (SPLIT == 3) wl = *reinterpret_cast<const bf16x8*>(smem + OFF_W1 + W_ARR + t * 32 * RB1 + w1_off[0]);
 #pragma unroll
             for (int kk = 0; kk < KK1; ++kk) {
-                const bf16x8 wh = *reinterpret_cast<const bf16x8*>(smem + OFF_W1 + t * 32 * RB1 + w1_off[kk]);
+                bf16x8 whn, wln;
+                if (kk + 1 < KK1) {
+                    whn = *reinterpret_cast<const bf16x8*>(smem + OFF_W1 + t * 32 * RB1 + w1_off[kk + 1]);
+                    if (SPLIT == 3) wln = *reinterpret_cast<const bf16x8*>(smem + OFF_W1 + W_ARR + t * 32 * RB1 + w1_off[kk + 1]);
+                }
+                __builtin_amdgcn_sched_barrier(0);  // keep the reads above the MFMAs below
                 if (SPLIT == 3) {
-                    const bf16x8 wl = *reinterpret_cast<const bf16x8*>(smem + OFF_W1 + W_ARR + t * 32 * RB1 + w1_off[kk]);
                     acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl, nh[kk], acc1, 0, 0, 0);
                     acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, nl[kk], acc1, 0, 0, 0);
                 }
                 acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, nh[kk], acc1, 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (kk + 1 < KK1) { wh = whn; if (SPLIT == 3) wl = wln; }
             }
+            // W2 fragments are read one (k16 step, channel tile) pair ahead as well; the first pair is requested before the
+            // GELU so it lands under it
+            auto w2_addr = [&](int ot, int s) {
+                const int c = 2 * (2 * t + s) + fh, row = 32 * ot + fr;  // 16-B chunk along the hidden (k) axis of W2
+                return smem + OFF_W2 + row * RB2 + (((c & ~15) | ((c ^ row) & 15)) << 4);
+            };
+            constexpr int W2LO = W_ARR;
+            bf16x8 vh = *reinterpret_cast<const bf16x8*>(w2_addr(0, 0)), vl;
+            if (SPLIT == 3) vl = *reinterpret_cast<const bf16x8*>(w2_addr(0, 0) + W2LO);
+            __builtin_amdgcn_sched_barrier(0);
             // ---- bias + GELU in place: row(r) = hidden 32 t + (r & 3) + 8 (r >> 2) + 4 fh -----------------------
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
@@ -208,18 +228,23 @@ __global__ __launch_bounds__(512) void codec_ffn_wave_kernel(FfnWaveArgs a) {
                 const bf16x8 ph = __builtin_bit_cast(bf16x8, *reinterpret_cast<uint4*>(fhh));
                 bf16x8 pl;
                 if (SPLIT == 3) pl = __builtin_bit_cast(bf16x8, *reinterpret_cast<uint4*>(fll));
-                const int c = 2 * (2 * t + s) + fh;  // 16-B chunk index along the hidden (k) axis of W2
 #pragma unroll
                 for (int ot = 0; ot < NOT; ++ot) {
-                    const int row = 32 * ot + fr;
-                    const int off = OFF_W2 + row * RB2 + (((c & ~15) | ((c ^ row) & 15)) << 4);
-                    const bf16x8 wh = *reinterpret_cast<const bf16x8*>(smem + off);
-                    if (SPLIT == 3) {
-                        const bf16x8 wl = *reinterpret_cast<const bf16x8*>(smem + off + W_ARR);
-                        acc2[ot] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl, ph, acc2[ot], 0, 0, 0);
-                        acc2[ot] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, pl, acc2[ot], 0, 0, 0);
+                    const bool more = ot + 1 < NOT || s == 0;
+                    bf16x8 vhn, vln;
+                    if (more) {
+                        const char* nx = ot + 1 < NOT ? w2_addr(ot + 1, s) : w2_addr(0, 1);
+                        vhn = *reinterpret_cast<const bf16x8*>(nx);
+                        if (SPLIT == 3) vln = *reinterpret_cast<const bf16x8*>(nx + W2LO);
                     }
-                    acc2[ot] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, ph, acc2[ot], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (SPLIT == 3) {
+                        acc2[ot] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vl, ph, acc2[ot], 0, 0, 0);
+                        acc2[ot] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, pl, acc2[ot], 0, 0, 0);
+                    }
+                    acc2[ot] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, ph, acc2[ot], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (more) { vh = vhn; if (SPLIT == 3) vl = vln; }
                 }
             }
         }

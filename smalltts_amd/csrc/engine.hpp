@@ -45,6 +45,7 @@ struct CodecBlockW {
     const float *norm_w, *dw_b, *gamma, *ffn_norm_w, *b1, *b2, *ffn_gamma;
     float* dw_w;  // [K][C]
     PW w1, w2;
+    PW w2t;       // C = 128 / 256: W2 repacked hidden-tile-major [F/32][C][32] for codec_ffn_stream.hip; N == 0 when unused
     PW w1f, w2f;  // fused-FFN packs for C <= 128: w1f [F][CP], w2f [CP][F], CP = max(C, 64); N == 0 when unused
 };
 struct CodecStageW {
