@@ -14,25 +14,28 @@
 #include "gemm3.hpp"
 #include "kernels.hpp"
 #include "prof.hpp"
+#include <cstdlib>
 
 typedef float f32x2s __attribute__((ext_vector_type(2)));
 
-__device__ __forceinline__ f32x2s gelu2s(f32x2s x) {  // exact-erf GELU (A&S 7.1.26), two values per v_pk_* op
-    const f32x2s z = __builtin_elementwise_abs(x) * 0.70710678118654752f;
-    const f32x2s d = 1.0f + 0.3275911f * z;
+__device__ __forceinline__ f32x2s gelu2s(f32x2s x) {
+    // exact-erf GELU, A&S 7.1.26 (|erf error| <= 1.5e-7): erfc(z) = t (a1 + t (a2 + ...)) exp(-z^2), t = 1 / (1 + p z),
+    // z = |x| / sqrt 2.  gelu(x) = x/2 (1 + erf(x / sqrt 2)) = x/2 + |x|/2 (1 - erfc(z)): no compare / select, the |.| are
+    // free source modifiers, the polynomial runs on v_pk_* ops (two values per instruction).
     f32x2s t;
-    t.x = fast_rcp(d.x);
-    t.y = fast_rcp(d.y);
+    t.x = fast_rcp(fmaf(fabsf(x.x), 0.3275911f * 0.70710678118654752f, 1.0f));
+    t.y = fast_rcp(fmaf(fabsf(x.y), 0.3275911f * 0.70710678118654752f, 1.0f));
     const f32x2s poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
-    const f32x2s ea = (z * z) * -1.4426950408889634f;
+    const f32x2s ea = (x * x) * (-0.5f * 1.4426950408889634f);  // exp(-z^2) = exp2(-x^2/2 log2 e)
     f32x2s e;
     e.x = __builtin_amdgcn_exp2f(ea.x);
     e.y = __builtin_amdgcn_exp2f(ea.y);
-    const f32x2s q = poly * e;
-    f32x2s s;
-    s.x = x.x > 0.f ? 2.0f - q.x : q.x;
-    s.y = x.y > 0.f ? 2.0f - q.y : q.y;
-    return (0.5f * x) * s;
+    const f32x2s u = 1.0f - poly * e;  // erf(z)
+    const f32x2s hx = 0.5f * x;
+    f32x2s r;
+    r.x = fmaf(fabsf(hx.x), u.x, hx.x);
+    r.y = fmaf(fabsf(hx.y), u.y, hx.y);
+    return r;
 }
 
 struct FfnStreamArgs {
@@ -48,9 +51,10 @@ struct FfnStreamArgs {
     const float* gamma;    // [C]
     int M;
     float eps;
+    int dbg;  // experiments: 1 skip GELU, 2 skip first-product MFMAs, 4 skip second-product MFMAs, 8 skip the split/permlane pack
 };
 
-template <int C, int SPLIT, int NW, int S>
+template <int C, int SPLIT, int NW, int S, int TPB>
 __global__ __launch_bounds__(NW * 64) void codec_ffn_stream_kernel(FfnStreamArgs a) {
     constexpr int F = 4 * C;
     constexpr int KK1 = C / 16;             // k16 steps of the first product
@@ -61,7 +65,9 @@ __global__ __launch_bounds__(NW * 64) void codec_ffn_stream_kernel(FfnStreamArgs
     constexpr int CPR1 = RB1 / 16;          // 16-B chunks per W1 row (16 / 32)
     constexpr int W1T = 32 * RB1;           // bytes of one W1 tile image per array (= 64 C)
     constexpr int W2T = C * 64;             // bytes of one W2 tile image per array (C rows x 64 B)
-    constexpr int SLOT = NARR * (W1T + W2T);
+    constexpr int SUB = NARR * (W1T + W2T); // one hidden tile's weights
+    constexpr int SLOT = TPB * SUB;         // a ring slot holds TPB consecutive hidden tiles (one barrier per slot)
+    constexpr int NST = NT1 / TPB;          // slots per pass
     constexpr int PIECES = SLOT / 1024;     // DMA pieces per slot
     constexpr int PW = PIECES / NW;         // per wave
     constexpr int HALF = NARR * (W1T / 1024);  // pieces [0, HALF) are W1, [HALF, PIECES) W2
@@ -86,20 +92,21 @@ __global__ __launch_bounds__(NW * 64) void codec_ffn_stream_kernel(FfnStreamArgs
     unsigned dst[PW];
 #pragma unroll
     for (int i = 0; i < PW; ++i) {
-        const int q = wave * PW + i;  // wave-uniform
+        const int qq = wave * PW + i;  // wave-uniform
+        const int u = qq / (SUB / 1024), q = qq % (SUB / 1024);  // hidden tile inside the slot, piece inside the tile
         if (q < HALF) {               // W1 tile: rows of RB1 bytes, 1024 / RB1 rows per piece
             const int arr = q / (W1T / 1024), j = q % (W1T / 1024);
             const int r = j * (1024 / RB1) + lane / CPR1, pos = lane % CPR1;
             const int c = (pos & ~15) | ((pos ^ r) & 15);
-            src[i] = (arr ? a.w1lo : a.w1hi) + (long)r * C + c * 8;
-            dst[i] = arr * W1T + j * 1024;
+            src[i] = (arr ? a.w1lo : a.w1hi) + (long)r * C + c * 8 + (long)u * 32 * C;
+            dst[i] = u * SUB + arr * W1T + j * 1024;
         } else {                      // W2 tile: 64-B rows, 16 rows per piece
             const int q2 = q - HALF;
             const int arr = q2 / (W2T / 1024), j = q2 % (W2T / 1024);
             const int r = j * 16 + (lane >> 2), pos = lane & 3;
             const int c = pos ^ ((r >> 2) & 3);
-            src[i] = (arr ? a.w2tlo : a.w2thi) + (long)r * 32 + c * 8;
-            dst[i] = NARR * W1T + arr * W2T + j * 1024;
+            src[i] = (arr ? a.w2tlo : a.w2thi) + (long)r * 32 + c * 8 + (long)u * 32 * C;
+            dst[i] = u * SUB + NARR * W1T + arr * W2T + j * 1024;
         }
     }
     auto dma16 = [&](const void* gsrc, unsigned lds_dst) {
@@ -114,9 +121,9 @@ __global__ __launch_bounds__(NW * 64) void codec_ffn_stream_kernel(FfnStreamArgs
             : "v"(gsrc), "s"(lds_dst)
             : "memory");
     };
-    // hidden tile t of either matrix starts 32 * C elements after tile t - 1
+    // hidden tile t of either matrix starts 32 * C elements after tile t - 1; slot index i covers tiles TPB * (i % NST) ..
     auto issue = [&](int i) {
-        const int t = i % NT1;
+        const int t = (i % NST) * TPB;
         const unsigned st = lds0 + (unsigned)((i % S) * SLOT);
 #pragma unroll
         for (int p = 0; p < PW; ++p)
@@ -125,7 +132,7 @@ __global__ __launch_bounds__(NW * 64) void codec_ffn_stream_kernel(FfnStreamArgs
 
     const int npass_total = (a.M + NW * 32 - 1) / (NW * 32);
     const int my_passes = blockIdx.x < npass_total ? (npass_total - blockIdx.x + gridDim.x - 1) / gridDim.x : 0;
-    const int total = my_passes * NT1;  // hidden tiles this workgroup will consume
+    const int total = my_passes * NST;  // ring slots this workgroup will consume
 #pragma unroll 1
     for (int s = 0; s < S - 1; ++s)
         if (s < total) issue(s);
@@ -191,15 +198,18 @@ __global__ __launch_bounds__(NW * 64) void codec_ffn_stream_kernel(FfnStreamArgs
             for (int r = 0; r < 16; ++r) acc2[ot][r] = 0.f;
 
 #pragma unroll 1
-        for (int t = 0; t < NT1; ++t, ++it) {
-            // this wave's pieces of tile `it` have landed: younger = the (S-2) tiles issued after it (none near the end)
+        for (int t = 0; t < NT1; ++t) {
+          if (t % TPB == 0) {
+            // this wave's pieces of slot `it` have landed: younger = the (S-2) tiles issued after it (none near the end)
             if (it + S - 1 <= total)
                 wait_vmcnt<(S - 2) * PW>();
             else
                 wait_vmcnt<0>();
             __builtin_amdgcn_s_barrier();  // everybody's pieces landed; everybody left tile it-1 -> its slot is free
             if (it + S - 1 < total) issue(it + S - 1);
-            const char* sl = smem + (it % S) * SLOT;
+            ++it;
+          }
+            const char* sl = smem + ((it - 1) % S) * SLOT + (t % TPB) * SUB;
 
             // ---- H^T tile: hidden rows 32 t .. +32 x this wave's 32 frames ----------------------------------------------
             floatx16 acc1;
@@ -217,11 +227,13 @@ __global__ __launch_bounds__(NW * 64) void codec_ffn_stream_kernel(FfnStreamArgs
                     if (SPLIT == 3) wln = *reinterpret_cast<const bf16x8*>(sl + W1T + w1_off[kk + 1]);
                 }
                 __builtin_amdgcn_sched_barrier(0);  // keep the reads above the MFMAs below
+                if (!(a.dbg & 2)) {
                 if (SPLIT == 3) {
                     acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl, nh[kk], acc1, 0, 0, 0);
                     acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, nl[kk], acc1, 0, 0, 0);
                 }
                 acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, nh[kk], acc1, 0, 0, 0);
+                }
                 __builtin_amdgcn_sched_barrier(0);
                 if (kk + 1 < KK1) { wh = whn; if (SPLIT == 3) wl = wln; }
             }
@@ -239,8 +251,10 @@ __global__ __launch_bounds__(NW * 64) void codec_ffn_stream_kernel(FfnStreamArgs
                 f32x2s u0, u1;
                 u0.x = acc1[4 * q + 0] + bv.x; u0.y = acc1[4 * q + 1] + bv.y;
                 u1.x = acc1[4 * q + 2] + bv.z; u1.y = acc1[4 * q + 3] + bv.w;
-                u0 = gelu2s(u0);
-                u1 = gelu2s(u1);
+                if (!(a.dbg & 1)) {
+                    u0 = gelu2s(u0);
+                    u1 = gelu2s(u1);
+                }
                 acc1[4 * q + 0] = u0.x; acc1[4 * q + 1] = u0.y; acc1[4 * q + 2] = u1.x; acc1[4 * q + 3] = u1.y;
             }
             // ---- Out^T += W2[:, tile t] . H^T tile: two k16 steps ---------------------------------------------------------
@@ -284,11 +298,13 @@ __global__ __launch_bounds__(NW * 64) void codec_ffn_stream_kernel(FfnStreamArgs
                         if (SPLIT == 3) vln = *reinterpret_cast<const bf16x8*>(nx + W2LO);
                     }
                     __builtin_amdgcn_sched_barrier(0);
+                    if (!(a.dbg & 4)) {
                     if (SPLIT == 3) {
                         acc2[ot] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vl, ph, acc2[ot], 0, 0, 0);
                         acc2[ot] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, pl, acc2[ot], 0, 0, 0);
                     }
                     acc2[ot] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, ph, acc2[ot], 0, 0, 0);
+                    }
                     __builtin_amdgcn_sched_barrier(0);
                     if (more) { vh = vhn; if (SPLIT == 3) vl = vln; }
                 }
@@ -322,12 +338,12 @@ __global__ __launch_bounds__(NW * 64) void codec_ffn_stream_kernel(FfnStreamArgs
     }
 }
 
-template <int C, int SPLIT, int NW, int S>
+template <int C, int SPLIT, int NW, int S, int TPB>
 static hipError_t ffn_stream_go(const FfnStreamArgs& a, hipStream_t st) {
     constexpr int NARR = SPLIT == 3 ? 2 : 1;
-    constexpr size_t lds = (size_t)S * NARR * 128 * C + (size_t)7 * C * 4;
+    constexpr size_t lds = (size_t)S * TPB * NARR * 128 * C + (size_t)7 * C * 4;
     static_assert(lds <= 160 * 1024, "ring exceeds LDS");
-    auto kern = codec_ffn_stream_kernel<C, SPLIT, NW, S>;
+    auto kern = codec_ffn_stream_kernel<C, SPLIT, NW, S, TPB>;
     static bool done = false;
     static int cus = 256;
     if (!done) {
@@ -350,10 +366,13 @@ hipError_t launch_codec_ffn_stream(float* x, RowMap img, const float* norm_w, co
                                    int M, int C, int F, float eps, int split, hipStream_t st) {
     if (!(C == 128 || C == 256) || F != 4 * C || img.ld % 4 || img.off % 4 || (img.rpb && img.bstride % 4)) return hipErrorInvalidValue;
     if (M <= 0) return hipSuccess;
-    FfnStreamArgs a{x, img, norm_w, w1hi, w1lo, b1, w2thi, w2tlo, b2, gamma, M, eps};
+    static const int dbg = getenv("SMTTS_FFN_DBG") ? atoi(getenv("SMTTS_FFN_DBG")) : 0;
+    FfnStreamArgs a{x, img, norm_w, w1hi, w1lo, b1, w2thi, w2tlo, b2, gamma, M, eps, dbg};
     ProfScope ps(st, C == 128 ? "codec_ffn_stream<128>" : "codec_ffn_stream<256>", 4.0 * M * (double)C * F, 8.0 * M * C + 8.0 * (double)C * F);
-    if (C == 128) return split == 3 ? ffn_stream_go<128, 3, 8, 4>(a, st) : ffn_stream_go<128, 1, 8, 4>(a, st);
-    return split == 3 ? ffn_stream_go<256, 3, 4, 2>(a, st) : ffn_stream_go<256, 1, 4, 4>(a, st);
+    static const int tpb2 = getenv("SMTTS_FFN_TPB2") ? atoi(getenv("SMTTS_FFN_TPB2")) : 0;  // experiment: two hidden tiles per barrier at C = 128
+    if (C == 128 && tpb2) return split == 3 ? ffn_stream_go<128, 3, 8, 2, 2>(a, st) : ffn_stream_go<128, 1, 8, 2, 2>(a, st);
+    if (C == 128) return split == 3 ? ffn_stream_go<128, 3, 8, 4, 1>(a, st) : ffn_stream_go<128, 1, 8, 4, 1>(a, st);
+    return split == 3 ? ffn_stream_go<256, 3, 4, 2, 1>(a, st) : ffn_stream_go<256, 1, 4, 4, 1>(a, st);
 }
 
 // out[(t * C + c) * 32 + k] = in[c * F + 32 t + k]   (W2 [C][F] -> hidden-tile-major)

@@ -18,23 +18,24 @@
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-// exact-erf GELU (same A&S 7.1.26 form as gelu_f) on two values at once: the polynomial runs on v_pk_* ops
 __device__ __forceinline__ f32x2 gelu2(f32x2 x) {
-    const f32x2 z = __builtin_elementwise_abs(x) * 0.70710678118654752f;
-    const f32x2 d = 1.0f + 0.3275911f * z;
+    // exact-erf GELU, A&S 7.1.26 (|erf error| <= 1.5e-7): erfc(z) = t (a1 + t (a2 + ...)) exp(-z^2), t = 1 / (1 + p z),
+    // z = |x| / sqrt 2.  gelu(x) = x/2 (1 + erf(x / sqrt 2)) = x/2 + |x|/2 (1 - erfc(z)): no compare / select, the |.| are
+    // free source modifiers, the polynomial runs on v_pk_* ops (two values per instruction).
     f32x2 t;
-    t.x = fast_rcp(d.x);
-    t.y = fast_rcp(d.y);
+    t.x = fast_rcp(fmaf(fabsf(x.x), 0.3275911f * 0.70710678118654752f, 1.0f));
+    t.y = fast_rcp(fmaf(fabsf(x.y), 0.3275911f * 0.70710678118654752f, 1.0f));
     const f32x2 poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
-    const f32x2 ea = (z * z) * -1.4426950408889634f;  // exp(-z^2) = exp2(-z^2 log2 e)
+    const f32x2 ea = (x * x) * (-0.5f * 1.4426950408889634f);  // exp(-z^2) = exp2(-x^2/2 log2 e)
     f32x2 e;
     e.x = __builtin_amdgcn_exp2f(ea.x);
     e.y = __builtin_amdgcn_exp2f(ea.y);
-    const f32x2 q = poly * e;  // erfc(z)
-    f32x2 s;
-    s.x = x.x > 0.f ? 2.0f - q.x : q.x;
-    s.y = x.y > 0.f ? 2.0f - q.y : q.y;
-    return (0.5f * x) * s;
+    const f32x2 u = 1.0f - poly * e;  // erf(z)
+    const f32x2 hx = 0.5f * x;
+    f32x2 r;
+    r.x = fmaf(fabsf(hx.x), u.x, hx.x);
+    r.y = fmaf(fabsf(hx.y), u.y, hx.y);
+    return r;
 }
 
 struct FfnWaveArgs {

@@ -51,14 +51,14 @@ __device__ __forceinline__ float group_sum(float v) {  // reduce within aligned 
 __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 __device__ __forceinline__ float silu_f(float x) { return x * fast_rcp(1.0f + __expf(-x)); }
 __device__ __forceinline__ float sigmoid_f(float x) { return fast_rcp(1.0f + __expf(-x)); }
-// exact-erf GELU via Abramowitz-Stegun 7.1.26 (|erf error| <= 1.5e-7); the negative side is evaluated in
-// erfc form so the tail keeps its relative accuracy.
+// exact-erf GELU via Abramowitz-Stegun 7.1.26 (|erf error| <= 1.5e-7): erfc(z) = t (a1 + t (a2 + ...)) exp(-z^2),
+// t = 1 / (1 + p z), z = |x| / sqrt 2, and gelu(x) = x/2 + |x|/2 erf(z) — no compare / select, |.| are source modifiers.
 __device__ __forceinline__ float gelu_f(float x) {
-    const float z = fabsf(x) * 0.70710678118654752f;
-    const float t = fast_rcp(1.0f + 0.3275911f * z);
+    const float t = fast_rcp(fmaf(fabsf(x), 0.3275911f * 0.70710678118654752f, 1.0f));
     const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
-    const float q = poly * __expf(-z * z);  // erfc(z)
-    return x > 0.f ? 0.5f * x * (2.0f - q) : 0.5f * x * q;
+    const float e = __builtin_amdgcn_exp2f((x * x) * (-0.5f * 1.4426950408889634f));  // exp(-z^2)
+    const float hx = 0.5f * x;
+    return fmaf(fabsf(hx), 1.0f - poly * e, hx);
 }
 __device__ __forceinline__ float mish_f(float x) {
     // x * tanh(softplus(x)); softplus with torch's threshold (20) for parity
