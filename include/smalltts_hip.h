@@ -115,8 +115,7 @@ int smtts_bench_gemm(smtts_handle h, int M, int N, int K, int epi, int split, in
 /* hot-path kernel (gemm3: split-bf16 A and W via DMA ring): C[M,N] = act(A W^T + bias); A, W fp32 on device, split internally; K % 64 == 0 */
 int smtts_test_gemm3(smtts_handle h, void* stream, const float* A, const float* W, const float* bias, int M, int N, int K,
                      int act, int split, int cfg, float* C);
-/* codec narrow stages (C <= 128): bit 0: 1 (default) = fused FFN kernel, 0 = two gemm3 launches; bit 1 set = use the
- * 64-frame / 4-wave variant of the C = 128 fused kernel instead of the 128-frame / 8-wave one (A/B tests) */
+/* codec blocks: 1 (default) = fused mixer and fused FFN kernels (C <= 256), 0 = separate norm / conv / two-GEMM path */
 int smtts_test_set_fused_ffn(smtts_handle h, int on);
 /* fp32-A GEMMs (cold paths): 1 (default) = register-staged v1 kernel, 0 = v2 DMA-ring kernel (A/B tests) */
 int smtts_test_force_gemm_v1(int on);

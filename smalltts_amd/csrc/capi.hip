@@ -134,14 +134,7 @@ int smtts_test_gemm3(smtts_handle h, void* stream, const float* A, const float* 
                      int act, int split, int cfg, float* C) {
     return E.test_gemm3(ST(stream), A, W, bias, M, N, K, act, split, cfg, C);
 }
-extern int g_ffn_bm128;
-int smtts_test_set_fused_ffn(smtts_handle h, int on) {
-    E.set_fused_ffn((on & 1) != 0);
-    g_ffn_bm128 = (on & 2) ? 0 : 1;
-    g_codec_wave_ffn = (on & 4) ? 0 : 1;
-    g_codec_stream_ffn = (on & 8) ? 0 : 1;
-    return 0;
-}
+int smtts_test_set_fused_ffn(smtts_handle h, int on) { E.set_fused_ffn(on != 0); return 0; }
 int smtts_test_set_attention_mfma(smtts_handle h, int on) { E.set_attn_mfma(on != 0); return 0; }
 int smtts_test_force_gemm_v1(int on) { g_gemm_force_v1 = on; return 0; }
 

@@ -29,8 +29,6 @@ inline std::string sidx(const std::string& a, int i, const std::string& b) { ret
 
 thread_local Profiler* g_prof = nullptr;
 thread_local const char* g_prof_tag = nullptr;
-int g_codec_stream_ffn = 1;  // C = 128 / 256 codec FFN: 1 = streamed fused kernel (codec_ffn_stream.hip), 0 = previous paths
-int g_codec_wave_ffn = 1;  // C <= 64 codec FFN: 1 = wave-autonomous kernel (codec_ffn_wave.hip), 0 = codec_ffn_kernel
 int g_gemm_force_v1 = 1;  // fp32-A GEMMs (cold paths) use the register-staged v1 kernel; 0 routes them to the v2 DMA kernel
 
 Engine::Engine(int device) : device_(device) {
@@ -434,12 +432,6 @@ int Engine::finalize_codec(bool decoder) {
             b.w2 = pack_rows({p + ".ffn.w2.weight"});
             if (!b.w1.N || !b.w2.N) return fail("codec ffn pack failed: " + p + " " + err_);
             const int F = s.ffn_mult * C;
-            if ((C == 32 || C == 64 || C == 128) && F % 64 == 0) {
-                const int CP = C < 64 ? 64 : C;
-                b.w1f = pack_from_f32(rawp(p + ".ffn.w1.weight"), F, C, CP, 0);
-                b.w2f = pack_from_f32(rawp(p + ".ffn.w2.weight"), C, F, 0, CP);
-                if (!b.w1f.N || !b.w2f.N) return fail("codec fused ffn pack failed: " + p);
-            }
             if ((C == 128 || C == 256) && F == 4 * C && b.w1.K == C && b.w2.K == F) {  // streamed fused FFN: W2 hidden-tile-major
                 b.w2t.hi = static_cast<bf16_t*>(dalloc((size_t)C * F * 2));
                 b.w2t.lo = static_cast<bf16_t*>(dalloc((size_t)C * F * 2));
@@ -1036,21 +1028,16 @@ int Engine::codec_block(hipStream_t st, const CodecBlockW& w, float** xp, float*
         HIPC(launch_dwconv_resid(x, nbuf, w.dw_w, w.dw_b, w.gamma, B, T, C, cspec_.kernel, pad, st));
     }
     // FFN: RMSNorm -> Linear 4x -> GELU -> Linear -> LayerScale residual
-    if (w.w1f.N && fused_ffn_ && g_codec_wave_ffn && (C == 32 || C == 64) && F == 4 * C) {
+    if (fused_ffn_ && (C == 32 || C == 64) && F == 4 * C && w.w1.K == C && w.w2.K == F) {
         // narrowest stages: all weights LDS-resident, one wave per 32 frames, hidden stays in registers (codec_ffn_wave.hip)
-        HIPC(launch_codec_ffn_wave(x, img, w.ffn_norm_w, w.w1f.hi, w.w1f.lo, w.w1f.K, w.b1, w.w2f.hi, w.w2f.lo, w.b2,
-                                   w.ffn_gamma, M, C, F, cspec_.eps, split_, st));
+        HIPC(launch_codec_ffn_wave(x, img, w.ffn_norm_w, w.w1.hi, w.w1.lo, w.w1.K, w.b1, w.w2.hi, w.w2.lo, w.b2, w.ffn_gamma, M,
+                                   C, F, cspec_.eps, split_, st));
         return 0;
     }
-    if (w.w2t.N && fused_ffn_ && g_codec_stream_ffn) {
+    if (w.w2t.N && fused_ffn_) {
         // C = 128 / 256: weights stream through an LDS ring, hidden in registers (codec_ffn_stream.hip)
         HIPC(launch_codec_ffn_stream(x, img, w.ffn_norm_w, w.w1.hi, w.w1.lo, w.b1, w.w2t.hi, w.w2t.lo, w.b2, w.ffn_gamma, M, C, F,
                                      cspec_.eps, split_, st));
-        return 0;
-    }
-    if (w.w1f.N && fused_ffn_) {  // narrow stages: one fused kernel, hidden stays in LDS (codec_ffn.hip)
-        HIPC(launch_codec_ffn_fused(x, img, w.ffn_norm_w, w.w1f.hi, w.w1f.lo, w.b1, w.w2f.hi, w.w2f.lo, w.b2, w.ffn_gamma, M,
-                                    C, F, cspec_.eps, split_, st));
         return 0;
     }
     // wide stages: two gemm3 launches; n2 / hidden are split bf16 pairs

@@ -46,7 +46,6 @@ struct CodecBlockW {
     float* dw_w;  // [K][C]
     PW w1, w2;
     PW w2t;       // C = 128 / 256: W2 repacked hidden-tile-major [F/32][C][32] for codec_ffn_stream.hip; N == 0 when unused
-    PW w1f, w2f;  // fused-FFN packs for C <= 128: w1f [F][CP], w2f [CP][F], CP = max(C, 64); N == 0 when unused
 };
 struct CodecStageW {
     int C = 0, r = 0;  // r: resample ratio entering this stage (0 for stage 0)

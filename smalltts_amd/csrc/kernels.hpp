@@ -111,16 +111,13 @@ hipError_t launch_zero_pad_frames(float* x, int B, int T, int C, int pad, hipStr
 hipError_t launch_codec_ffn_wave(float* x, RowMap img, const float* norm_w, const bf16_t* w1hi, const bf16_t* w1lo, int ld1,
                                  const float* b1, const bf16_t* w2hi, const bf16_t* w2lo, const float* b2, const float* gamma,
                                  int M, int C, int F, float eps, int split, hipStream_t st);
-extern int g_codec_wave_ffn;
 // C in {128, 256}: weights streamed through an LDS ring (codec_ffn_stream.hip); w1 [F][C], w2t = launch_w2_tile_pack(W2 [C][F])
 hipError_t launch_codec_ffn_stream(float* x, RowMap img, const float* norm_w, const bf16_t* w1hi, const bf16_t* w1lo,
                                    const float* b1, const bf16_t* w2thi, const bf16_t* w2tlo, const float* b2, const float* gamma,
                                    int M, int C, int F, float eps, int split, hipStream_t st);
 hipError_t launch_w2_tile_pack(const bf16_t* in, bf16_t* out, int C, int F, hipStream_t st);
-extern int g_codec_stream_ffn;
-hipError_t launch_codec_ffn_fused(float* x, RowMap img, const float* norm_w, const bf16_t* w1hi, const bf16_t* w1lo,
-                                  const float* b1, const bf16_t* w2hi, const bf16_t* w2lo, const float* b2,
-                                  const float* gamma, int M, int C, int F, float eps, int split, hipStream_t st);
+
+
 
 // x[m][n] += mask(m) * gate[(grow0 + (m / rows_per_batch) * grstride) * gld + n] * (sum_s part[s][m][n] + bias[n])
 // (gate == null -> 1; fixed summation order s = 0..S-1).  Closes a split-K GEMM (see gemm3_resid_splitk).
