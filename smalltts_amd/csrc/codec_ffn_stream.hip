@@ -14,9 +14,20 @@
 #include "gemm3.hpp"
 #include "kernels.hpp"
 #include "prof.hpp"
-#include <cstdlib>
 
 typedef float f32x2s __attribute__((ext_vector_type(2)));
+
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+// (a, b) -> packed bf16 pair in one v_cvt_pk_bf16_f32; split_pair also returns the packed bf16 of the two residuals
+__device__ __forceinline__ unsigned cvt_pk_bf16(float a, float b) {
+    f32x2s v;
+    v.x = a; v.y = b;
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
+}
+__device__ __forceinline__ void split_pair(float a, float b, unsigned& hi, unsigned& lo) {
+    hi = cvt_pk_bf16(a, b);
+    lo = cvt_pk_bf16(a - __uint_as_float(hi << 16), b - __uint_as_float(hi & 0xffff0000u));
+}
 
 __device__ __forceinline__ f32x2s gelu2s(f32x2s x) {
     // exact-erf GELU, A&S 7.1.26 (|erf error| <= 1.5e-7): erfc(z) = t (a1 + t (a2 + ...)) exp(-z^2), t = 1 / (1 + p z),
@@ -51,7 +62,6 @@ struct FfnStreamArgs {
     const float* gamma;    // [C]
     int M;
     float eps;
-    int dbg;  // experiments: 1 skip GELU, 2 skip first-product MFMAs, 4 skip second-product MFMAs, 8 skip the split/permlane pack
 };
 
 template <int C, int SPLIT, int NW, int S, int TPB>
@@ -184,11 +194,11 @@ __global__ __launch_bounds__(NW * 64) void codec_ffn_stream_kernel(FfnStreamArgs
                 const float4 g1 = *reinterpret_cast<const float4*>(vnw + 16 * kk + 8 * fh + 4);
                 const float v[8] = {xa[kk][0].x * rstd * g0.x, xa[kk][0].y * rstd * g0.y, xa[kk][0].z * rstd * g0.z, xa[kk][0].w * rstd * g0.w,
                                     xa[kk][1].x * rstd * g1.x, xa[kk][1].y * rstd * g1.y, xa[kk][1].z * rstd * g1.z, xa[kk][1].w * rstd * g1.w};
+                unsigned nhp[4], nlp[4];
 #pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    nh[kk][e] = (bf16_t)v[e];
-                    nl[kk][e] = (bf16_t)(v[e] - (float)nh[kk][e]);
-                }
+                for (int e = 0; e < 4; ++e) split_pair(v[2 * e], v[2 * e + 1], nhp[e], nlp[e]);
+                nh[kk] = __builtin_bit_cast(bf16x8, *reinterpret_cast<uint4*>(nhp));
+                nl[kk] = __builtin_bit_cast(bf16x8, *reinterpret_cast<uint4*>(nlp));
             }
         }
         floatx16 acc2[NOT];
@@ -217,32 +227,30 @@ __global__ __launch_bounds__(NW * 64) void codec_ffn_stream_kernel(FfnStreamArgs
             for (int r = 0; r < 16; ++r) acc1[r] = 0.f;
             // fragment reads run one k16 step ahead of the MFMAs that consume them (the compiler keeps this order and counts
             // lgkmcnt, so the LDS latency of step kk+1 hides under the three MFMAs of step kk)
-            bf16x8 wh = *reinterpret_cast<const bf16x8*>(sl + w1_off[0]), wl;
-            if (SPLIT == 3) wl = *reinterpret_cast<const bf16x8*>(sl + W1T + w1_off[0]);
+            bf16x8 w1f[2][2];  // [buffer kk & 1][hi | lo]: compile-time ping-pong, no register copies
+            w1f[0][0] = *reinterpret_cast<const bf16x8*>(sl + w1_off[0]);
+            if (SPLIT == 3) w1f[0][1] = *reinterpret_cast<const bf16x8*>(sl + W1T + w1_off[0]);
 #pragma unroll
             for (int kk = 0; kk < KK1; ++kk) {
-                bf16x8 whn, wln;
                 if (kk + 1 < KK1) {
-                    whn = *reinterpret_cast<const bf16x8*>(sl + w1_off[kk + 1]);
-                    if (SPLIT == 3) wln = *reinterpret_cast<const bf16x8*>(sl + W1T + w1_off[kk + 1]);
+                    w1f[(kk + 1) & 1][0] = *reinterpret_cast<const bf16x8*>(sl + w1_off[kk + 1]);
+                    if (SPLIT == 3) w1f[(kk + 1) & 1][1] = *reinterpret_cast<const bf16x8*>(sl + W1T + w1_off[kk + 1]);
                 }
                 __builtin_amdgcn_sched_barrier(0);  // keep the reads above the MFMAs below
-                if (!(a.dbg & 2)) {
                 if (SPLIT == 3) {
-                    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl, nh[kk], acc1, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, nl[kk], acc1, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1f[kk & 1][1], nh[kk], acc1, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1f[kk & 1][0], nl[kk], acc1, 0, 0, 0);
                 }
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, nh[kk], acc1, 0, 0, 0);
-                }
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1f[kk & 1][0], nh[kk], acc1, 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
-                if (kk + 1 < KK1) { wh = whn; if (SPLIT == 3) wl = wln; }
             }
             // W2 fragments are read one (k16 step, channel tile) pair ahead as well; the first pair is requested before the
             // GELU so it lands under it
             auto w2_addr = [&](int ot, int s) { return sl + w2_off[ot][s]; };
             constexpr int W2LO = W2T;
-            bf16x8 vh = *reinterpret_cast<const bf16x8*>(w2_addr(0, 0)), vl;
-            if (SPLIT == 3) vl = *reinterpret_cast<const bf16x8*>(w2_addr(0, 0) + W2LO);
+            bf16x8 w2f[2][2];  // [buffer][hi | lo], buffer = (s * NOT + ot) & 1
+            w2f[0][0] = *reinterpret_cast<const bf16x8*>(w2_addr(0, 0));
+            if (SPLIT == 3) w2f[0][1] = *reinterpret_cast<const bf16x8*>(w2_addr(0, 0) + W2LO);
             __builtin_amdgcn_sched_barrier(0);
             // ---- bias + GELU in place: row(r) = hidden 32 t + (r & 3) + 8 (r >> 2) + 4 fh -----------------------------
 #pragma unroll
@@ -251,10 +259,8 @@ __global__ __launch_bounds__(NW * 64) void codec_ffn_stream_kernel(FfnStreamArgs
                 f32x2s u0, u1;
                 u0.x = acc1[4 * q + 0] + bv.x; u0.y = acc1[4 * q + 1] + bv.y;
                 u1.x = acc1[4 * q + 2] + bv.z; u1.y = acc1[4 * q + 3] + bv.w;
-                if (!(a.dbg & 1)) {
-                    u0 = gelu2s(u0);
-                    u1 = gelu2s(u1);
-                }
+                u0 = gelu2s(u0);
+                u1 = gelu2s(u1);
                 acc1[4 * q + 0] = u0.x; acc1[4 * q + 1] = u0.y; acc1[4 * q + 2] = u1.x; acc1[4 * q + 3] = u1.y;
             }
             // ---- Out^T += W2[:, tile t] . H^T tile: two k16 steps ---------------------------------------------------------
@@ -264,16 +270,8 @@ __global__ __launch_bounds__(NW * 64) void codec_ffn_stream_kernel(FfnStreamArgs
                 unsigned xh[2], yh[2], xl[2], yl[2];
 #pragma unroll
                 for (int e = 0; e < 2; ++e) {
-                    const float pa = acc1[r0 + 2 * e], pb = acc1[r0 + 2 * e + 1];
-                    const float pc = acc1[r0 + 4 + 2 * e], pd = acc1[r0 + 4 + 2 * e + 1];
-                    const bf16_t ah = (bf16_t)pa, bh = (bf16_t)pb, ch = (bf16_t)pc, dh = (bf16_t)pd;
-                    const bf16_t al = (bf16_t)(pa - (float)ah), bl = (bf16_t)(pb - (float)bh);
-                    const bf16_t cl = (bf16_t)(pc - (float)ch), dl = (bf16_t)(pd - (float)dh);
-                    auto pk = [](bf16_t lo, bf16_t hi) {
-                        return (unsigned)__builtin_bit_cast(unsigned short, lo) | ((unsigned)__builtin_bit_cast(unsigned short, hi) << 16);
-                    };
-                    xh[e] = pk(ah, bh); yh[e] = pk(ch, dh);
-                    xl[e] = pk(al, bl); yl[e] = pk(cl, dl);
+                    split_pair(acc1[r0 + 2 * e], acc1[r0 + 2 * e + 1], xh[e], xl[e]);
+                    split_pair(acc1[r0 + 4 + 2 * e], acc1[r0 + 4 + 2 * e + 1], yh[e], yl[e]);
                 }
                 unsigned fhh[4], fll[4];
 #pragma unroll
@@ -290,23 +288,19 @@ __global__ __launch_bounds__(NW * 64) void codec_ffn_stream_kernel(FfnStreamArgs
                 if (SPLIT == 3) pl = __builtin_bit_cast(bf16x8, *reinterpret_cast<uint4*>(fll));
 #pragma unroll
                 for (int ot = 0; ot < NOT; ++ot) {
-                    const bool more = ot + 1 < NOT || s == 0;
-                    bf16x8 vhn, vln;
-                    if (more) {
+                    const int cur = (s * NOT + ot) & 1, nxt = cur ^ 1;
+                    if (ot + 1 < NOT || s == 0) {
                         const char* nx = ot + 1 < NOT ? w2_addr(ot + 1, s) : w2_addr(0, 1);
-                        vhn = *reinterpret_cast<const bf16x8*>(nx);
-                        if (SPLIT == 3) vln = *reinterpret_cast<const bf16x8*>(nx + W2LO);
+                        w2f[nxt][0] = *reinterpret_cast<const bf16x8*>(nx);
+                        if (SPLIT == 3) w2f[nxt][1] = *reinterpret_cast<const bf16x8*>(nx + W2LO);
                     }
                     __builtin_amdgcn_sched_barrier(0);
-                    if (!(a.dbg & 4)) {
                     if (SPLIT == 3) {
-                        acc2[ot] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vl, ph, acc2[ot], 0, 0, 0);
-                        acc2[ot] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, pl, acc2[ot], 0, 0, 0);
+                        acc2[ot] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w2f[cur][1], ph, acc2[ot], 0, 0, 0);
+                        acc2[ot] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w2f[cur][0], pl, acc2[ot], 0, 0, 0);
                     }
-                    acc2[ot] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, ph, acc2[ot], 0, 0, 0);
-                    }
+                    acc2[ot] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w2f[cur][0], ph, acc2[ot], 0, 0, 0);
                     __builtin_amdgcn_sched_barrier(0);
-                    if (more) { vh = vhn; if (SPLIT == 3) vl = vln; }
                 }
             }
         }
@@ -366,11 +360,8 @@ hipError_t launch_codec_ffn_stream(float* x, RowMap img, const float* norm_w, co
                                    int M, int C, int F, float eps, int split, hipStream_t st) {
     if (!(C == 128 || C == 256) || F != 4 * C || img.ld % 4 || img.off % 4 || (img.rpb && img.bstride % 4)) return hipErrorInvalidValue;
     if (M <= 0) return hipSuccess;
-    static const int dbg = getenv("SMTTS_FFN_DBG") ? atoi(getenv("SMTTS_FFN_DBG")) : 0;
-    FfnStreamArgs a{x, img, norm_w, w1hi, w1lo, b1, w2thi, w2tlo, b2, gamma, M, eps, dbg};
+    FfnStreamArgs a{x, img, norm_w, w1hi, w1lo, b1, w2thi, w2tlo, b2, gamma, M, eps};
     ProfScope ps(st, C == 128 ? "codec_ffn_stream<128>" : "codec_ffn_stream<256>", 4.0 * M * (double)C * F, 8.0 * M * C + 8.0 * (double)C * F);
-    static const int tpb2 = getenv("SMTTS_FFN_TPB2") ? atoi(getenv("SMTTS_FFN_TPB2")) : 0;  // experiment: two hidden tiles per barrier at C = 128
-    if (C == 128 && tpb2) return split == 3 ? ffn_stream_go<128, 3, 8, 2, 2>(a, st) : ffn_stream_go<128, 1, 8, 2, 2>(a, st);
     if (C == 128) return split == 3 ? ffn_stream_go<128, 3, 8, 4, 1>(a, st) : ffn_stream_go<128, 1, 8, 4, 1>(a, st);
     return split == 3 ? ffn_stream_go<256, 3, 4, 2, 1>(a, st) : ffn_stream_go<256, 1, 4, 4, 1>(a, st);
 }

@@ -18,6 +18,18 @@
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+// (a, b) -> packed bf16 pair in one v_cvt_pk_bf16_f32; split_pair also returns the packed bf16 of the two residuals
+__device__ __forceinline__ unsigned cvt_pk_bf16(float a, float b) {
+    f32x2 v;
+    v.x = a; v.y = b;
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
+}
+__device__ __forceinline__ void split_pair(float a, float b, unsigned& hi, unsigned& lo) {
+    hi = cvt_pk_bf16(a, b);
+    lo = cvt_pk_bf16(a - __uint_as_float(hi << 16), b - __uint_as_float(hi & 0xffff0000u));
+}
+
 __device__ __forceinline__ f32x2 gelu2(f32x2 x) {
     // exact-erf GELU, A&S 7.1.26 (|erf error| <= 1.5e-7): erfc(z) = t (a1 + t (a2 + ...)) exp(-z^2), t = 1 / (1 + p z),
     // z = |x| / sqrt 2.  gelu(x) = x/2 (1 + erf(x / sqrt 2)) = x/2 + |x|/2 (1 - erfc(z)): no compare / select, the |.| are
@@ -135,11 +147,11 @@ __global__ __launch_bounds__(512) void codec_ffn_wave_kernel(FfnWaveArgs a) {
             const float4 g1 = *reinterpret_cast<const float4*>(vnw + 16 * kk + 8 * fh + 4);
             const float v[8] = {xa[kk][0].x * rstd * g0.x, xa[kk][0].y * rstd * g0.y, xa[kk][0].z * rstd * g0.z, xa[kk][0].w * rstd * g0.w,
                                 xa[kk][1].x * rstd * g1.x, xa[kk][1].y * rstd * g1.y, xa[kk][1].z * rstd * g1.z, xa[kk][1].w * rstd * g1.w};
+            unsigned nhp[4], nlp[4];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                nh[kk][e] = (bf16_t)v[e];
-                nl[kk][e] = (bf16_t)(v[e] - (float)nh[kk][e]);
-            }
+            for (int e = 0; e < 4; ++e) split_pair(v[2 * e], v[2 * e + 1], nhp[e], nlp[e]);
+            nh[kk] = __builtin_bit_cast(bf16x8, *reinterpret_cast<uint4*>(nhp));
+            nl[kk] = __builtin_bit_cast(bf16x8, *reinterpret_cast<uint4*>(nlp));
         }
         const int m_cur = wt * 32 + fr;
         if (wt + nwg < ntiles) load_tile(wt + nwg);  // next tile's x arrives under this tile's MFMA / GELU work
@@ -158,23 +170,22 @@ __global__ __launch_bounds__(512) void codec_ffn_wave_kernel(FfnWaveArgs a) {
             for (int r = 0; r < 16; ++r) acc1[r] = 0.f;
             // fragment reads run one k16 step ahead of the MFMAs that consume them (the compiler keeps this order and counts
             // lgkmcnt, so the LDS latency of step kk+1 hides under the three MFMAs of step kk)
-            bf16x8 wh = *reinterpret_cast<const bf16x8*>(smem + OFF_W1 + t * 32 * RB1 + w1_off[0]), wl;
-            if (SPLIT == 3) wl = *reinterpret_cast<const bf16x8*>(smem + OFF_W1 + W_ARR + t * 32 * RB1 + w1_off[0]);
+            bf16x8 w1f[2][2];  // [buffer kk & 1][hi | lo]: compile-time ping-pong, no register copies
+            w1f[0][0] = *reinterpret_cast<const bf16x8*>(smem + OFF_W1 + t * 32 * RB1 + w1_off[0]);
+            if (SPLIT == 3) w1f[0][1] = *reinterpret_cast<const bf16x8*>(smem + OFF_W1 + W_ARR + t * 32 * RB1 + w1_off[0]);
 #pragma unroll
             for (int kk = 0; kk < KK1; ++kk) {
-                bf16x8 whn, wln;
                 if (kk + 1 < KK1) {
-                    whn = *reinterpret_cast<const bf16x8*>(smem + OFF_W1 + t * 32 * RB1 + w1_off[kk + 1]);
-                    if (SPLIT == 3) wln = *reinterpret_cast<const bf16x8*>(smem + OFF_W1 + W_ARR + t * 32 * RB1 + w1_off[kk + 1]);
+                    w1f[(kk + 1) & 1][0] = *reinterpret_cast<const bf16x8*>(smem + OFF_W1 + t * 32 * RB1 + w1_off[kk + 1]);
+                    if (SPLIT == 3) w1f[(kk + 1) & 1][1] = *reinterpret_cast<const bf16x8*>(smem + OFF_W1 + W_ARR + t * 32 * RB1 + w1_off[kk + 1]);
                 }
                 __builtin_amdgcn_sched_barrier(0);  // keep the reads above the MFMAs below
                 if (SPLIT == 3) {
-                    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl, nh[kk], acc1, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, nl[kk], acc1, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1f[kk & 1][1], nh[kk], acc1, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1f[kk & 1][0], nl[kk], acc1, 0, 0, 0);
                 }
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, nh[kk], acc1, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1f[kk & 1][0], nh[kk], acc1, 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
-                if (kk + 1 < KK1) { wh = whn; if (SPLIT == 3) wl = wln; }
             }
             // W2 fragments are read one (k16 step, channel tile) pair ahead as well; the first pair is requested before the
             // GELU so it lands under it
@@ -183,8 +194,9 @@ __global__ __launch_bounds__(512) void codec_ffn_wave_kernel(FfnWaveArgs a) {
                 return smem + OFF_W2 + row * RB2 + (((c & ~15) | ((c ^ row) & 15)) << 4);
             };
             constexpr int W2LO = W_ARR;
-            bf16x8 vh = *reinterpret_cast<const bf16x8*>(w2_addr(0, 0)), vl;
-            if (SPLIT == 3) vl = *reinterpret_cast<const bf16x8*>(w2_addr(0, 0) + W2LO);
+            bf16x8 w2f[2][2];  // [buffer][hi | lo], buffer = (s * NOT + ot) & 1
+            w2f[0][0] = *reinterpret_cast<const bf16x8*>(w2_addr(0, 0));
+            if (SPLIT == 3) w2f[0][1] = *reinterpret_cast<const bf16x8*>(w2_addr(0, 0) + W2LO);
             __builtin_amdgcn_sched_barrier(0);
             // ---- bias + GELU in place: row(r) = hidden 32 t + (r & 3) + 8 (r >> 2) + 4 fh -----------------------
 #pragma unroll
@@ -204,16 +216,8 @@ __global__ __launch_bounds__(512) void codec_ffn_wave_kernel(FfnWaveArgs a) {
                 unsigned xh[2], yh[2], xl[2], yl[2];
 #pragma unroll
                 for (int e = 0; e < 2; ++e) {
-                    const float pa = acc1[r0 + 2 * e], pb = acc1[r0 + 2 * e + 1];
-                    const float pc = acc1[r0 + 4 + 2 * e], pd = acc1[r0 + 4 + 2 * e + 1];
-                    const bf16_t ah = (bf16_t)pa, bh = (bf16_t)pb, ch = (bf16_t)pc, dh = (bf16_t)pd;
-                    const bf16_t al = (bf16_t)(pa - (float)ah), bl = (bf16_t)(pb - (float)bh);
-                    const bf16_t cl = (bf16_t)(pc - (float)ch), dl = (bf16_t)(pd - (float)dh);
-                    auto pk = [](bf16_t lo, bf16_t hi) {
-                        return (unsigned)__builtin_bit_cast(unsigned short, lo) | ((unsigned)__builtin_bit_cast(unsigned short, hi) << 16);
-                    };
-                    xh[e] = pk(ah, bh); yh[e] = pk(ch, dh);
-                    xl[e] = pk(al, bl); yl[e] = pk(cl, dl);
+                    split_pair(acc1[r0 + 2 * e], acc1[r0 + 2 * e + 1], xh[e], xl[e]);
+                    split_pair(acc1[r0 + 4 + 2 * e], acc1[r0 + 4 + 2 * e + 1], yh[e], yl[e]);
                 }
                 // lane half 0 needs hidden 0..7 of the step, half 1 hidden 8..15: swap upper half of X with lower half of Y
                 unsigned fhh[4], fll[4];
@@ -231,21 +235,19 @@ __global__ __launch_bounds__(512) void codec_ffn_wave_kernel(FfnWaveArgs a) {
                 if (SPLIT == 3) pl = __builtin_bit_cast(bf16x8, *reinterpret_cast<uint4*>(fll));
 #pragma unroll
                 for (int ot = 0; ot < NOT; ++ot) {
-                    const bool more = ot + 1 < NOT || s == 0;
-                    bf16x8 vhn, vln;
-                    if (more) {
+                    const int cur = (s * NOT + ot) & 1, nxt = cur ^ 1;
+                    if (ot + 1 < NOT || s == 0) {
                         const char* nx = ot + 1 < NOT ? w2_addr(ot + 1, s) : w2_addr(0, 1);
-                        vhn = *reinterpret_cast<const bf16x8*>(nx);
-                        if (SPLIT == 3) vln = *reinterpret_cast<const bf16x8*>(nx + W2LO);
+                        w2f[nxt][0] = *reinterpret_cast<const bf16x8*>(nx);
+                        if (SPLIT == 3) w2f[nxt][1] = *reinterpret_cast<const bf16x8*>(nx + W2LO);
                     }
                     __builtin_amdgcn_sched_barrier(0);
                     if (SPLIT == 3) {
-                        acc2[ot] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vl, ph, acc2[ot], 0, 0, 0);
-                        acc2[ot] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, pl, acc2[ot], 0, 0, 0);
+                        acc2[ot] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w2f[cur][1], ph, acc2[ot], 0, 0, 0);
+                        acc2[ot] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w2f[cur][0], pl, acc2[ot], 0, 0, 0);
                     }
-                    acc2[ot] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, ph, acc2[ot], 0, 0, 0);
+                    acc2[ot] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w2f[cur][0], ph, acc2[ot], 0, 0, 0);
                     __builtin_amdgcn_sched_barrier(0);
-                    if (more) { vh = vhn; if (SPLIT == 3) vl = vln; }
                 }
             }
         }
