@@ -12,6 +12,8 @@ offline).  Unlike the reference, `forward` runs all utterances as ONE padded bat
 """
 from __future__ import annotations
 
+import collections
+import hashlib
 import os
 from typing import Dict, Iterable, List, Optional, Sequence
 
@@ -179,3 +181,24 @@ class Encoder(_CodecRunner):
     def encode(self, audio: torch.Tensor) -> torch.Tensor:
         """audio f32 (batch, 1, time) @ 24 kHz -> latents f32 (batch, time // 3200, 64), on the CPU."""
         return self.engine.codec_encode(audio.detach()).cpu()
+
+    # reference voices are encoded once per voice (clone.py:36, interactive.py:34): latents cached by content hash
+    _ref_cache: "collections.OrderedDict[bytes, torch.Tensor]" = None  # type: ignore[assignment]
+    REF_CACHE_ENTRIES = 64
+
+    def encode_reference(self, audio: torch.Tensor) -> torch.Tensor:
+        """Like encode() for ONE reference clip (1, 1, time), memoised on the samples' digest."""
+        if Encoder._ref_cache is None:
+            Encoder._ref_cache = collections.OrderedDict()
+        a = audio.detach().to(torch.float32).contiguous().cpu()
+        key = hashlib.blake2b(a.numpy().tobytes(), digest_size=16, person=str(tuple(a.shape)).encode()[:16]).digest()
+        key += str(id(self.engine)).encode()
+        hit = Encoder._ref_cache.get(key)
+        if hit is not None:
+            Encoder._ref_cache.move_to_end(key)
+            return hit
+        lat = self.encode(a)
+        Encoder._ref_cache[key] = lat
+        while len(Encoder._ref_cache) > self.REF_CACHE_ENTRIES:
+            Encoder._ref_cache.popitem(last=False)
+        return lat

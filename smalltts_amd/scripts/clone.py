@@ -23,7 +23,7 @@ def main(argv=None):
     x = load_reference_wav(args.wav)
     print("encoding reference audio")
     kw = dict(weights=args.weights, device=args.device, precision=args.precision)
-    ref_latents = Encoder(**kw).encode(torch.from_numpy(x))[0].numpy()
+    ref_latents = Encoder(**kw).encode_reference(torch.from_numpy(x))[0].numpy()
     tts = SmallTTS(num_steps=args.steps, seed=args.seed, **kw)
     tokens = tokens_for(args, args.text)
     duration = args.duration or estimate_duration(args.text)

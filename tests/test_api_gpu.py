@@ -98,6 +98,18 @@ def test_codec_wrappers_roundtrip_shapes_and_oracle(eng, oracle_w):
     assert wav.device.type == "cpu" and tuple(wav.shape) == (2, 1, 9600)
     with torch.no_grad():
         assert snr_db(wav.numpy(), CO.decode(wd, lat, SPEC).numpy()) > 60.0
+    # reference-voice cache: same samples -> the cached latents, no second device encode
+    calls = []
+    real = eng.codec_encode
+    eng.codec_encode = lambda a: (calls.append(1), real(a))[1]
+    try:
+        one = audio[:1]
+        l1 = enc.encode_reference(one)
+        l2 = enc.encode_reference(one.clone())
+        l3 = enc.encode_reference(one * 0.5)
+    finally:
+        eng.codec_encode = real
+    assert l2 is l1 and len(calls) == 2 and torch.equal(l1, lat[:1]) and not torch.equal(l3, l1)
 
 
 def test_clone_cli_end_to_end(tmp_path):
