@@ -102,6 +102,15 @@ int smtts_randn(smtts_handle h, void* stream, float* out, int64_t n, uint64_t se
 /* (alpha, sigma) of the reference schedule for t (infer/onnx.py:31-39); host-side, float64 math */
 void smtts_alpha_sigma(float t, float* alpha, float* sigma);
 
+/* ---- device-side audio front / back end -----------------------------------------------
+ * Polyphase windowed-sinc resampling of `channels` rows of n_in samples (reference infer/utils.py:7-16, torchaudio
+ * Resample with sinc_interp_kaiser): y[c][f*up + p] = sum_k xpad[c][f*down + k] * bank[p][k], xpad = x with `width`
+ * leading zeros.  The caller builds the bank [up][klen] (smalltts_amd/audio.py:_sinc_kernel) and owns every buffer. */
+int smtts_resample_poly(smtts_handle h, void* stream, const float* x, int channels, int64_t n_in, const float* bank, int up,
+                        int down, int klen, int width, float* y, int64_t n_out);
+/* float [-1, 1] -> int16 PCM: clamp, x 32767, round to nearest (reference server audio.rs:22-37; CLIs write PCM_16, tryme.py:29) */
+int smtts_pcm16(smtts_handle h, void* stream, const float* x, int64_t n, int16_t* y);
+
 /* per-kernel HIP-event timing on the launch stream (bench.py roofline): enable, run, then read a JSON array
  * [{"name","launches","ms","flops","bytes"}] of algorithmic work and measured time per kernel class */
 int smtts_profile_enable(smtts_handle h, int on);

@@ -44,6 +44,8 @@ SIGNATURES: Dict[str, Tuple[object, List[object]]] = {
     "smtts_encode_workspace_bytes": (sz, [vp, i32, i32]),
     "smtts_codec_encode": (i32, [vp, vp, vp, i32, i32, vp, vp, sz]),
     "smtts_randn": (i32, [vp, vp, vp, i64, u64, u64]),
+    "smtts_resample_poly": (i32, [vp, vp, vp, i32, i64, vp, i32, i32, i32, i32, vp, i64]),
+    "smtts_pcm16": (i32, [vp, vp, vp, i64, vp]),
     "smtts_alpha_sigma": (None, [f32, C.POINTER(f32), C.POINTER(f32)]),
     "smtts_profile_enable": (i32, [vp, i32]),
     "smtts_profile_report": (i32, [vp, C.c_char_p, sz]),

@@ -119,6 +119,16 @@ int smtts_randn(smtts_handle h, void* stream, float* out, int64_t n, uint64_t se
 
 void smtts_alpha_sigma(float t, float* alpha, float* sigma) { alpha_sigma_host(t, *alpha, *sigma); }
 
+int smtts_resample_poly(smtts_handle h, void* stream, const float* x, int channels, int64_t n_in, const float* bank, int up,
+                        int down, int klen, int width, float* y, int64_t n_out) {
+    if (up <= 0 || down <= 0 || klen <= 0 || channels <= 0) return E.fail("resample_poly: bad arguments");
+    hipError_t e = launch_resample_poly(x, n_in, bank, up, down, klen, width, y, n_out, channels, ST(stream));
+    return e == hipSuccess ? 0 : E.fail_hip(e, "resample_poly");
+}
+int smtts_pcm16(smtts_handle h, void* stream, const float* x, int64_t n, int16_t* y) {
+    hipError_t e = launch_pcm16(x, y, n, ST(stream));
+    return e == hipSuccess ? 0 : E.fail_hip(e, "pcm16");
+}
 int smtts_profile_enable(smtts_handle h, int on) { E.profile_enable(on); return 0; }
 int smtts_profile_report(smtts_handle h, char* buf, size_t cap) {
     std::string r = E.profile_report();

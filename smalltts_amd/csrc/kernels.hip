@@ -777,3 +777,51 @@ hipError_t launch_mixer_fused(const float* xin, float* xout, const float* norm_w
                        T, C, K, pad, eps, TT, tiles);
     LAUNCH_CHECK();
 }
+
+// ------------------------------------------------------------------------------------------
+// Device-side audio front / back end
+// ------------------------------------------------------------------------------------------
+// Polyphase windowed-sinc resampler (reference infer/utils.py:7-16 = torchaudio Resample): output sample
+// f * up + p of channel c = sum_k xpad[c][f * down + k] * bank[p][k], where xpad is x with `width` zeros in front
+// (and zeros behind).  One thread per output sample; the bank row is shared by every thread with the same phase.
+__global__ __launch_bounds__(256) void resample_poly_kernel(const float* __restrict__ x, long n_in, const float* __restrict__ bank,
+                                                            int up, int down, int klen, int width, float* __restrict__ y,
+                                                            long n_out, int channels) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_out * channels) return;
+    const int c = (int)(i / n_out);
+    const long o = i % n_out;
+    const long f = o / up;
+    const int p = (int)(o % up);
+    const float* xc = x + (long)c * n_in;
+    const float* b = bank + (long)p * klen;
+    const long s0 = f * down - width;  // index into x of tap 0
+    float acc = 0.f;
+    int k0 = s0 < 0 ? (int)(-s0) : 0;
+    long k1 = n_in - s0;
+    if (k1 > klen) k1 = klen;
+    for (int k = k0; k < k1; ++k) acc = fmaf(xc[s0 + k], b[k], acc);
+    y[i] = acc;
+}
+hipError_t launch_resample_poly(const float* x, long n_in, const float* bank, int up, int down, int klen, int width, float* y,
+                                long n_out, int channels, hipStream_t st) {
+    const long n = n_out * channels;
+    if (n <= 0) return hipSuccess;
+    ProfScope ps(st, "resample_poly", 2.0 * n * klen, 4.0 * (n + (double)n_in * channels));
+    hipLaunchKernelGGL(resample_poly_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, x, n_in, bank, up, down, klen,
+                       width, y, n_out, channels);
+    LAUNCH_CHECK();
+}
+
+// float [-1, 1] -> int16: clamp, scale by 32767, round to nearest even (reference server audio.rs:22-37; tryme.py:29 PCM_16)
+__global__ void pcm16_kernel(const float* __restrict__ x, int16_t* __restrict__ y, long n) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float v = fminf(fmaxf(x[i], -1.0f), 1.0f) * 32767.0f;
+    y[i] = (int16_t)__float2int_rn(v);
+}
+hipError_t launch_pcm16(const float* x, int16_t* y, long n, hipStream_t st) {
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(pcm16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, x, y, n);
+    LAUNCH_CHECK();
+}

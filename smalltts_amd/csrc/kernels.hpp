@@ -135,3 +135,8 @@ hipError_t launch_splitk_resid(const float* part, int S, float* x, const float* 
 // zero pad frames.
 hipError_t launch_mixer_fused(const float* xin, float* xout, const float* norm_w, const float* w, const float* bias,
                               const float* gamma, int B, int T, int C, int K, int pad, float eps, hipStream_t st);
+
+// device-side audio helpers (kernels.hip): polyphase resampler with a caller-built bank [up][klen], float -> PCM16
+hipError_t launch_resample_poly(const float* x, long n_in, const float* bank, int up, int down, int klen, int width, float* y,
+                                long n_out, int channels, hipStream_t st);
+hipError_t launch_pcm16(const float* x, int16_t* y, long n, hipStream_t st);

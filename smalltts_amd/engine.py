@@ -39,6 +39,7 @@ class HipEngine:
         self._ws_named: Dict[str, torch.Tensor] = {}
         self._ws_slot: Optional[str] = None   # set via use_workspace(): separate scratch per concurrent stream
         self.codec_spec: CodecSpec = DEFAULT_CODEC
+        self._banks: Dict[tuple, tuple] = {}   # (down, up) -> (polyphase bank on the device, width)
         self.set_precision(precision)
 
     # ---- plumbing ------------------------------------------------------------------------------
@@ -246,6 +247,41 @@ class HipEngine:
         out = torch.empty(n, device=self.device)
         self._ck(self.lib.smtts_randn(self.h, self._stream(), _p(out), n, C.c_uint64(seed), C.c_uint64(stream_id)), "randn")
         return out
+
+    # ---- device-side audio front / back end ---------------------------------------------------------
+    def resample(self, audio, sr: int, target: int = 24_000) -> torch.Tensor:
+        """(samples,) or (channels, samples) float -> resampled on the device (same bank as audio.resample_hq)."""
+        import math
+        from .audio import _sinc_kernel
+        x = self._dev(torch.as_tensor(audio, dtype=torch.float32), torch.float32)
+        squeeze = x.dim() == 1
+        if squeeze:
+            x = x[None]
+        x = x.contiguous()
+        if sr == target:
+            return x[0] if squeeze else x
+        g = math.gcd(int(sr), int(target))
+        down, up = sr // g, target // g
+        key = (down, up)
+        bank = self._banks.get(key)
+        if bank is None:
+            k, width = _sinc_kernel(down, up)
+            bank = (torch.from_numpy(k).to(self.device).contiguous(), width)
+            self._banks[key] = bank
+        kern, width = bank
+        n_in = x.shape[-1]
+        n_out = int(math.ceil(up * n_in / down))
+        y = torch.empty(x.shape[0], n_out, device=self.device)
+        self._ck(self.lib.smtts_resample_poly(self.h, self._stream(), _p(x), x.shape[0], n_in, _p(kern), up, down,
+                                              kern.shape[1], width, _p(y), n_out), "resample_poly")
+        return y[0] if squeeze else y
+
+    def pcm16(self, audio) -> torch.Tensor:
+        """float [-1, 1] (any shape) -> int16 PCM on the device (clamp, x 32767, round to nearest)."""
+        x = self._dev(torch.as_tensor(audio, dtype=torch.float32), torch.float32).contiguous()
+        y = torch.empty(x.shape, dtype=torch.int16, device=self.device)
+        self._ck(self.lib.smtts_pcm16(self.h, self._stream(), _p(x), x.numel(), _p(y)), "pcm16")
+        return y
 
     def profile(self, on, tagged: bool = False):
         """on: False/True; tagged=True prefixes kernel names with the pipeline phase (enc, mod, dit, dec.s<i> ...)."""

@@ -26,10 +26,14 @@ def tokens_for(args, text: str):
     return get_token_ids(text, backend=args.tokenizer)
 
 
-def load_reference_wav(path: str) -> np.ndarray:
-    """-> mono float32 @ 24 kHz, shape (1, 1, S) (clone.py:29-33)."""
+def load_reference_wav(path: str, engine=None) -> np.ndarray:
+    """-> mono float32 @ 24 kHz, shape (1, 1, S) (clone.py:29-33).  With an engine the resampling runs on the
+    device (smtts_resample_poly); the host numpy restatement is the fallback-free CPU path of the same filter."""
     y, sr = read_wav(path)
     if y.ndim == 2:
         y = y.mean(axis=1)
-    y = resample_hq(y.astype(np.float32), sr, 24_000)
+    if engine is not None:
+        y = engine.resample(y.astype(np.float32), sr, 24_000).cpu().numpy()
+    else:
+        y = resample_hq(y.astype(np.float32), sr, 24_000)
     return y[None, None, :]

@@ -39,7 +39,7 @@ def main(argv=None):
     pairs = list(zip(files, TEXTS))
     refs = []
     for fpath, _ in pairs:
-        refs.append(enc.encode_reference(torch.from_numpy(load_reference_wav(str(fpath))))[0].numpy())
+        refs.append(enc.encode_reference(torch.from_numpy(load_reference_wav(str(fpath), enc.engine)))[0].numpy())
     toks = [get_token_ids(t, backend=args.tokenizer) for _, t in pairs]
     durs = [estimate_duration(t) for _, t in pairs]
     audios = tts.synthesize_batch(refs, toks, durs)

@@ -20,10 +20,11 @@ def main(argv=None):
     args = ap.parse_args(argv)
     Path(args.out).parent.mkdir(parents=True, exist_ok=True)
     print("loading")
-    x = load_reference_wav(args.wav)
-    print("encoding reference audio")
     kw = dict(weights=args.weights, device=args.device, precision=args.precision)
-    ref_latents = Encoder(**kw).encode_reference(torch.from_numpy(x))[0].numpy()
+    enc = Encoder(**kw)
+    x = load_reference_wav(args.wav, enc.engine)
+    print("encoding reference audio")
+    ref_latents = enc.encode_reference(torch.from_numpy(x))[0].numpy()
     tts = SmallTTS(num_steps=args.steps, seed=args.seed, **kw)
     tokens = tokens_for(args, args.text)
     duration = args.duration or estimate_duration(args.text)

@@ -223,3 +223,29 @@ def test_randn_matches_oracle_philox(eng):
     assert np.abs(got - ref).max() < 2e-5
     big = eng.randn(1 << 20, seed=1, stream_id=0).cpu().numpy()
     assert abs(big.mean()) < 5e-3 and abs(big.std() - 1) < 5e-3
+
+
+@pytest.mark.parametrize("sr,target", [(16000, 24000), (44100, 24000), (48000, 24000), (22050, 24000)])
+def test_device_resampler_matches_host_restatement(eng, sr, target):
+    """the device polyphase resampler against the numpy restatement of torchaudio's Resample."""
+    from smalltts_amd.audio import resample_hq
+    rng = np.random.default_rng(sr)
+    t = np.arange(int(0.37 * sr)) / sr
+    x = (0.5 * np.sin(2 * np.pi * 440 * t) + 0.05 * rng.standard_normal(t.size)).astype(np.float32)
+    want = resample_hq(x, sr, target)
+    got = eng.resample(x, sr, target).cpu().numpy()
+    assert got.shape == want.shape
+    assert rel_l2(got, want) < 2e-6
+    two = eng.resample(np.stack([x, -x]), sr, target).cpu().numpy()
+    assert two.shape == (2, want.size) and rel_l2(two[1], -want) < 2e-6
+    assert torch.equal(eng.resample(x, target, target).cpu(), torch.from_numpy(x))
+
+
+def test_device_pcm16_is_bit_exact_with_the_wav_writer(eng, tmp_path):
+    from smalltts_amd.audio import read_wav, write_wav_pcm16
+    rng = np.random.default_rng(5)
+    x = np.concatenate([rng.uniform(-1.3, 1.3, 5000), [0.0, 1.0, -1.0, 0.5 / 32767, 1.5 / 32767, -2.5 / 32767]]).astype(np.float32)
+    write_wav_pcm16(str(tmp_path / "a.wav"), x)
+    host = np.frombuffer(open(tmp_path / "a.wav", "rb").read()[44:], "<i2")
+    dev = eng.pcm16(x).cpu().numpy()
+    assert dev.dtype == np.int16 and np.array_equal(dev, host)
