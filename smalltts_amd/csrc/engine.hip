@@ -35,6 +35,7 @@ Engine::Engine(int device) : device_(device) {
     const char* s = getenv("SMTTS_SINGLE_STREAM");
     if (s && *s == '1') dual_stream_ = false;
     if ((s = getenv("SMTTS_KSPLIT_OUT")) && atoi(s) >= 1 && atoi(s) <= kSplitK) ksplit_out_ = atoi(s);
+    if ((s = getenv("SMTTS_KSPLIT_ENC")) && atoi(s) >= 1 && atoi(s) <= kSplitK) ksplit_enc_ = atoi(s);
     if ((s = getenv("SMTTS_KSPLIT_FF2")) && atoi(s) >= 1 && atoi(s) <= kSplitK) ksplit_ff2_ = atoi(s);
 }
 
@@ -551,6 +552,8 @@ struct NextLN {  // optional: the AdaLN that follows the residual, fused into th
     const float* scale = nullptr;
     bf16_t* yhi = nullptr;
     bf16_t* ylo = nullptr;
+    bool rms = false;   // true: RMSNorm with weight `shift` (encoders) instead of LayerNorm * (1 + scale) + shift
+    float eps = 1e-6f;
 };
 static hipError_t gemm3_resid_splitk(const Gemm3Operands& g0, const EpiResid<0>& r, float* partial, int splits, int split,
                                      hipStream_t st, const NextLN& ln = NextLN()) {
@@ -563,7 +566,7 @@ static hipError_t gemm3_resid_splitk(const Gemm3Operands& g0, const EpiResid<0>&
     if (err != hipSuccess) return err;
     if (ln.shift)
         return launch_splitk_resid_ln(partial, used, r.x, r.bias, r.gate, r.gld, r.grow0, r.grstride, r.rows_per_batch,
-                                      r.rowmask, g.M, g.N, 1e-6f, ln.shift, ln.scale, ln.yhi, ln.ylo, st);
+                                      r.rowmask, g.M, g.N, ln.eps, ln.shift, ln.scale, ln.yhi, ln.ylo, st, ln.rms);
     return launch_splitk_resid(partial, used, r.x, r.bias, r.gate, r.gld, r.grow0, r.grstride, r.rows_per_batch, r.rowmask,
                                g.M, g.N, st);
 }
@@ -574,10 +577,11 @@ static hipError_t gemm3_resid_splitk(const Gemm3Operands& g0, const EpiResid<0>&
 // ---------------------------------------------------------------------------------------------
 namespace {
 struct EncWs {
-    float *x, *qkvg, *seq;
+    float *x, *qkvg, *seq, *part;
     SplitBuf y, o, ffh, seqs;
     void plan(Bump& b, int Mx) {
         x = b.take<float>((size_t)Mx * 512);
+        part = b.take<float>((size_t)kSplitK * Mx * 512);
         qkvg = b.take<float>((size_t)Mx * 2048);
         seq = b.take<float>((size_t)Mx * kHidden);
         y = take_split(b, (size_t)Mx * 512);
@@ -589,11 +593,15 @@ struct EncWs {
 }  // namespace
 
 int Engine::run_encoder(hipStream_t st, const EncoderW& e, void* wsv, int B, int S, const uint8_t* key_mask) {
+    // On return w.y holds RMSNorm(x; final_norm) as a split pair: every norm except the first is fused into the
+    // split-K reduction of the residual GEMM in front of it (the tiny-M projections get 4x the workgroups that way).
     EncWs& w = *static_cast<EncWs*>(wsv);
     const int M = B * S, D = e.dim;
     const RowMap rd = rowmap_plain(D);
-    for (const EncBlockW& b : e.blocks) {
-        HIPC(launch_rmsnorm(w.x, rd, nullptr, w.y.hi, w.y.lo, rd, M, D, e.eps, b.an, st));
+    if (e.blocks.empty()) return fail("encoder without blocks");
+    HIPC(launch_rmsnorm(w.x, rd, nullptr, w.y.hi, w.y.lo, rd, M, D, e.eps, e.blocks[0].an, st));
+    for (size_t l = 0; l < e.blocks.size(); ++l) {
+        const EncBlockW& b = e.blocks[l];
         HIPC(gemm3_store(ops3(w.y, rd, b.qkvg, M), ACT_NONE, store_to(w.qkvg, rowmap_plain(4 * D), nullptr), 1, split_, st));
         AttnArgs a{};
         a.q = w.qkvg; a.k = w.qkvg + D; a.v = w.qkvg + 2 * D; a.gate = w.qkvg + 3 * D;
@@ -607,11 +615,22 @@ int Engine::run_encoder(hipStream_t st, const EncoderW& e, void* wsv, int B, int
         HIPC(launch_qk_prep(a, st));
         HIPC(attn_mfma_ ? launch_attention_mfma(a, st) : launch_attention(a, st));
         EpiResid<0> r1{w.x, rd, nullptr, nullptr, 0, 0, 0, 1, nullptr};
-        HIPC(gemm3_resid(ops3(w.o, rd, b.wo, M), 0, r1, split_, st));
-        HIPC(launch_rmsnorm(w.x, rd, nullptr, w.y.hi, w.y.lo, rd, M, D, e.eps, b.mn, st));
+        NextLN n1{b.mn, nullptr, w.y.hi, w.y.lo, true, e.eps};
+        if (ksplit_enc_ > 1) {
+            HIPC(gemm3_resid_splitk(ops3(w.o, rd, b.wo, M), r1, w.part, ksplit_enc_, split_, st, n1));
+        } else {
+            HIPC(gemm3_resid(ops3(w.o, rd, b.wo, M), 0, r1, split_, st));
+            HIPC(launch_rmsnorm(w.x, rd, nullptr, w.y.hi, w.y.lo, rd, M, D, e.eps, n1.shift, st));
+        }
         EpiSwiGLU sw{nullptr, e.ff, nullptr, nullptr, w.ffh.hi, w.ffh.lo};
         HIPC(gemm3_swiglu(ops3(w.y, rd, b.ff13, M), sw, split_, st));
-        HIPC(gemm3_resid(ops3(w.ffh, rowmap_plain(e.ff), b.w2, M), 0, r1, split_, st));
+        NextLN n2{l + 1 < e.blocks.size() ? e.blocks[l + 1].an : e.final_norm, nullptr, w.y.hi, w.y.lo, true, e.eps};
+        if (ksplit_enc_ > 1) {
+            HIPC(gemm3_resid_splitk(ops3(w.ffh, rowmap_plain(e.ff), b.w2, M), r1, w.part, ksplit_enc_, split_, st, n2));
+        } else {
+            HIPC(gemm3_resid(ops3(w.ffh, rowmap_plain(e.ff), b.w2, M), 0, r1, split_, st));
+            HIPC(launch_rmsnorm(w.x, rd, nullptr, w.y.hi, w.y.lo, rd, M, D, e.eps, n2.shift, st));
+        }
     }
     return 0;
 }
@@ -664,8 +683,7 @@ int Engine::cond_encode(hipStream_t st, const float* ref, const int64_t* ref_len
     if (P > 0) {
         const int M = B * P;
         HIPC(launch_embedding(ids, rawp("phoneme_embedding.text_embedding.weight"), wt.x, M, 512, 198, stt));
-        if (run_encoder(stt, text_, &wt, B, P, ph_mask)) return 1;
-        HIPC(launch_rmsnorm(wt.x, r512, nullptr, wt.y.hi, wt.y.lo, r512, M, 512, text_.eps, text_.final_norm, stt));
+        if (run_encoder(stt, text_, &wt, B, P, ph_mask)) return 1;  // leaves RMSNorm(x; final_norm) in wt.y
         float* mem = mem_out ? mem_out : wt.seq;
         HIPC(gemm3_store(ops3(wt.y, r512, phproj_, M), ACT_NONE,
                          store_to(mem, rh, rawp("dit.phoneme_proj.bias"), 1.f, ph_mask), 1, split_, stt));
@@ -681,8 +699,7 @@ int Engine::cond_encode(hipStream_t st, const float* ref, const int64_t* ref_len
         HIPC(launch_len_mask(ref_len, ref_mask, B, R, st));
         HIPC(gemm_store(ops(ref, rowmap_plain(kLatent), style_in_, M), ACT_NONE,
                         store_to(w.x, r512, rawp("style_encoder.in_proj.bias"), style_scale_), 1, split_, st));
-        if (run_encoder(st, style_, &w, B, R, ref_mask)) return 1;
-        HIPC(launch_rmsnorm(w.x, r512, nullptr, w.y.hi, w.y.lo, r512, M, 512, style_.eps, style_.final_norm, st));
+        if (run_encoder(st, style_, &w, B, R, ref_mask)) return 1;  // leaves RMSNorm(x; final_norm) in w.y
         float* seq = ref_seq_out ? ref_seq_out : w.seq;
         HIPC(gemm3_store(ops3(w.y, r512, style_out_, M), ACT_NONE,
                          store_to(seq, rh, rawp("style_encoder.out_proj.bias"), 1.f, ref_mask), 1, split_, st));

@@ -168,6 +168,7 @@ class Engine {
     std::vector<void*> allocs_;
     int split_ = 3;
     bool fused_ffn_ = true;  // test hook: smtts_test_set_fused_ffn
+    int ksplit_enc_ = 4;  // split-K of the encoders' residual projections (1 = fused-epilogue GEMM + separate RMSNorm)
     int ksplit_out_ = 3, ksplit_ff2_ = 3;  // (<= kSplitK; 150 tiles x 3 = 450 workgroups = one round at 2 per CU) split-K factors of the two N = 960 DiT projections (1 = fused epilogue)
     bool dual_stream_ = true;  // cond_encode: text encoder on a side stream (SMTTS_SINGLE_STREAM=1 turns it off)
     hipStream_t aux_ = nullptr;

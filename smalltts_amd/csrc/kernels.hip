@@ -602,7 +602,7 @@ __global__ __launch_bounds__(256) void splitk_resid_kernel(const float* __restri
 }
 // splitk_resid followed by the NEXT AdaLN (ln_modulate) in one pass over the row: one wave per row, the updated
 // residual row stays in registers for the LayerNorm.  Same arithmetic order as the two separate kernels.
-template <int NV4>
+template <int NV4, bool RMS>
 __global__ __launch_bounds__(256) void splitk_resid_ln_kernel(const float* __restrict__ part, int S, float* __restrict__ x,
                                                               const float* __restrict__ bias, const float* __restrict__ gate,
                                                               long gld, int grow0, int grstride, int rpb,
@@ -616,8 +616,9 @@ __global__ __launch_bounds__(256) void splitk_resid_ln_kernel(const float* __res
     const long MN4 = (long)M * C4;
     const long mrow = (long)(grow0 + (row / rpb) * grstride) * gld;
     float4* xr = reinterpret_cast<float4*>(x + (long)row * C);
-    const float4* sh4 = reinterpret_cast<const float4*>(shift + mrow);
-    const float4* sc4 = reinterpret_cast<const float4*>(scale + mrow);
+    // RMS mode (encoders): `shift` is the RMSNorm weight [C], `scale` is unused; otherwise AdaLN rows of the modulation table
+    const float4* sh4 = reinterpret_cast<const float4*>(RMS ? shift : shift + mrow);
+    const float4* sc4 = reinterpret_cast<const float4*>(RMS ? shift : scale + mrow);
     // every load of the row is issued up front and unconditionally (the row-mask byte only selects afterwards), so
     // the kernel is one memory round trip + two wave reductions
     const uint8_t mk = rowmask ? rowmask[row] : (uint8_t)1;
@@ -651,6 +652,22 @@ __global__ __launch_bounds__(256) void splitk_resid_ln_kernel(const float* __res
         }
         if (c >= C4) v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
+    if (RMS) {
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV4; ++i) q += v[i].x * v[i].x + v[i].y * v[i].y + v[i].z * v[i].z + v[i].w * v[i].w;
+        const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)C + eps);
+#pragma unroll
+        for (int i = 0; i < NV4; ++i) {
+            const int c = lane + 64 * i;
+            if (c < C4) {
+                const float4 o = make_float4(v[i].x * rstd * sh[i].x, v[i].y * rstd * sh[i].y, v[i].z * rstd * sh[i].z,
+                                             v[i].w * rstd * sh[i].w);
+                store_split4(yhi, ylo, (long)row * C + c * 4, o);
+            }
+        }
+        return;
+    }
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < NV4; ++i) s += v[i].x + v[i].y + v[i].z + v[i].w;
@@ -679,11 +696,16 @@ __global__ __launch_bounds__(256) void splitk_resid_ln_kernel(const float* __res
 
 hipError_t launch_splitk_resid_ln(const float* part, int S, float* x, const float* bias, const float* gate, long gld,
                                   int grow0, int grstride, int rows_per_batch, const uint8_t* rowmask, int M, int N, float eps,
-                                  const float* shift, const float* scale, bf16_t* yhi, bf16_t* ylo, hipStream_t st) {
+                                  const float* shift, const float* scale, bf16_t* yhi, bf16_t* ylo, hipStream_t st, bool rms) {
     if (N > 1024 || N % 4 || gld % 4) return hipErrorInvalidValue;
-    ProfScope ps(st, "splitk_resid_ln", 1.0 * M * N * (S + 10), 4.0 * M * N * (S + 3));
-    hipLaunchKernelGGL(splitk_resid_ln_kernel<4>, dim3((M + 3) / 4), dim3(256), 0, st, part, S, x, bias, gate, gld, grow0,
-                       grstride, rows_per_batch, rowmask, M, N, eps, shift, scale, yhi, ylo);
+    ProfScope ps(st, rms ? "splitk_resid_rms" : "splitk_resid_ln", 1.0 * M * N * (S + 10), 4.0 * M * N * (S + 3));
+    const dim3 grid((M + 3) / 4), block(256);
+    if (rms)
+        hipLaunchKernelGGL((splitk_resid_ln_kernel<4, true>), grid, block, 0, st, part, S, x, bias, gate, gld, grow0, grstride,
+                           rows_per_batch, rowmask, M, N, eps, shift, scale, yhi, ylo);
+    else
+        hipLaunchKernelGGL((splitk_resid_ln_kernel<4, false>), grid, block, 0, st, part, S, x, bias, gate, gld, grow0, grstride,
+                           rows_per_batch, rowmask, M, N, eps, shift, scale, yhi, ylo);
     LAUNCH_CHECK();
 }
 

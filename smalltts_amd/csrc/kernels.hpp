@@ -124,7 +124,8 @@ hipError_t launch_w2_tile_pack(const bf16_t* in, bf16_t* out, int C, int F, hipS
 // split-K reduce + gated residual, then LayerNorm * (1 + scale) + shift of the updated row -> split bf16 (the next AdaLN)
 hipError_t launch_splitk_resid_ln(const float* part, int S, float* x, const float* bias, const float* gate, long gld,
                                   int grow0, int grstride, int rows_per_batch, const uint8_t* rowmask, int M, int N, float eps,
-                                  const float* shift, const float* scale, bf16_t* yhi, bf16_t* ylo, hipStream_t st);
+                                  const float* shift, const float* scale, bf16_t* yhi, bf16_t* ylo, hipStream_t st,
+                                  bool rms = false /* true: y = RMSNorm(x; weight = shift, eps), encoders */);
 hipError_t launch_splitk_resid(const float* part, int S, float* x, const float* bias, const float* gate, long gld,
                                int grow0, int grstride, int rows_per_batch, const uint8_t* rowmask, int M, int N,
                                hipStream_t st);
