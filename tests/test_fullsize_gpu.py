@@ -70,6 +70,22 @@ def test_full_spec_decode_10s_vs_oracle(eng, golden_seed):
     assert torch.equal(g2[0], got[0]) and torch.equal(g2[1, :, :40 * 3200], got[0, :, :40 * 3200])
 
 
+@pytest.mark.parametrize("B,T", [(1, 1), (3, 2), (2, 5)])
+def test_full_spec_decode_odd_frame_counts_vs_oracle(eng, golden_seed, B, T):
+    """Partial tiles of the fused FFN kernels: at T = 1 the C = 256 stage has 200 frames (1.56 passes of 128), the
+    C = 32 stage 3200; B = 3, T = 2 and B = 2, T = 5 leave ragged last waves / passes at every stage."""
+    wd = O.to_torch(synth_state_dict(codec_decoder_param_specs(DEFAULT_CODEC), golden_seed))
+    lat = torch.randn(B, T, 64, generator=torch.Generator().manual_seed(40 + T))
+    with torch.no_grad():
+        ref = CO.decode(wd, lat, DEFAULT_CODEC)
+    got = eng.codec_decode(lat).cpu()
+    assert tuple(got.shape) == (B, 1, 3200 * T)
+    s = snr_db(got.numpy(), ref.numpy())
+    assert s > 60.0, f"B={B} T={T}: decode SNR {s:.1f} dB"
+    one = eng.codec_decode(lat[:1]).cpu()
+    assert torch.equal(one[0], got[0])          # batch invariance with ragged tiles
+
+
 def test_codec_is_bitwise_repeatable_and_batch_invariant(eng):
     """Races in the fused LDS kernels show up as run-to-run or batch-size dependent bits (a missing lgkmcnt drain
     before a raw s_barrier did exactly that)."""
