@@ -975,8 +975,10 @@ int Engine::sample(hipStream_t st, int mode, int n_steps, int cfg, float s_text,
         ts[i] = linspace10(i, n_steps);
         alpha_sigma_host(ts[i], al[i], sg[i]);
     }
-    HIPC(hipMemcpyAsync(s.ts, ts.data(), n_steps * sizeof(float), hipMemcpyHostToDevice, st));
-    HIPC(hipStreamSynchronize(st));  // ts lives on the host stack
+    // the same float32(np.linspace(1, 0, n)) values, generated on the device: a host -> device copy of the stack array would
+    // need a stream synchronisation here, which drains the queue and leaves the GPU waiting on kernel launches for the
+    // first DiT block of every batch (~0.1-0.5 ms of idle time in the rocprof timeline)
+    HIPC(launch_linspace10(s.ts, n_steps, st));
     // t is shared by the whole batch -> every AdaLN vector of every step in one pass (SURVEY §7 hard part 3)
     if (modulation(st, s.ts, n_steps, m.sinb, m.t1, m.temb, m.e1, m.semb, m.mod)) return 1;
 

@@ -847,3 +847,18 @@ hipError_t launch_pcm16(const float* x, int16_t* y, long n, hipStream_t st) {
     hipLaunchKernelGGL(pcm16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, x, y, n);
     LAUNCH_CHECK();
 }
+
+// t[i] = float32(np.linspace(1, 0, n))[i]: float64 arithmetic, exact end point (reference infer/onnx.py:98)
+__global__ void linspace10_kernel(float* __restrict__ t, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float v = 1.0f;
+    // numpy: arange(n) * step + start, two separately rounded float64 operations (no fused multiply-add)
+    if (n > 1) v = i == n - 1 ? 0.0f : (float)__dadd_rn(1.0, __dmul_rn(-1.0 / (double)(n - 1), (double)i));
+    t[i] = v;
+}
+hipError_t launch_linspace10(float* t, int n, hipStream_t st) {
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(linspace10_kernel, dim3((n + 255) / 256), dim3(256), 0, st, t, n);
+    LAUNCH_CHECK();
+}

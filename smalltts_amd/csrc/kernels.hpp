@@ -141,3 +141,5 @@ hipError_t launch_mixer_fused(const float* xin, float* xout, const float* norm_w
 hipError_t launch_resample_poly(const float* x, long n_in, const float* bank, int up, int down, int klen, int width, float* y,
                                 long n_out, int channels, hipStream_t st);
 hipError_t launch_pcm16(const float* x, int16_t* y, long n, hipStream_t st);
+// t[i] = float32(np.linspace(1, 0, n))[i] on the device (sampler timesteps)
+hipError_t launch_linspace10(float* t, int n, hipStream_t st);
