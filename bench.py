@@ -250,6 +250,20 @@ def main():
                 tk = json.load(f).get("by_prof_name", {})
             if top["name"] in tk:
                 res["roofline"]["traffic"] = tk[top["name"]]
+        # rocprofv3 average of the same kernel class from the committed summary (the HIP-event pair adds ~1.5 us per launch)
+        spath = os.path.join(ROOT, "profiles", "kernel_stats_latest.csv")
+        if os.path.exists(spath):
+            import csv
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            from prof_names import prof_name
+            us = calls = 0.0
+            with open(spath) as f:
+                for r in csv.DictReader(f):
+                    if prof_name(r["kernel"]) == top["name"]:
+                        us += float(r["total_us"])
+                        calls += float(r["calls"])
+            if calls:
+                res["roofline"]["rocprof_avg_us"] = round(us / calls, 3)
         res["kernel_breakdown"] = [
             {"name": r["name"], "launches_per_step": r["launches"] // reps, "ms_per_step": round(r["ms"] / reps, 4),
              "TFLOPs": round(r["flops"] / max(r["ms"], 1e-9) / 1e9, 2), "GBs": round(r["bytes"] / max(r["ms"], 1e-9) / 1e6, 1)}

@@ -1,0 +1,30 @@
+"""Map a rocprofv3 kernel name to the name bench.py's in-process profiler gives the same kernel class, so the
+rocprof averages / PMC traffic committed under profiles/ can be quoted next to the HIP-event numbers."""
+import re
+
+_EPI3 = {"EpiStore<0>": "store", "EpiStore<1>": "store_silu", "EpiStore<2>": "store_gelu", "EpiStore<3>": "store_mish",
+         "EpiSwiGLU": "swiglu", "EpiResid<0>": "resid", "EpiResid<1>": "resid_gate", "EpiResid<2>": "resid_layerscale",
+         "EpiKV": "kv_scatter", "EpiConvPos<0>": "convpos", "EpiConvPos<1>": "convpos_final"}
+
+
+def prof_name(kernel: str):
+    k = kernel.strip()
+    k = k[5:] if k.startswith("void ") else k
+    m = re.match(r"gemm3_kernel<(\d+), (\d+), \d+, \d+, (\d), \d+, (Epi\w+(?:<\d>)?) ?>", k)
+    if m:
+        return f"gemm3<{m.group(1)}x{m.group(2)},s{m.group(3)},{_EPI3.get(m.group(4), m.group(4))}>"
+    m = re.match(r"gemm_kernel<(\d+), (\d+), (\d+), \d+, \d+, (\d), (Epi\w+(?:<\d>)?) ?>", k)
+    if m:
+        return f"gemm<{m.group(1)}x{m.group(2)}x{m.group(3)},s{m.group(4)},{_EPI3.get(m.group(5), m.group(5))}>"
+    m = re.match(r"codec_ffn_(stream|wave)_kernel<(\d+),", k)
+    if m:
+        return f"codec_ffn_{m.group(1)}<{m.group(2)}>"
+    m = re.match(r"(attention_mfma|attention|qk_prep)_kernel<(\d+)>", k)
+    if m:
+        return f"{m.group(1)}<{m.group(2)}>" if m.group(1) == "attention_mfma" else m.group(1)
+    if "splitk_resid_ln_kernel" in k:
+        return "splitk_resid_rms" if "Lb1E" in k or ", true>" in k else "splitk_resid_ln"
+    m = re.match(r"([a-z0-9_]+)_kernel\b", k)
+    if m:
+        return m.group(1)
+    return None

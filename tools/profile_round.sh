@@ -12,3 +12,4 @@ rocprofv3 --kernel-trace --pmc FETCH_SIZE -d gpurun_out/${TAG}_fetch -o f --outp
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d gpurun_out/${TAG}_write -o w --output-format csv -- $CMD --no-roofline > /dev/null 2> gpurun_out/${TAG}_write.err
 python tools/rocpd_summary.py $(ls gpurun_out/${TAG}_trace/*.db | head -1) gpurun_out/${TAG}_kernel_stats.csv
 python tools/pmc_traffic.py gpurun_out/${TAG}_fetch/f_counter_collection.csv gpurun_out/${TAG}_write/w_counter_collection.csv gpurun_out/${TAG}_traffic.json
+# copy into profiles/ by hand:  *_kernel_stats.csv (+ as kernel_stats_latest.csv), *_traffic.json (+ as traffic_latest.json), bench JSONs
