@@ -6,12 +6,13 @@
 // hipcc --offload-arch=gfx950 -O3 tools/ubench/lds_contention.hip -o /tmp/lds_contention && /tmp/lds_contention
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstdlib>
 #define LPTR(p) ((__attribute__((address_space(3))) void*)(p))
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 __global__ __launch_bounds__(768) void k(const char* __restrict__ buf, size_t bytes, int iters, int readers, int dmas, unsigned* sink,
-                                         unsigned long long* cycles, int mf, int mfmode, int prio) {
+                                         unsigned long long* cycles, int mf, int mfmode, int prio, int bar) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -33,8 +34,16 @@ __global__ __launch_bounds__(768) void k(const char* __restrict__ buf, size_t by
         const int d = wave - readers;
         const unsigned lds0 = (unsigned)(size_t)LPTR(smem) + 65536 + d * 8192;
         size_t pos = ((size_t)blockIdx.x * dmas + d) * 8192 + lane * 16;
-        const int dit = mf ? iters * 6 : iters;
+        const int dit = bar ? iters : (mf ? iters * 6 : iters);
         for (int it = 0; it < dit; ++it) {
+            if (bar) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                const char* p2 = buf + ((pos + 4096) & (bytes - 1));   // second half of the 16 pieces
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(p2 + u * 1024), "s"(lds0 + 32768 + u * 1024) : "memory", "m0");
+            }
             const char* p = buf + (pos & (bytes - 1));
             pos += (size_t)gridDim.x * dmas * 8192;
 #pragma unroll
@@ -51,6 +60,7 @@ __global__ __launch_bounds__(768) void k(const char* __restrict__ buf, size_t by
         for (int e = 0; e < 8; ++e) { a[e] = (__bf16)(float)(lane + e); b[e] = (__bf16)(float)(lane - e); }
         const char* base = smem + lane * 16;
         for (int it = 0; it < iters; ++it) {
+            if (bar) __builtin_amdgcn_s_barrier();
             if (mfmode == 3) {  // gemm-like: 6 fragment reads + 6 MFMAs (two accumulators) per step, 4 steps
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
@@ -81,7 +91,7 @@ __global__ __launch_bounds__(768) void k(const char* __restrict__ buf, size_t by
 }
 
 int main() {
-    const size_t bytes = 2u << 20;
+    const size_t bytes = (size_t)(getenv("UB_MB") ? atoi(getenv("UB_MB")) : 2) << 20;  // power of two: 2 = L2-resident, 512 = HBM
     char* buf; hipMalloc(&buf, bytes + (1 << 20)); hipMemset(buf, 1, bytes + (1 << 20));
     unsigned* sink; hipMalloc(&sink, 4);
     unsigned long long* cyc; hipMalloc(&cyc, 128);
@@ -89,10 +99,11 @@ int main() {
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     const int iters = 4000;
     struct Cfg { int r, d, mf, mode, prio; } cfgs[] = {{4, 0, 0, 0, 0}, {0, 4, 0, 0, 0}, {4, 4, 0, 0, 0}, {0, 0, 8, 3, 0}, {0, 4, 8, 3, 0},
-                                                       {0, 4, 8, 3, 1}, {0, 2, 8, 3, 0}, {0, 4, 4, 3, 0}, {0, 0, 4, 3, 0}};
+                                                       {0, 4, 8, 3, 1}, {0, 2, 8, 3, 0}, {0, 4, 4, 3, 0}, {0, 0, 4, 3, 0},
+                                                       {0, 0, 8, 3, 2}, {0, 4, 8, 3, 2}};  // prio 2 = one s_barrier per k-tile-sized step
     for (auto c : cfgs) {
         const int threads = (c.r + c.d + c.mf) * 64;
-        auto run = [&]() { hipLaunchKernelGGL(k, dim3(256), dim3(threads), 128 * 1024 + 8192, 0, buf, bytes, iters, c.r, c.d, sink, cyc, c.mf, c.mode, c.prio); };
+        auto run = [&]() { hipLaunchKernelGGL(k, dim3(256), dim3(threads), 128 * 1024 + 8192, 0, buf, bytes, iters, c.r, c.d, sink, cyc, c.mf, c.mode, c.prio == 1, c.prio == 2); };
         run(); hipDeviceSynchronize();
         hipEventRecord(e0); run(); hipEventRecord(e1); hipEventSynchronize(e1);
         float ms; hipEventElapsedTime(&ms, e0, e1);
@@ -104,7 +115,7 @@ int main() {
         // per-stream rates from the waves' own elapsed time (block 0; s_memtime ticks at 100 MHz): streams finish at different times
         const double t_r = c.r ? hc[0] * 10e-9 : 0, t_d = c.d ? hc[c.r] * 10e-9 : 0, t_m = c.mf ? hc[c.r + c.d] * 10e-9 : 0;
         printf("readers %d dma %d mfma %d (mode %d, prio %d): %6.3f ms | ds_read %6.1f GB/s/CU | lds-dma %6.1f GB/s/CU | mfma %6.1f TF/s chip-equivalent\n",
-               c.r, c.d, c.mf, c.mode, c.prio, ms, t_r ? c.r * iters * 16384.0 / t_r / 1e9 : 0.0, t_d ? c.d * (c.mf ? 6.0 : 1.0) * iters * 8192.0 / t_d / 1e9 : 0.0,
+               c.r, c.d, c.mf, c.mode, c.prio, ms, t_r ? c.r * iters * 16384.0 / t_r / 1e9 : 0.0, t_d ? c.d * ((c.mf && c.prio != 2) ? 6.0 : (c.prio == 2 ? 2.0 : 1.0)) * iters * 8192.0 / t_d / 1e9 : 0.0,
                t_m ? c.mf * iters * 24 * 32768.0 * 256 / t_m / 1e12 : 0.0);
     }
     return 0;
