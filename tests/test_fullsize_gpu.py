@@ -54,6 +54,23 @@ def test_sampler_vs_oracle_at_range_edges(eng, dit_weights, B, N, R, P, ragged):
     assert err < 1e-4, f"B={B} N={N} R={R} P={P}: latent rel L2 {err:.3e}"
 
 
+@pytest.mark.parametrize("steps", [1, 2, 7])
+def test_sampler_other_step_counts_vs_oracle(eng, dit_weights, steps):
+    """NUM_STEPS is a constant in the reference (4) but a parameter of the operator: linspace(1, 0, n) incl. n = 1 (t = 1 only)."""
+    B, N, R, P = 2, 20, 9, 17
+    ref, rl, ids, pm, mask, _ = _inputs(B, N, R, P, seed=300 + steps, ragged=True)
+    noise = torch.randn(steps, B, N, 64, generator=torch.Generator().manual_seed(steps))
+    with torch.no_grad():
+        oc = O.encode_conditions(dit_weights, ref, rl, ids, pm)
+        keep = []
+        ox = O.sample_dmd(dit_weights, oc, pm, mask, noise, steps, keep=keep)
+    x, per_step = eng.sample(eng.cond_encode(ref, rl, ids, pm), mask, num_steps=steps, noise=noise, return_steps=True)
+    m = mask.numpy()
+    assert rel_l2(x.cpu().numpy()[m], ox.numpy()[m]) < 1e-4
+    for i in range(steps):   # every intermediate x-hat, not just the last
+        assert rel_l2(per_step[i].cpu().numpy()[m], keep[i].numpy()[m]) < 1e-4, f"step {i}"
+
+
 def test_full_spec_decode_10s_vs_oracle(eng, golden_seed):
     """The bench's codec workload per utterance: 75 frames -> 240000 samples through the 344 M-parameter decoder."""
     wd = O.to_torch(synth_state_dict(codec_decoder_param_specs(DEFAULT_CODEC), golden_seed))
