@@ -119,15 +119,13 @@ int smtts_profile_report(smtts_handle h, char* buf, size_t cap);
 /* ---- single-kernel test hooks (used by tests/ to check kernels in isolation) -------------------- */
 /* C[M,N] = A[M,K] (f32, lda) * W[N,K]^T (f32 host-layout on device, split internally) + bias ; act as ACT_* */
 /* microbenchmark of one GEMM launch configuration (epi: 0 store, 1 store+gelu, 2 swiglu, 3 tanh-gated residual) */
-int smtts_bench_gemm(smtts_handle h, int M, int N, int K, int epi, int split, int cfg, int iters, int ver /* kernel generation 1|2|3 */,
+int smtts_bench_gemm(smtts_handle h, int M, int N, int K, int epi, int split, int cfg, int iters, int ver /* kernel generation 1 (fp32 A, register-staged) | 3 (gemm3) */,
                      float* avg_us);
 /* hot-path kernel (gemm3: split-bf16 A and W via DMA ring): C[M,N] = act(A W^T + bias); A, W fp32 on device, split internally; K % 64 == 0 */
 int smtts_test_gemm3(smtts_handle h, void* stream, const float* A, const float* W, const float* bias, int M, int N, int K,
                      int act, int split, int cfg, float* C);
 /* codec blocks: 1 (default) = fused mixer and fused FFN kernels (C <= 256), 0 = separate norm / conv / two-GEMM path */
 int smtts_test_set_fused_ffn(smtts_handle h, int on);
-/* fp32-A GEMMs (cold paths): 1 (default) = register-staged v1 kernel, 0 = v2 DMA-ring kernel (A/B tests) */
-int smtts_test_force_gemm_v1(int on);
 int smtts_test_gemm(smtts_handle h, void* stream, const float* A, int lda, const float* W, const float* bias, int M,
                     int N, int K, int act, int split, int cfg, float* C, int ldc);
 int smtts_test_swiglu(smtts_handle h, void* stream, const float* A, const float* W1, const float* W3, const float* b1,

@@ -146,7 +146,6 @@ int smtts_test_gemm3(smtts_handle h, void* stream, const float* A, const float* 
 }
 int smtts_test_set_fused_ffn(smtts_handle h, int on) { E.set_fused_ffn(on != 0); return 0; }
 int smtts_test_set_attention_mfma(smtts_handle h, int on) { E.set_attn_mfma(on != 0); return 0; }
-int smtts_test_force_gemm_v1(int on) { g_gemm_force_v1 = on; return 0; }
 
 // ---- test hooks -------------------------------------------------------------------------------
 int smtts_test_gemm(smtts_handle h, void* stream, const float* A, int lda, const float* W, const float* bias, int M,

@@ -88,3 +88,10 @@ __device__ __forceinline__ void store_split4(bf16_t* hi, bf16_t* lo, long off, c
     *reinterpret_cast<bf16x4*>(hi + off) = h;
     if (lo) *reinterpret_cast<bf16x4*>(lo + off) = l;
 }
+
+// LDS pointer for direct-to-LDS DMA operands and a counted wait on this wave's outstanding vector-memory operations
+#define SM_LPTR(p) ((__attribute__((address_space(3))) void*)(p))
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}

@@ -29,7 +29,6 @@ inline std::string sidx(const std::string& a, int i, const std::string& b) { ret
 
 thread_local Profiler* g_prof = nullptr;
 thread_local const char* g_prof_tag = nullptr;
-int g_gemm_force_v1 = 1;  // fp32-A GEMMs (cold paths) use the register-staged v1 kernel; 0 routes them to the v2 DMA kernel
 
 Engine::Engine(int device) : device_(device) {
     const char* s = getenv("SMTTS_SINGLE_STREAM");
@@ -1324,8 +1323,6 @@ int Engine::bench_gemm(int M, int N, int K, int epi, int split, int cfg, int ite
     HIPC(hipSetDevice(device_));
     float *A = nullptr, *Wf = nullptr, *C = nullptr, *bias = nullptr, *gate = nullptr;
     bf16_t *hi = nullptr, *lo = nullptr, *ahi = nullptr, *alo = nullptr;
-    const int saved_force = g_gemm_force_v1;
-    g_gemm_force_v1 = ver == 1;
     HIPC(hipMalloc(&ahi, (size_t)M * K * 2));
     HIPC(hipMalloc(&alo, (size_t)M * K * 2));
     HIPC(hipMalloc(&A, (size_t)M * K * 4));
@@ -1376,6 +1373,5 @@ int Engine::bench_gemm(int M, int N, int K, int epi, int split, int cfg, int ite
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     for (void* p : {(void*)A, (void*)Wf, (void*)C, (void*)bias, (void*)gate, (void*)hi, (void*)lo, (void*)ahi, (void*)alo})
         (void)hipFree(p);
-    g_gemm_force_v1 = saved_force;
     return 0;
 }

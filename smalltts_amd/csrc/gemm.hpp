@@ -39,7 +39,7 @@ __device__ __forceinline__ void split4(const float4& v, uint2& hi, uint2& lo) {
 
 
 struct RowCtx;
-// Shared accumulator write-out for gemm_kernel / gemm2_kernel.  mw0 / nw0 = first row / column of this wave.
+// Shared accumulator write-out for gemm_kernel / gemm3_kernel.  mw0 / nw0 = first row / column of this wave.
 template <int TM, int TN, class Epi>
 __device__ __forceinline__ void gemm_epilogue(const Epi& epi, floatx16 (&acc)[TM][TN], int M, int N, int mw0, int nw0,
                                               int z, int lane);

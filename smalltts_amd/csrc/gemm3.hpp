@@ -11,7 +11,7 @@
 // * 8 waves (2 per SIMD) per workgroup so one wave's LDS latency hides under the other's MFMAs.
 // Requires K % 64 == 0, 16-B aligned rows.  Epilogue functors are shared with gemm.hpp.
 #pragma once
-#include "gemm2.hpp"
+#include "gemm.hpp"
 
 struct Gemm3Operands {
     const bf16_t* Ahi;

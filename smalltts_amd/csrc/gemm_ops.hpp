@@ -11,9 +11,8 @@ static inline std::string gemm_prof_name(const GemmOperands& g, bool paired, int
     if (cfg < 0) cfg = gemm_pick_cfg(g.M, g.N, g.K, paired);
     static const char* tiles[] = {"64x128x64", "64x64x64", "128x128x64", "128x32x64", "128x64x64"};
     std::string t = tiles[cfg];
-    const bool v2 = !g_gemm_force_v1 && gemm2_ok(g);
-    if (!v2 && cfg == CFG_128x64 && g.K <= 32) t = "128x64x32";
-    return std::string(v2 ? "gemm2<" : "gemm<") + t + ",s" + std::to_string(split) + "," + epi + ">";
+    if (cfg == CFG_128x64 && g.K <= 32) t = "128x64x32";
+    return std::string("gemm<") + t + ",s" + std::to_string(split) + "," + epi + ">";
 }
 // algorithmic work of one GEMM launch: 2*M*N*K flops (x Z); bytes = A fp32 read once + W (bf16 hi[+lo]) read
 // once + C fp32 written once (+ read once for residual epilogues)

@@ -9,9 +9,9 @@ hipError_t gemm_resid(const GemmOperands& g, int gate_mode, const EpiResid<0>& p
     ProfScope ps(st, gemm_prof_name(g, false, cfg, split, names[gate_mode % 3]), gemm_flops(g, 1),
                  gemm_bytes(g, 1, split, 2.0));
     switch (gate_mode) {
-        case 0: return gemm_dispatch(g, p, 1, split, st, cfg);
-        case 1: return gemm_dispatch(g, conv<1>(p), 1, split, st, cfg);
-        case 2: return gemm_dispatch(g, conv<2>(p), 1, split, st, cfg);
+        case 0: return gemm_launch(g, p, 1, split, st, cfg);
+        case 1: return gemm_launch(g, conv<1>(p), 1, split, st, cfg);
+        case 2: return gemm_launch(g, conv<2>(p), 1, split, st, cfg);
     }
     return hipErrorInvalidValue;
 }

@@ -9,10 +9,10 @@ hipError_t gemm_store(const GemmOperands& g, int act, const EpiStore<ACT_NONE>& 
     ProfScope ps(st, gemm_prof_name(g, false, cfg, split, names[act & 3]), gemm_flops(g, Z),
                  gemm_bytes(g, Z, split, 1.0));
     switch (act) {
-        case ACT_NONE: return gemm_dispatch(g, p, Z, split, st, cfg);
-        case ACT_SILU: return gemm_dispatch(g, conv<ACT_SILU>(p), Z, split, st, cfg);
-        case ACT_GELU: return gemm_dispatch(g, conv<ACT_GELU>(p), Z, split, st, cfg);
-        case ACT_MISH: return gemm_dispatch(g, conv<ACT_MISH>(p), Z, split, st, cfg);
+        case ACT_NONE: return gemm_launch(g, p, Z, split, st, cfg);
+        case ACT_SILU: return gemm_launch(g, conv<ACT_SILU>(p), Z, split, st, cfg);
+        case ACT_GELU: return gemm_launch(g, conv<ACT_GELU>(p), Z, split, st, cfg);
+        case ACT_MISH: return gemm_launch(g, conv<ACT_MISH>(p), Z, split, st, cfg);
     }
     return hipErrorInvalidValue;
 }
