@@ -93,19 +93,21 @@ def cpu_baseline(cores):
     pm = torch.ones(B, P_TOK, dtype=torch.bool)
     mask = torch.ones(B, N_FRAMES, dtype=torch.bool)
     noise = torch.randn(DMD_STEPS, B, N_FRAMES, 64, generator=g)
+    t_dit = t_dec1 = float("inf")
     with torch.no_grad():
-        t0 = time.perf_counter()
-        cache = O.encode_conditions(w, ref, torch.full((B,), R_FRAMES), ids, pm)
-        x = O.sample_dmd(w, cache, pm, mask, noise, DMD_STEPS)
-        t_dit = time.perf_counter() - t0
-        t0 = time.perf_counter()
-        CO.decode(wd, x[:1], DEFAULT_CODEC)
-        t_dec1 = time.perf_counter() - t0
+        for _ in range(3):   # best of 3: the first pass pays page faults / thread-pool start-up (~10 s of CPU work in all)
+            t0 = time.perf_counter()
+            cache = O.encode_conditions(w, ref, torch.full((B,), R_FRAMES), ids, pm)
+            x = O.sample_dmd(w, cache, pm, mask, noise, DMD_STEPS)
+            t_dit = min(t_dit, time.perf_counter() - t0)
+            t0 = time.perf_counter()
+            CO.decode(wd, x[:1], DEFAULT_CODEC)
+            t_dec1 = min(t_dec1, time.perf_counter() - t0)
     total = t_dit + B * t_dec1
     return {"value": round(B * AUDIO_SEC_PER_UTT / total, 3), "unit": "audio-seconds/sec", "cores": cores,
             "kind": "port",
             "sample": f"CPU oracle (torch fp32): cond-encode + 4 DMD steps on the full 8x10s batch ({t_dit:.2f} s) + "
-                      f"codec decode of 1 of 8 utterances ({t_dec1:.2f} s, scaled x8); stands in for the reference's "
+                      f"codec decode of 1 of 8 utterances ({t_dec1:.2f} s, scaled x8), best of 3 passes; stands in for the reference's "
                       "ORT-CPU path, which cannot run offline",
             "dit_seconds": round(t_dit, 3), "codec_decode_seconds_per_utt": round(t_dec1, 3)}
 
