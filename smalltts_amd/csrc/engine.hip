@@ -27,10 +27,12 @@ struct Bump {  // bump allocator over a caller-owned workspace (also used, with 
 inline std::string sidx(const std::string& a, int i, const std::string& b) { return a + std::to_string(i) + b; }
 }  // namespace
 
+int g_gemm3_nfast = 1;  // gemm3 tile order: N fastest when M > N (SMTTS_GEMM_NFAST=0 restores M fastest everywhere)
 thread_local Profiler* g_prof = nullptr;
 thread_local const char* g_prof_tag = nullptr;
 
 Engine::Engine(int device) : device_(device) {
+    if (const char* nf = getenv("SMTTS_GEMM_NFAST")) g_gemm3_nfast = atoi(nf);
     const char* s = getenv("SMTTS_SINGLE_STREAM");
     if (s && *s == '1') dual_stream_ = false;
     if ((s = getenv("SMTTS_KSPLIT_OUT")) && atoi(s) >= 1 && atoi(s) <= kSplitK) ksplit_out_ = atoi(s);

@@ -23,6 +23,7 @@ struct Gemm3Operands {
     int M, N, K;
     long a_z, w_z;
     int w_zmod;
+    int nfast = 0;     // tile order inside an XCD's run: 0 = M fastest, 1 = N fastest (set by gemm3_launch)
     int ksplit_tiles;  // > 0: blockIdx.z is a split-K index; this launch slice covers k-tiles [z*ksplit_tiles, +ksplit_tiles)
 };
 
@@ -53,8 +54,8 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm3_kernel(Gemm3Operands g, Epi
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
     // XCD-aware tile order (workgroup p runs on XCD p % 8, each XCD has its own L2): give every XCD a
-    // contiguous run of virtual tile ids, M-tile fastest, so all M-tiles that share one W panel (and the
-    // activation rows they stream) hit the same L2 instead of re-fetching the panel on 8 XCDs.
+    // contiguous run of virtual tile ids so tiles that share an operand panel hit the same L2 instead of
+    // re-fetching it on 8 XCDs.
     const int Mt = (g.M + BM - 1) / BM, Nt = (g.N + BN - 1) / BN;
     int vid;
     {
@@ -62,7 +63,12 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm3_kernel(Gemm3Operands g, Epi
         const int q = tot / 8, r = tot % 8, xcd = p % 8, loc = p / 8;
         vid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
     }
-    const int m0 = (vid % Mt) * BM, n0 = (vid / Mt) * BN, z = blockIdx.z;
+    // Which index runs fastest decides what stays hot in the XCD's L2 while the run is walked: M fastest keeps the weight
+    // panel (right when W is the big operand: the small-M DiT products); N fastest keeps the A rows and re-streams the
+    // (small, L2 / MALL resident) weights — right for the tall codec products, where M-fastest re-read all of A from HBM
+    // once per N-tile (PMC: 896 MB per launch against 250 MB of operands at 24000 x 2048 x 512).
+    const bool nfast = g.nfast;
+    const int m0 = (nfast ? vid / Nt : vid % Mt) * BM, n0 = (nfast ? vid % Nt : vid / Mt) * BN, z = blockIdx.z;
     const int zb = g.ksplit_tiles ? 0 : z;  // batch index (split-K launches are unbatched)
     const long wz = (long)(g.w_zmod ? zb % g.w_zmod : zb) * g.w_z;
 
@@ -285,11 +291,15 @@ static inline hipError_t gemm3_launch_split(const Gemm3Operands& g, const Epi& e
 }
 
 template <class Epi>
-static inline hipError_t gemm3_launch(const Gemm3Operands& g, const Epi& epi, int Z, int split, hipStream_t st,
+static inline hipError_t gemm3_launch(const Gemm3Operands& g_in, const Epi& epi, int Z, int split, hipStream_t st,
                                       int cfg = -1) {
-    if (g.M <= 0 || g.N <= 0) return hipSuccess;
-    if (!gemm3_ok(g)) return hipErrorInvalidValue;
-    if (cfg < 0) cfg = gemm3_pick_cfg(g.M, g.N, Epi::PAIRED);
+    const Gemm3Operands& g0 = g_in;
+    if (g0.M <= 0 || g0.N <= 0) return hipSuccess;
+    if (!gemm3_ok(g0)) return hipErrorInvalidValue;
+    if (cfg < 0) cfg = gemm3_pick_cfg(g0.M, g0.N, Epi::PAIRED);
+    extern int g_gemm3_nfast;
+    Gemm3Operands g = g_in;
+    g.nfast = g_gemm3_nfast && (long)g.M > (long)g.N;  // the bigger operand streams, the smaller stays in L2
     if (split == 3) return gemm3_launch_split<3, Epi>(g, epi, Z, cfg, st);
     return gemm3_launch_split<1, Epi>(g, epi, Z, cfg, st);
 }
