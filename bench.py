@@ -120,7 +120,10 @@ def main():
     ap.add_argument("--precision", default="bf16x3", choices=["bf16x3", "bf16"])
     ap.add_argument("--workload", default="dmd4", choices=list(WORKLOADS),
                     help="dmd4 = the headline configuration; clone / teacher128 = BASELINE.json configs[2] / configs[4]")
-    ap.add_argument("--pipeline", action="store_true", help="overlap latent phase of batch i+1 with codec decode of batch i")
+    ap.add_argument("--no-pipeline", dest="pipeline", action="store_false",
+                    help="one batch at a time on one stream (default: two batches in flight — the latent phase of batch i+1 "
+                         "runs on a second HIP stream while the codec decode of batch i is in flight)")
+    ap.set_defaults(pipeline=True)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
@@ -158,10 +161,11 @@ def main():
         torch.cuda.synchronize()
 
     def run_steps(n, seed0):
-        """n full passes. --pipeline (dmd4 only): the latent phase (cond-encode + sampler: small, latency-bound grids)
-        of batch i+1 runs on a second stream while the codec decode (huge grids) of batch i is in flight; every batch
-        still goes through the whole path inside the timed region, only consecutive batches overlap."""
-        if not (args.pipeline and args.workload == "dmd4"):
+        """n full passes.  Pipelined (default; dmd4 / clone): the latent phase (codec encode of the reference for clone,
+        cond-encode, sampler: small, latency-bound grids that leave CUs idle) of batch i+1 runs on a second stream while
+        the codec decode (huge grids) of batch i is in flight; every batch still goes through the whole path inside the
+        timed region, only consecutive batches overlap."""
+        if not (pipelined and args.workload in ("dmd4", "clone")):
             out = None
             for i in range(n):
                 out = one_step(eng, inp, seed0 + i, gather, args.workload)
@@ -174,8 +178,10 @@ def main():
             if i < n:
                 with torch.cuda.stream(s_lat):
                     eng.use_workspace("latent")
-                    cache = eng.cond_encode(inp["ref"], inp["ref_len"], inp["ids"], inp["ph_mask"])
+                    ref = eng.codec_encode(inp["ref_wav"]) if args.workload == "clone" else inp["ref"]
+                    cache = eng.cond_encode(ref, inp["ref_len"], inp["ids"], inp["ph_mask"])
                     x = eng.sample(cache, inp["mask"], num_steps=DMD_STEPS, seed=seed0 + i)
+                    x.record_stream(s_dec)   # allocated on s_lat, read on s_dec: keep the allocator from recycling it early
                     ev = torch.cuda.Event(); ev.record(s_lat)
             if pending is not None:
                 px, pev = pending
@@ -191,12 +197,24 @@ def main():
         cur.wait_stream(s_lat); cur.wait_stream(s_dec)
         return out
 
+    pipelined = bool(args.pipeline)
     run_steps(args.warmup, 0)
     barrier()
     t0 = time.perf_counter()
     out = run_steps(args.steps, 100)
     barrier()
     dt = time.perf_counter() - t0
+    seq_ms = None
+    if pipelined and args.workload in ("dmd4", "clone"):   # also report one-batch-at-a-time latency (not the metric)
+        pipelined = False
+        ns = max(3, min(args.steps, 10))
+        run_steps(1, 50)
+        barrier()
+        t1 = time.perf_counter()
+        run_steps(ns, 60)
+        barrier()
+        seq_ms = 1e3 * (time.perf_counter() - t1) / ns
+        pipelined = True
     if dist is not None:
         tmax = torch.tensor([dt], device=device if backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -215,8 +233,11 @@ def main():
         "config": {"workload": WORKLOADS[args.workload] + ", B=8 x 10 s per GPU "
                                "(N=75 frames, R=15 ref frames, P=30 tokens; reference bench.rs workload)",
                    "global_batch": n_gpus * B, "utterance_seconds": AUDIO_SEC_PER_UTT, "sampler_steps": 128 if args.workload == "teacher128" else DMD_STEPS,
-                   "parallelism": f"dp{n_gpus} (utterance shards, waveform all-gather)" if n_gpus > 1 else "single GPU"},
+                   "parallelism": f"dp{n_gpus} (utterance shards, waveform all-gather)" if n_gpus > 1 else "single GPU",
+                   "batches_in_flight": 2 if (pipelined and args.workload in ("dmd4", "clone")) else 1},
     }
+    if seq_ms is not None:
+        res["sequential_ms_per_step"] = round(seq_ms, 3)   # one batch at a time on one stream (latency of a batch)
 
     if rank == 0 and not args.no_roofline:
         # per-kernel HIP-event timing on the launch stream, separate (untimed) passes
