@@ -120,10 +120,10 @@ def main():
     ap.add_argument("--precision", default="bf16x3", choices=["bf16x3", "bf16"])
     ap.add_argument("--workload", default="dmd4", choices=list(WORKLOADS),
                     help="dmd4 = the headline configuration; clone / teacher128 = BASELINE.json configs[2] / configs[4]")
-    ap.add_argument("--no-pipeline", dest="pipeline", action="store_false",
-                    help="one batch at a time on one stream (default: two batches in flight — the latent phase of batch i+1 "
-                         "runs on a second HIP stream while the codec decode of batch i is in flight)")
-    ap.set_defaults(pipeline=True)
+    ap.add_argument("--in-flight", type=int, default=3,
+                    help="independent batches in flight on one GPU: batch i runs, whole, on HIP stream i %% IN_FLIGHT with its own "
+                         "workspace (default 3; 1 = one batch at a time on one stream)")
+    ap.add_argument("--no-pipeline", dest="in_flight", action="store_const", const=1, help="same as --in-flight 1")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
@@ -160,61 +160,47 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def run_steps(n, seed0):
-        """n full passes.  Pipelined (default; dmd4 / clone): the latent phase (codec encode of the reference for clone,
-        cond-encode, sampler: small, latency-bound grids that leave CUs idle) of batch i+1 runs on a second stream while
-        the codec decode (huge grids) of batch i is in flight; every batch still goes through the whole path inside the
-        timed region, only consecutive batches overlap."""
-        if not (pipelined and args.workload in ("dmd4", "clone")):
+    def run_steps(n, seed0, in_flight):
+        """n full passes of the hot path, each over its own batch of 8.  With in_flight > 1 consecutive batches are issued
+        round-robin to that many HIP streams (one workspace each): the latency-bound phases of one batch (condition
+        encoders, DiT: grids of 30-190 workgroups on 256 CUs) fill the CUs another batch's kernels leave idle.  Every batch
+        still goes through the whole path inside the timed region; nothing is shared between batches but the weights."""
+        if in_flight <= 1:
             out = None
             for i in range(n):
                 out = one_step(eng, inp, seed0 + i, gather, args.workload)
             return out
-        s_lat, s_dec = torch.cuda.Stream(device), torch.cuda.Stream(device)
         cur = torch.cuda.current_stream(device)
-        s_lat.wait_stream(cur); s_dec.wait_stream(cur)
-        pending, out = None, None
-        for i in range(n + 1):
-            if i < n:
-                with torch.cuda.stream(s_lat):
-                    eng.use_workspace("latent")
-                    ref = eng.codec_encode(inp["ref_wav"]) if args.workload == "clone" else inp["ref"]
-                    cache = eng.cond_encode(ref, inp["ref_len"], inp["ids"], inp["ph_mask"])
-                    x = eng.sample(cache, inp["mask"], num_steps=DMD_STEPS, seed=seed0 + i)
-                    x.record_stream(s_dec)   # allocated on s_lat, read on s_dec: keep the allocator from recycling it early
-                    ev = torch.cuda.Event(); ev.record(s_lat)
-            if pending is not None:
-                px, pev = pending
-                with torch.cuda.stream(s_dec):
-                    s_dec.wait_event(pev)
-                    eng.use_workspace("decode")
-                    out = eng.codec_decode(px)
-                    if gather is not None:
-                        import torch.distributed as dist
-                        dist.all_gather_into_tensor(gather, out if gather.is_cuda else out.cpu())
-            pending = (x, ev) if i < n else None
+        for s_ in streams[:in_flight]:
+            s_.wait_stream(cur)
+        out = None
+        for i in range(n):
+            with torch.cuda.stream(streams[i % in_flight]):
+                eng.use_workspace(f"batch{i % in_flight}")
+                out = one_step(eng, inp, seed0 + i, gathers[i % in_flight] if gather is not None else None, args.workload)
         eng.use_workspace(None)
-        cur.wait_stream(s_lat); cur.wait_stream(s_dec)
+        for s_ in streams[:in_flight]:
+            cur.wait_stream(s_)
         return out
 
-    pipelined = bool(args.pipeline)
-    run_steps(args.warmup, 0)
+    in_flight = max(1, args.in_flight) if args.workload in ("dmd4", "clone") else 1
+    streams = [torch.cuda.Stream(device) for _ in range(in_flight)] if in_flight > 1 else []
+    gathers = [gather] + [torch.empty_like(gather) for _ in range(in_flight - 1)] if gather is not None else []  # one per slot
+    run_steps(args.warmup, 0, in_flight)
     barrier()
     t0 = time.perf_counter()
-    out = run_steps(args.steps, 100)
+    out = run_steps(args.steps, 100, in_flight)
     barrier()
     dt = time.perf_counter() - t0
     seq_ms = None
-    if pipelined and args.workload in ("dmd4", "clone"):   # also report one-batch-at-a-time latency (not the metric)
-        pipelined = False
+    if in_flight > 1:   # also report one-batch-at-a-time latency (not the metric)
         ns = max(3, min(args.steps, 10))
-        run_steps(1, 50)
+        run_steps(1, 50, 1)
         barrier()
         t1 = time.perf_counter()
-        run_steps(ns, 60)
+        run_steps(ns, 60, 1)
         barrier()
         seq_ms = 1e3 * (time.perf_counter() - t1) / ns
-        pipelined = True
     if dist is not None:
         tmax = torch.tensor([dt], device=device if backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -234,7 +220,7 @@ def main():
                                "(N=75 frames, R=15 ref frames, P=30 tokens; reference bench.rs workload)",
                    "global_batch": n_gpus * B, "utterance_seconds": AUDIO_SEC_PER_UTT, "sampler_steps": 128 if args.workload == "teacher128" else DMD_STEPS,
                    "parallelism": f"dp{n_gpus} (utterance shards, waveform all-gather)" if n_gpus > 1 else "single GPU",
-                   "batches_in_flight": 2 if (pipelined and args.workload in ("dmd4", "clone")) else 1},
+                   "batches_in_flight": in_flight},
     }
     if seq_ms is not None:
         res["sequential_ms_per_step"] = round(seq_ms, 3)   # one batch at a time on one stream (latency of a batch)
