@@ -100,7 +100,8 @@ class SmallTTS:
         return int(np.random.randint(0, 2 ** 31 - 1)) * 2654435761 % (2 ** 63)
 
     def synthesize_batch(self, ref_latents: Sequence[np.ndarray], phoneme_ids: Sequence[Sequence[int]],
-                         durations, *, noise: Optional[np.ndarray] = None, return_latents: bool = False):
+                         durations, *, noise: Optional[np.ndarray] = None, return_latents: bool = False,
+                         _defer: bool = False):
         """Batched synthesize: per-utterance (R_i,64) refs, token lists and durations -> list of (1, samples)."""
         B = len(ref_latents)
         if B == 0:
@@ -124,11 +125,44 @@ class SmallTTS:
         cache = eng.cond_encode(ref, np.asarray(rs, np.int64), ids, pm)
         x = eng.sample(cache, mask, num_steps=self.num_steps, noise=noise, seed=self._next_seed())
         audio = eng.codec_decode(x)                           # (B, 1, HOP * Nm); causal => prefixes are exact
+        if _defer:                                             # synthesize_batches: stay on the device / stream
+            return audio, x, ns
         audio = audio.cpu().numpy()
         outs = [audio[b, :, : HOP_SIZE * ns[b]] for b in range(B)]
         if return_latents:
             xl = x.cpu().numpy()
             return outs, [xl[b, : ns[b]] for b in range(B)]
+        return outs
+
+    def synthesize_batches(self, batches: Sequence[tuple], in_flight: int = 3) -> List[list]:
+        """Several independent batches, `in_flight` of them overlapping on the GPU.
+
+        batches: [(ref_latents, phoneme_ids, durations), ...] as for synthesize_batch.  Batch i runs whole on HIP stream
+        i % in_flight with its own workspace, so one batch's latency-bound phases (condition encoders, DiT) fill the
+        CUs another batch's kernels leave idle (bench.py: 16 ms per 8 x 10 s batch against 20 ms one at a time).
+        Results are identical to calling synthesize_batch in a loop with the same seeds."""
+        eng = self.engine
+        if in_flight <= 1 or len(batches) <= 1:
+            return [self.synthesize_batch(*b) for b in batches]
+        dev = eng.device
+        cur = torch.cuda.current_stream(dev)
+        streams = [torch.cuda.Stream(dev) for _ in range(min(in_flight, len(batches)))]
+        for st in streams:
+            st.wait_stream(cur)
+        pending = []
+        try:
+            for i, (refs, toks, durs) in enumerate(batches):
+                with torch.cuda.stream(streams[i % len(streams)]):
+                    eng.use_workspace(f"batch{i % len(streams)}")
+                    pending.append(self.synthesize_batch(refs, toks, durs, _defer=True))
+        finally:
+            eng.use_workspace(None)
+        for st in streams:
+            cur.wait_stream(st)
+        outs = []
+        for audio, _, ns in pending:
+            a = audio.cpu().numpy()
+            outs.append([a[b, :, : HOP_SIZE * ns[b]] for b in range(len(ns))])
         return outs
 
     def synthesize(self, ref_latents: np.ndarray, phoneme_ids: list, duration_sec: float) -> np.ndarray:

@@ -168,3 +168,20 @@ def test_batches_in_flight_equal_sequential(eng):
         cur.wait_stream(s)
     torch.cuda.synchronize()
     assert all(torch.equal(o.cpu(), s) for o, s in zip(outs, seq))
+
+
+def test_synthesize_batches_matches_a_loop_of_synthesize_batch(eng):
+    """Product-level entry for overlapped batches: same seeds, same audio as one batch after the other."""
+    from smalltts_amd.api import SmallTTS
+    rng = np.random.default_rng(21)
+    batches = []
+    for i in range(5):
+        n = 2 + i % 2
+        batches.append(([rng.standard_normal((3 + j, 64)).astype(np.float32) for j in range(n)],
+                        [[int(v) for v in rng.integers(1, 198, size=5 + j)] for j in range(n)], [0.4 + 0.3 * j for j in range(n)]))
+    a = SmallTTS(engine=eng, seed=5).synthesize_batches(batches, in_flight=3)
+    tts = SmallTTS(engine=eng, seed=5)
+    b = [tts.synthesize_batch(*x) for x in batches]
+    assert len(a) == len(b) == 5
+    for xa, xb in zip(a, b):
+        assert len(xa) == len(xb) and all(np.array_equal(u, v) for u, v in zip(xa, xb))
