@@ -173,12 +173,14 @@ def main():
         cur = torch.cuda.current_stream(device)
         for s_ in streams[:in_flight]:
             s_.wait_stream(cur)
+        eng.set_dual_stream(False)   # the engine's single side stream would serialise the text encoders of all batches in flight
         out = None
         for i in range(n):
             with torch.cuda.stream(streams[i % in_flight]):
                 eng.use_workspace(f"batch{i % in_flight}")
                 out = one_step(eng, inp, seed0 + i, gathers[i % in_flight] if gather is not None else None, args.workload)
         eng.use_workspace(None)
+        eng.set_dual_stream(True)
         for s_ in streams[:in_flight]:
             cur.wait_stream(s_)
         return out

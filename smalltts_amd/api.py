@@ -150,6 +150,7 @@ class SmallTTS:
         for st in streams:
             st.wait_stream(cur)
         pending = []
+        eng.set_dual_stream(False)   # the engine's own side stream would serialise the text encoders of all batches in flight
         try:
             for i, (refs, toks, durs) in enumerate(batches):
                 with torch.cuda.stream(streams[i % len(streams)]):
@@ -157,6 +158,7 @@ class SmallTTS:
                     pending.append(self.synthesize_batch(refs, toks, durs, _defer=True))
         finally:
             eng.use_workspace(None)
+            eng.set_dual_stream(True)
         for st in streams:
             cur.wait_stream(st)
         outs = []

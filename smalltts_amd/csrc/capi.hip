@@ -129,6 +129,7 @@ int smtts_pcm16(smtts_handle h, void* stream, const float* x, int64_t n, int16_t
     hipError_t e = launch_pcm16(x, y, n, ST(stream));
     return e == hipSuccess ? 0 : E.fail_hip(e, "pcm16");
 }
+int smtts_set_dual_stream(smtts_handle h, int on) { E.set_dual_stream(on != 0); return 0; }
 int smtts_profile_enable(smtts_handle h, int on) { E.profile_enable(on); return 0; }
 int smtts_profile_report(smtts_handle h, char* buf, size_t cap) {
     std::string r = E.profile_report();

@@ -92,6 +92,7 @@ class Engine {
     void set_precision(int split) { split_ = split == 1 ? 1 : 3; }
     void set_fused_ffn(bool on) { fused_ffn_ = on; }
     void set_attn_mfma(bool on) { attn_mfma_ = on; }
+    void set_dual_stream(bool on) { dual_stream_ = on; }
     int precision() const { return split_; }
 
     // ---- operators (device pointers, async on `st`) ------------------------------------------

@@ -82,6 +82,10 @@ class HipEngine:
             t = torch.from_numpy(t)
         return t.to(device=self.device, dtype=dtype).contiguous()
 
+    def set_dual_stream(self, on: bool):
+        """Text encoder of cond_encode on the engine's side stream (default) or inline on the caller's stream."""
+        self._ck(self.lib.smtts_set_dual_stream(self.h, int(bool(on))), "set_dual_stream")
+
     def set_precision(self, precision: str):
         self.precision = precision
         self._ck(self.lib.smtts_set_precision(self.h, PRECISION[precision]), "set_precision")
