@@ -185,7 +185,7 @@ def main():
             cur.wait_stream(s_)
         return out
 
-    in_flight = max(1, args.in_flight) if args.workload in ("dmd4", "clone") else 1
+    in_flight = max(1, args.in_flight)
     streams = [torch.cuda.Stream(device) for _ in range(in_flight)] if in_flight > 1 else []
     gathers = [gather] + [torch.empty_like(gather) for _ in range(in_flight - 1)] if gather is not None else []  # one per slot
     run_steps(args.warmup, 0, in_flight)
