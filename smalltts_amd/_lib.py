@@ -10,7 +10,7 @@ import re
 from typing import Dict, List, Tuple
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsmalltts_hip.so")
+LIB_PATH = os.environ.get("SMTTS_LIB") or os.path.join(_HERE, "libsmalltts_hip.so")  # SMTTS_LIB: A/B builds (csrc/Makefile)
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "smalltts_hip.h")
 
 _lib = None
