@@ -15,6 +15,7 @@
 #include "gemm3.hpp"
 #include "kernels.hpp"
 #include "prof.hpp"
+#include <type_traits>
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
@@ -123,7 +124,15 @@ __global__ __launch_bounds__(512) void codec_ffn_wave_kernel(FfnWaveArgs a) {
     int w1_off[KK1];
 #pragma unroll
     for (int kk = 0; kk < KK1; ++kk) w1_off[kk] = fr * RB1 + (((2 * kk + fh) ^ swz1(fr)) << 4);  // + t * 32 * RB1 (swz unchanged)
-    // W2 fragment: row 32*ot + fr, chunk c = 2*g + fh (g = global k16 step) -> ((c & ~15) | ((c ^ row) & 15)) << 4
+    // W2 fragment of (hidden tile t, k16 step s, channel tile ot): row 32 ot + fr, 16-B chunk c = 4 t + 2 s + fh, stored at
+    // ((c & ~15) | ((c ^ row) & 15)) << 4.  With c ^ row split into its low two bits (2 s + fh, t-free) and bits 2-3 (t & 3):
+    //   offset = w2_b[s] + w2_t(t) + ot * 32 * RB2,  w2_t(t) = (((t & 3) ^ ((fr >> 2) & 3)) << 6) + (t >> 2) * 256
+    int w2_b[2];
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) w2_b[s2] = fr * RB2 + (((2 * s2 + fh) ^ (fr & 3)) << 4);
+    const int rsw = (fr >> 2) & 3;
+    constexpr int W2LO = W_ARR;
+    constexpr int NPASS = SPLIT == 3 ? 3 : 1;
 
     const int ntiles = (a.M + 31) / 32;
     const int wg = blockIdx.x * 8 + wave, nwg = gridDim.x * 8;
@@ -175,93 +184,201 @@ __global__ __launch_bounds__(512) void codec_ffn_wave_kernel(FfnWaveArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc2[ot][r] = 0.f;
 
-#pragma unroll 1
-        for (int t = 0; t < NT1; ++t) {  // not unrolled: keeps the weight-fragment reads of different tiles from piling up in VGPRs
-            // ---- H^T tile t: hidden rows 32 t .. +32, this wave's 32 frames -------------------------------------
-            floatx16 acc1;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc1[r] = 0.f;
-            // fragment reads run one k16 step ahead of the MFMAs that consume them (the compiler keeps this order and counts
-            // lgkmcnt, so the LDS latency of step kk+1 hides under the three MFMAs of step kk)
-            bf16x8 w1f[2][2];  // [buffer kk & 1][hi | lo]: compile-time ping-pong, no register copies
-            w1f[0][0] = *reinterpret_cast<const bf16x8*>(smem + OFF_W1 + t * 32 * RB1 + w1_off[0]);
-            if (SPLIT == 3) w1f[0][1] = *reinterpret_cast<const bf16x8*>(smem + OFF_W1 + W_ARR + t * 32 * RB1 + w1_off[0]);
-#pragma unroll
-            for (int kk = 0; kk < KK1; ++kk) {
-                if (kk + 1 < KK1) {
-                    w1f[(kk + 1) & 1][0] = *reinterpret_cast<const bf16x8*>(smem + OFF_W1 + t * 32 * RB1 + w1_off[kk + 1]);
-                    if (SPLIT == 3) w1f[(kk + 1) & 1][1] = *reinterpret_cast<const bf16x8*>(smem + OFF_W1 + W_ARR + t * 32 * RB1 + w1_off[kk + 1]);
-                }
-                __builtin_amdgcn_sched_barrier(0);  // keep the reads above the MFMAs below
-                if (SPLIT == 3) {
-                    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1f[kk & 1][1], nh[kk], acc1, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1f[kk & 1][0], nl[kk], acc1, 0, 0, 0);
-                }
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1f[kk & 1][0], nh[kk], acc1, 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            // W2 fragments are read one (k16 step, channel tile) pair ahead as well; the first pair is requested before the
-            // GELU so it lands under it
-            auto w2_addr = [&](int ot, int s) {
-                const int c = 2 * (2 * t + s) + fh, row = 32 * ot + fr;  // 16-B chunk along the hidden (k) axis of W2
-                return smem + OFF_W2 + row * RB2 + (((c & ~15) | ((c ^ row) & 15)) << 4);
-            };
-            constexpr int W2LO = W_ARR;
-            bf16x8 w2f[2][2];  // [buffer][hi | lo], buffer = (s * NOT + ot) & 1
-            w2f[0][0] = *reinterpret_cast<const bf16x8*>(w2_addr(0, 0));
-            if (SPLIT == 3) w2f[0][1] = *reinterpret_cast<const bf16x8*>(w2_addr(0, 0) + W2LO);
-            __builtin_amdgcn_sched_barrier(0);
-            // ---- bias + GELU in place: row(r) = hidden 32 t + (r & 3) + 8 (r >> 2) + 4 fh -----------------------
+        // ---- software pipeline over the hidden tiles --------------------------------------------------------------
+        // On gfx950 v_pk_*_f32 instructions do not run next to MFMAs (they serialise with the matrix pipe, measured in
+        // tools/ubench/mfma_valu.hip) while plain VALU / transcendental instructions do.  One step therefore handles three
+        // hidden tiles at once: the MFMAs of the first product of tile t+1 and of the second product of tile t-1 carry the
+        // non-packed half of tile t's GELU + split in their shadow (rcp / exp2 under the former; the final fma, the bf16
+        // splits and the lane swaps under the latter), the packed polynomial runs between the two MFMA groups.
+        // sched_barrier(0) pins the source order, which IS the schedule: one MFMA, then its share of the VALU work.
+        struct Frags { bf16x8 h[2], l[2]; };   // B fragments (two k16 steps) of one GELU'd hidden tile
+        auto mfma3 = [&](floatx16& acc, const bf16x8 (&w)[2], const bf16x8& bh, const bf16x8& bl, int pass) {
+            // pass order: the two cross terms first, hi . hi last (as before)
+            if (SPLIT == 3 && pass == 0) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[1], bh, acc, 0, 0, 0);
+            else if (SPLIT == 3 && pass == 1) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[0], bl, acc, 0, 0, 0);
+            else acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[0], bh, acc, 0, 0, 0);
+        };
+        // accumulator row r of hidden tile t is hidden unit 32 t + (r & 3) + 8 (r >> 2) + 4 fh
+        auto bias_init = [&](floatx16& acc, int t) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const float4 bv = *reinterpret_cast<const float4*>(vb1 + 32 * t + 8 * q + 4 * fh);
-                f32x2 u0, u1;
-                u0.x = acc1[4 * q + 0] + bv.x; u0.y = acc1[4 * q + 1] + bv.y;
-                u1.x = acc1[4 * q + 2] + bv.z; u1.y = acc1[4 * q + 3] + bv.w;
-                u0 = gelu2(u0);
-                u1 = gelu2(u1);
-                acc1[4 * q + 0] = u0.x; acc1[4 * q + 1] = u0.y; acc1[4 * q + 2] = u1.x; acc1[4 * q + 3] = u1.y;
+                acc[4 * q + 0] = bv.x; acc[4 * q + 1] = bv.y; acc[4 * q + 2] = bv.z; acc[4 * q + 3] = bv.w;
             }
-            // ---- Out^T += W2[:, hidden tile t] . H^T tile: two k16 steps ---------------------------------------------
+        };
+        auto step = [&](auto do_p1, auto do_p2, int t, const floatx16& h, floatx16& accn, const Frags& prev, Frags& cur) {
+            constexpr bool P1 = decltype(do_p1)::value, P2 = decltype(do_p2)::value;
+            // fragment reads for the first MFMA group of each product, and the tile's bias
+            bf16x8 w1f[2][2], w2f[2][2];
+            const int w1t = (t + 1) * 32 * RB1;
+            const int w2t = (((t - 1) & 3) ^ rsw) * 64 + ((t - 1) >> 2) * 256;
+            if (P1) {
+                w1f[0][0] = *reinterpret_cast<const bf16x8*>(smem + OFF_W1 + w1t + w1_off[0]);
+                if (SPLIT == 3) w1f[0][1] = *reinterpret_cast<const bf16x8*>(smem + OFF_W1 + W_ARR + w1t + w1_off[0]);
+            }
+            if (P1) bias_init(accn, t + 1);  // the accumulators start from b1: no separate bias add
+            // ---- A (packed): exponent argument ----
+            f32x2 u[8], ea[8];
 #pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                const int r0 = 8 * s;
-                unsigned xh[2], yh[2], xl[2], yl[2];
+            for (int pr = 0; pr < 8; ++pr) {
+                u[pr].x = h[2 * pr]; u[pr].y = h[2 * pr + 1];
+                ea[pr] = (u[pr] * u[pr]) * (-0.5f * 1.4426950408889634f);  // exp(-z^2) = exp2(-x^2/2 log2 e)
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            // ---- B: first product of tile t+1 || t = 1 / (1 + p z), e = exp2(.) of the 16 values ----
+            f32x2 tt[8], ee[8];
+            auto trans = [&](int v) {
+                const float xv = (v & 1) ? u[v >> 1].y : u[v >> 1].x;
+                const float av = (v & 1) ? ea[v >> 1].y : ea[v >> 1].x;
+                const float tv = fast_rcp(fmaf(fabsf(xv), 0.3275911f * 0.70710678118654752f, 1.0f));
+                const float ev = __builtin_amdgcn_exp2f(av);
+                if (v & 1) { tt[v >> 1].y = tv; ee[v >> 1].y = ev; } else { tt[v >> 1].x = tv; ee[v >> 1].x = ev; }
+            };
+            if (P1) {
+                constexpr int NB = KK1 * NPASS;
 #pragma unroll
-                for (int e = 0; e < 2; ++e) {
-                    split_pair(acc1[r0 + 2 * e], acc1[r0 + 2 * e + 1], xh[e], xl[e]);
-                    split_pair(acc1[r0 + 4 + 2 * e], acc1[r0 + 4 + 2 * e + 1], yh[e], yl[e]);
+                for (int kk = 0; kk < KK1; ++kk) {
+                    if (kk + 1 < KK1) {
+                        w1f[(kk + 1) & 1][0] = *reinterpret_cast<const bf16x8*>(smem + OFF_W1 + w1t + w1_off[kk + 1]);
+                        if (SPLIT == 3) w1f[(kk + 1) & 1][1] = *reinterpret_cast<const bf16x8*>(smem + OFF_W1 + W_ARR + w1t + w1_off[kk + 1]);
+                    } else if (P2) {
+                        w2f[0][0] = *reinterpret_cast<const bf16x8*>(smem + OFF_W2 + w2_b[0] + w2t);
+                        if (SPLIT == 3) w2f[0][1] = *reinterpret_cast<const bf16x8*>(smem + OFF_W2 + W2LO + w2_b[0] + w2t);
+                    }
+#pragma unroll
+                    for (int ps = 0; ps < NPASS; ++ps) {
+                        const int j = kk * NPASS + ps;
+                        __builtin_amdgcn_sched_barrier(0);
+                        mfma3(accn, w1f[kk & 1], nh[kk], nl[kk], ps);
+#pragma unroll
+                        for (int v = 16 * j / NB; v < 16 * (j + 1) / NB; ++v) trans(v);
+                    }
                 }
-                // lane half 0 needs hidden 0..7 of the step, half 1 hidden 8..15: swap upper half of X with lower half of Y
+            } else {
+                if (P2) {
+                    w2f[0][0] = *reinterpret_cast<const bf16x8*>(smem + OFF_W2 + w2_b[0] + w2t);
+                    if (SPLIT == 3) w2f[0][1] = *reinterpret_cast<const bf16x8*>(smem + OFF_W2 + W2LO + w2_b[0] + w2t);
+                }
+#pragma unroll
+                for (int v = 0; v < 16; ++v) trans(v);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            // ---- C (packed): erfc polynomial, erf, x / 2 ----
+            f32x2 uu[8], hx[8];
+#pragma unroll
+            for (int pr = 0; pr < 8; ++pr) {
+                const f32x2 t2 = tt[pr];
+                const f32x2 poly = t2 * (0.254829592f + t2 * (-0.284496736f + t2 * (1.421413741f + t2 * (-1.453152027f + t2 * 1.061405429f))));
+                uu[pr] = 1.0f - poly * ee[pr];  // erf(z)
+                hx[pr] = 0.5f * u[pr];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            // ---- D: second product of tile t-1 || gelu = x/2 + |x/2| erf, bf16 split, lane swap -> fragments of tile t ----
+            unsigned hiP[8], loP[8];
+            auto finish = [&](int pr) {
+                const float rx = fmaf(fabsf(hx[pr].x), uu[pr].x, hx[pr].x);
+                const float ry = fmaf(fabsf(hx[pr].y), uu[pr].y, hx[pr].y);
+                hiP[pr] = cvt_pk_bf16(rx, ry);
+                if (SPLIT == 3) {
+                    f32x2 rr, hf;
+                    rr.x = rx; rr.y = ry;
+                    hf.x = __uint_as_float(hiP[pr] << 16); hf.y = __uint_as_float(hiP[pr] & 0xffff0000u);
+                    const f32x2 lo2 = rr - hf;
+                    loP[pr] = cvt_pk_bf16(lo2.x, lo2.y);
+                }
+            };
+            auto swap_half = [&](int s2) {
+                // lane half 0 needs hidden 0..7 of the k16 step, half 1 hidden 8..15: swap upper half of X with lower half of Y
                 unsigned fhh[4], fll[4];
 #pragma unroll
                 for (int e = 0; e < 2; ++e) {
-                    auto rh = __builtin_amdgcn_permlane32_swap(xh[e], yh[e], false, false);
+                    auto rh = __builtin_amdgcn_permlane32_swap(hiP[4 * s2 + e], hiP[4 * s2 + 2 + e], false, false);
                     fhh[e] = rh[0]; fhh[2 + e] = rh[1];
                     if (SPLIT == 3) {
-                        auto rl = __builtin_amdgcn_permlane32_swap(xl[e], yl[e], false, false);
+                        auto rl = __builtin_amdgcn_permlane32_swap(loP[4 * s2 + e], loP[4 * s2 + 2 + e], false, false);
                         fll[e] = rl[0]; fll[2 + e] = rl[1];
                     }
                 }
-                const bf16x8 ph = __builtin_bit_cast(bf16x8, *reinterpret_cast<uint4*>(fhh));
-                bf16x8 pl;
-                if (SPLIT == 3) pl = __builtin_bit_cast(bf16x8, *reinterpret_cast<uint4*>(fll));
+                cur.h[s2] = __builtin_bit_cast(bf16x8, *reinterpret_cast<uint4*>(fhh));
+                if (SPLIT == 3) cur.l[s2] = __builtin_bit_cast(bf16x8, *reinterpret_cast<uint4*>(fll));
+            };
+            if (P2) {
+                constexpr int ND = 2 * NOT * NPASS;
 #pragma unroll
-                for (int ot = 0; ot < NOT; ++ot) {
-                    const int cur = (s * NOT + ot) & 1, nxt = cur ^ 1;
-                    if (ot + 1 < NOT || s == 0) {
-                        const char* nx = ot + 1 < NOT ? w2_addr(ot + 1, s) : w2_addr(0, 1);
-                        w2f[nxt][0] = *reinterpret_cast<const bf16x8*>(nx);
-                        if (SPLIT == 3) w2f[nxt][1] = *reinterpret_cast<const bf16x8*>(nx + W2LO);
+                for (int g = 0; g < 2 * NOT; ++g) {
+                    const int s2 = g / NOT, ot = g % NOT;
+                    if (g + 1 < 2 * NOT) {
+                        const int s3 = (g + 1) / NOT, ot3 = (g + 1) % NOT;
+                        const char* nx = smem + OFF_W2 + w2_b[s3] + w2t + ot3 * 32 * RB2;
+                        w2f[(g + 1) & 1][0] = *reinterpret_cast<const bf16x8*>(nx);
+                        if (SPLIT == 3) w2f[(g + 1) & 1][1] = *reinterpret_cast<const bf16x8*>(nx + W2LO);
                     }
-                    __builtin_amdgcn_sched_barrier(0);
-                    if (SPLIT == 3) {
-                        acc2[ot] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w2f[cur][1], ph, acc2[ot], 0, 0, 0);
-                        acc2[ot] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w2f[cur][0], pl, acc2[ot], 0, 0, 0);
+#pragma unroll
+                    for (int ps = 0; ps < NPASS; ++ps) {
+                        const int j = g * NPASS + ps;
+                        __builtin_amdgcn_sched_barrier(0);
+                        mfma3(acc2[ot], w2f[g & 1], prev.h[s2], prev.l[s2], ps);
+#pragma unroll
+                        for (int pr = 8 * j / ND; pr < 8 * (j + 1) / ND; ++pr) {
+                            finish(pr);
+                            if (pr == 3) swap_half(0);
+                            if (pr == 7) swap_half(1);
+                        }
                     }
-                    acc2[ot] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w2f[cur][0], ph, acc2[ot], 0, 0, 0);
-                    __builtin_amdgcn_sched_barrier(0);
                 }
+            } else {
+#pragma unroll
+                for (int pr = 0; pr < 8; ++pr) finish(pr);
+                swap_half(0);
+                swap_half(1);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        using T_ = std::true_type;
+        using F_ = std::false_type;
+        floatx16 hA, hB;
+        Frags fX, fY;
+        {   // pipeline fill: first product of hidden tile 0
+            bias_init(hA, 0);
+            bf16x8 w1f[2][2];
+            w1f[0][0] = *reinterpret_cast<const bf16x8*>(smem + OFF_W1 + w1_off[0]);
+            if (SPLIT == 3) w1f[0][1] = *reinterpret_cast<const bf16x8*>(smem + OFF_W1 + W_ARR + w1_off[0]);
+#pragma unroll
+            for (int kk = 0; kk < KK1; ++kk) {
+                if (kk + 1 < KK1) {
+                    w1f[(kk + 1) & 1][0] = *reinterpret_cast<const bf16x8*>(smem + OFF_W1 + w1_off[kk + 1]);
+                    if (SPLIT == 3) w1f[(kk + 1) & 1][1] = *reinterpret_cast<const bf16x8*>(smem + OFF_W1 + W_ARR + w1_off[kk + 1]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int ps = 0; ps < NPASS; ++ps) mfma3(hA, w1f[kk & 1], nh[kk], nl[kk], ps);
+            }
+        }
+        step(T_{}, F_{}, 0, hA, hB, fY, fX);  // tile 0: GELU || first product of tile 1
+        static_assert(NT1 >= 4 && NT1 % 2 == 0, "pipeline assumes an even number (>= 4) of hidden tiles");
+#pragma unroll 1
+        for (int t = 1; t < NT1 - 1; t += 2) {  // two steps per trip: the accumulators and fragment sets swap roles
+            step(T_{}, T_{}, t, hB, hA, fX, fY);
+            step(T_{}, T_{}, t + 1, hA, hB, fY, fX);
+        }
+        step(F_{}, T_{}, NT1 - 1, hB, hA, fX, fY);
+        {   // pipeline drain: second product of the last hidden tile
+            const int w2t = (((NT1 - 1) & 3) ^ rsw) * 64 + ((NT1 - 1) >> 2) * 256;
+            bf16x8 w2f[2][2];
+            w2f[0][0] = *reinterpret_cast<const bf16x8*>(smem + OFF_W2 + w2_b[0] + w2t);
+            if (SPLIT == 3) w2f[0][1] = *reinterpret_cast<const bf16x8*>(smem + OFF_W2 + W2LO + w2_b[0] + w2t);
+#pragma unroll
+            for (int g = 0; g < 2 * NOT; ++g) {
+                const int s2 = g / NOT, ot = g % NOT;
+                if (g + 1 < 2 * NOT) {
+                    const int s3 = (g + 1) / NOT, ot3 = (g + 1) % NOT;
+                    const char* nx = smem + OFF_W2 + w2_b[s3] + w2t + ot3 * 32 * RB2;
+                    w2f[(g + 1) & 1][0] = *reinterpret_cast<const bf16x8*>(nx);
+                    if (SPLIT == 3) w2f[(g + 1) & 1][1] = *reinterpret_cast<const bf16x8*>(nx + W2LO);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int ps = 0; ps < NPASS; ++ps) mfma3(acc2[ot], w2f[g & 1], fY.h[s2], fY.l[s2], ps);
             }
         }
         // ---- epilogue: x[frame][c] += gamma[c] (out + b2[c]); channel(r) = 32 ot + (r & 3) + 8 (r >> 2) + 4 fh -------

@@ -27,12 +27,14 @@ struct Bump {  // bump allocator over a caller-owned workspace (also used, with 
 inline std::string sidx(const std::string& a, int i, const std::string& b) { return a + std::to_string(i) + b; }
 }  // namespace
 
+int g_gemm3_t160 = 1;   // gemm3 160x128 tiles for M = 600 x wide N (SMTTS_GEMM_T160=0: off)
 int g_gemm3_nfast = 1;  // gemm3 tile order: N fastest when M > N (SMTTS_GEMM_NFAST=0 restores M fastest everywhere)
 thread_local Profiler* g_prof = nullptr;
 thread_local const char* g_prof_tag = nullptr;
 
 Engine::Engine(int device) : device_(device) {
     if (const char* nf = getenv("SMTTS_GEMM_NFAST")) g_gemm3_nfast = atoi(nf);
+    if (const char* t1 = getenv("SMTTS_GEMM_T160")) g_gemm3_t160 = atoi(t1);
     const char* s = getenv("SMTTS_SINGLE_STREAM");
     if (s && *s == '1') dual_stream_ = false;
     if ((s = getenv("SMTTS_KSPLIT_OUT")) && atoi(s) >= 1 && atoi(s) <= kSplitK) ksplit_out_ = atoi(s);
@@ -557,19 +559,19 @@ struct NextLN {  // optional: the AdaLN that follows the residual, fused into th
     float eps = 1e-6f;
 };
 static hipError_t gemm3_resid_splitk(const Gemm3Operands& g0, const EpiResid<0>& r, float* partial, int splits, int split,
-                                     hipStream_t st, const NextLN& ln = NextLN()) {
+                                     hipStream_t st, const NextLN& ln = NextLN(), int cfg = G3_64x64) {
     Gemm3Operands g = g0;
     const int nk = g.K / 64;
     g.ksplit_tiles = (nk + splits - 1) / splits;
     const int used = (nk + g.ksplit_tiles - 1) / g.ksplit_tiles;
     EpiStore<ACT_NONE> e{partial, rowmap_plain(g.N), (long)g.M * g.N, nullptr, 0, 1.f, nullptr, nullptr, nullptr};
-    hipError_t err = gemm3_store(g, ACT_NONE, e, used, split, st, G3_64x64);
+    hipError_t err = gemm3_store(g, ACT_NONE, e, used, split, st, cfg);
     if (err != hipSuccess) return err;
     if (ln.shift)
         return launch_splitk_resid_ln(partial, used, r.x, r.bias, r.gate, r.gld, r.grow0, r.grstride, r.rows_per_batch,
                                       r.rowmask, g.M, g.N, ln.eps, ln.shift, ln.scale, ln.yhi, ln.ylo, st, ln.rms);
     return launch_splitk_resid(partial, used, r.x, r.bias, r.gate, r.gld, r.grow0, r.grstride, r.rows_per_batch, r.rowmask,
-                               g.M, g.N, st);
+                               g.M, g.N, st, &r.xmap);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1031,7 +1033,7 @@ int Engine::sample(hipStream_t st, int mode, int n_steps, int cfg, float s_text,
 // k-tap convs all become plain GEMMs over overlapping rows.
 // ---------------------------------------------------------------------------------------------
 int Engine::codec_block(hipStream_t st, const CodecBlockW& w, float** xp, float** xaltp, float* nbuf, bf16_t* n2hi,
-                        bf16_t* n2lo, bf16_t* hhi, bf16_t* hlo, int B, int T, int C) {
+                        bf16_t* n2lo, bf16_t* hhi, bf16_t* hlo, int B, int T, int C, size_t n2_elems) {
     const int M = B * T, pad = kCodecPad;
     float* x = *xp;
     const RowMap img = rowmap_batched(C, T, (long)(pad + T) * C, (long)pad * C);
@@ -1080,6 +1082,21 @@ int Engine::codec_block(hipStream_t st, const CodecBlockW& w, float** xp, float*
         HIPC(gemm_store(ops(nbuf, img, w.w1, M), ACT_GELU, store_split_to(hid, rf, w.b1), 1, split_, st));
     }
     EpiResid<0> r{x, img, w.b2, w.ffn_gamma, 0, 0, 0, 1, nullptr};
+    {
+        // M = 600 against a wide-K second product (the coarsest stage: 600 x 2048 x 8192): 160x128 tiles cut K so that ONE round
+        // of workgroups fills the chip; fp32 partials go to the (now dead) n2 buffer, one pass reduces them in a fixed order
+        // and applies bias / LayerScale / residual (same deterministic scheme as the DiT projections)
+        extern int g_gemm3_t160;
+        const long t160 = (long)((M + 159) / 160) * ((C + 127) / 128);
+        const int nk = F / 64;
+        int splits = t160 > 0 && t160 <= 128 ? (int)(256 / t160) : 1;
+        if (splits > nk / 8) splits = nk / 8;
+        if (g_gemm3_t160 && M > 480 && M <= 640 && splits >= 2 && (size_t)splits * M * C * 2 <= n2_elems && C % 4 == 0) {
+            float* part = reinterpret_cast<float*>(n2hi);  // n2hi holds n2_elems bf16 = n2_elems / 2 floats
+            HIPC(gemm3_resid_splitk(ops3(hid, rf, w.w2, M), r, part, splits, split_, st, NextLN(), G3_160x128));
+            return 0;
+        }
+    }
     HIPC(gemm3_resid(ops3(hid, rf, w.w2, M), 2, r, split_, st));
     return 0;
 }
@@ -1177,7 +1194,7 @@ int Engine::codec_decode(hipStream_t st, const float* latents, int B, int T, flo
             HIPC(launch_zero_pad_frames(xn, B, Ti, C, pad, st));  // the ping-pong partner needs zero pads at this geometry too
         }
         for (const CodecBlockW& b : sg.blocks)
-            if (codec_block(st, b, &x, &xn, w.nb, w.n2hi, w.n2lo, w.hhi, w.hlo, B, Ti, C)) return 1;
+            if (codec_block(st, b, &x, &xn, w.nb, w.n2hi, w.n2lo, w.hhi, w.hlo, B, Ti, C, max_img)) return 1;
     }
     HIPC(launch_head_conv(x, dec_.head_w, dec_.head_b_host, audio, B, Ti, C, Kc, pad, st));
     return 0;
@@ -1249,7 +1266,7 @@ int Engine::codec_encode(hipStream_t st, const float* audio, int B, int S_, floa
             HIPC(launch_zero_pad_frames(xn, B, Ti, C, pad, st));
         }
         for (const CodecBlockW& b : sg.blocks)
-            if (codec_block(st, b, &x, &xn, w.nb, w.n2hi, w.n2lo, w.hhi, w.hlo, B, Ti, C)) return 1;
+            if (codec_block(st, b, &x, &xn, w.nb, w.n2hi, w.n2lo, w.hhi, w.hlo, B, Ti, C, max_img)) return 1;
     }
     RowMap am = rowmap_batched(C, Ti, (long)(pad + Ti) * C, (long)(pad - (Kc - 1)) * C);
     HIPC(gemm_store(ops(x, am, enc_.head, B * Ti), ACT_NONE, store_to(latents, rowmap_plain(s.latent_dim), enc_.head_b), 1,

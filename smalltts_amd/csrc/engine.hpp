@@ -161,7 +161,7 @@ class Engine {
     size_t denoise_core_bytes(int B, int N) const;
     // runs one block; the result lives in *x on return (the fused mixer ping-pongs *x <-> *xalt)
     int codec_block(hipStream_t st, const CodecBlockW& w, float** x, float** xalt, float* nbuf, bf16_t* n2hi, bf16_t* n2lo,
-                    bf16_t* hhi, bf16_t* hlo, int B, int T, int C);
+                    bf16_t* hhi, bf16_t* hlo, int B, int T, int C, size_t n2_elems /* capacity of n2hi (bf16 elements) */);
 
     int device_;
     std::string err_;

@@ -36,8 +36,9 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm3_kernel(Gemm3Operands g, Epi
     constexpr int A_ARR = BM * 128, W_ARR = BN * 128;  // bytes per array per stage
     constexpr int STAGE = NARR * (A_ARR + W_ARR);
     constexpr int NA = NARR * (BM / 8), NWS = NARR * (BN / 8);  // DMA slots (8 rows each)
-    constexpr int PW = (NA + NWS) / NW;                         // slots per wave per stage
-    static_assert(PW * NW == NA + NWS, "DMA slots must divide evenly over the waves");
+    constexpr int PW = (NA + NWS + NW - 1) / NW;                // slots per wave per stage
+    constexpr bool DUMMY = PW * NW != NA + NWS;                 // odd wave counts (160-row tiles, 10 waves): the surplus slots DMA
+    constexpr int STAGE_LD = STAGE + (DUMMY ? 1024 : 0);        // into a 1-KiB pad behind the stage so every wave counts the same vmcnt
     static_assert(!Epi::PAIRED || TN == 2, "paired epilogue needs a 32x64 wave tile");
     // L2 prefetch-touch: one dword load per 128-B line of the tile PFD k-tiles beyond the stage being DMA'd.  HBM
     // has spare bandwidth (the loop is bound by bytes-in-flight / latency), so touching early makes the later DMA an
@@ -79,7 +80,12 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm3_kernel(Gemm3Operands g, Epi
     for (int i = 0; i < PW; ++i) {
         const int slot = wave * PW + i;  // wave-uniform
         const int rl = lane >> 3, p = lane & 7;
-        if (slot < NA) {
+        if (DUMMY && slot >= NA + NWS) {
+            int m = m0 + rl;
+            m = m < g.M ? m : g.M - 1;
+            src[i] = g.Ahi + (long)zb * g.a_z + g.amap.at(m) + p * 8;
+            dst[i] = STAGE;
+        } else if (slot < NA) {
             const int arr = slot / (BM / 8), rb = slot % (BM / 8);
             const int r = rb * 8 + rl;
             const int c = p ^ ((r >> 1) & 7);
@@ -147,7 +153,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm3_kernel(Gemm3Operands g, Epi
             : "memory");
     };
     auto issue = [&](int kt) {
-        const unsigned st = lds0 + (unsigned)((kt % S) * STAGE);
+        const unsigned st = lds0 + (unsigned)((kt % S) * STAGE_LD);
 #pragma unroll
         for (int i = 0; i < PW; ++i)
             dma16(src[i] + (kt0 + kt) * BK, st + (unsigned)__builtin_amdgcn_readfirstlane((int)dst[i]));
@@ -155,7 +161,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm3_kernel(Gemm3Operands g, Epi
         kp = kp < nk_all ? kp : nk_all - 1;
 #pragma unroll
         for (int i = 0; i < PFN; ++i)
-            touch4(pf[i] + kp * BK, lds0 + (unsigned)(S * STAGE));
+            touch4(pf[i] + kp * BK, lds0 + (unsigned)(S * STAGE_LD));
     };
 
     floatx16 acc[TM][TN];
@@ -195,7 +201,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm3_kernel(Gemm3Operands g, Epi
             wait_vmcnt<0>();
         __builtin_amdgcn_s_barrier();
         if (kt + S - 1 < nk) issue(kt + S - 1);
-        const char* st = smem + (kt % S) * STAGE;
+        const char* st = smem + (kt % S) * STAGE_LD;
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
             bf16x8 ah[TM], al[TM], bh[TN], bl[TN];
@@ -227,7 +233,8 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm3_kernel(Gemm3Operands g, Epi
 template <int BM, int BN, int WM, int WN, int SPLIT, int S, class Epi>
 static inline hipError_t gemm3_launch_cfg(const Gemm3Operands& g, const Epi& epi, int Z, hipStream_t st) {
     constexpr int NARR = SPLIT == 3 ? 2 : 1;
-    constexpr size_t lds = (size_t)S * NARR * (BM + BN) * 128 + 256;  // ring + dummy slot of the prefetch touches
+    constexpr bool DUMMY = (NARR * (BM / 8 + BN / 8)) % (WM * WN) != 0;
+    constexpr size_t lds = (size_t)S * (NARR * (BM + BN) * 128 + (DUMMY ? 1024 : 0)) + 256;  // ring (+ pads) + dummy slot of the prefetch touches
     static_assert(lds <= 160 * 1024, "LDS ring exceeds 160 KiB");
     dim3 grid(((g.N + BN - 1) / BN) * ((g.M + BM - 1) / BM), 1, Z);  // 1-D tile index, remapped per XCD in-kernel
     auto kern = gemm3_kernel<BM, BN, WM, WN, SPLIT, S, Epi>;
@@ -248,6 +255,7 @@ enum Gemm3Cfg {
     G3_64x64 = 2,    // 4 waves 2x2, wave 32x32, 2 stages (64 KiB) -> 2 workgroups / CU: small N
     G3_128x64 = 3,   // 8 waves 4x2, wave 32x32, 3 stages (144 KiB): tall, N <= 64
     G3_128x32 = 4,   // 4 waves 4x1, wave 32x32, 2 stages (80 KiB) -> 2 workgroups / CU: tall, N <= 32
+    G3_160x128 = 5,  // 10 waves 5x2, wave 32x64, 2 stages (146 KiB): M = 600 (4 row tiles, 6 % padding) x wide N in ONE round
 };
 
 static inline int gemm3_pick_cfg(int M, int N, bool paired) {
@@ -257,6 +265,9 @@ static inline int gemm3_pick_cfg(int M, int N, bool paired) {
     // cost model measured on MI355X: time ~ rounds(tiles / 256 CUs) x bytes ingested per workgroup / ~40 GB/s.
     // 128x128 moves the fewest bytes per flop; prefer it whenever it fills at least half the chip in ONE round or
     // many rounds (a 64x128 grid of 257..511 tiles costs two rounds, e.g. DiT QKVG: 300 tiles 36.5 us vs 150 tiles 29.5 us)
+    extern int g_gemm3_t160;
+    const long t160 = (long)((M + 159) / 160) * ((N + 127) / 128);
+    if (g_gemm3_t160 && M <= 640 && M > 480 && t160 > 128 && t160 <= 256) return G3_160x128;
     const long t128 = (long)((M + 127) / 128) * ((N + 127) / 128);
     if (t128 >= 512 || (t128 >= 128 && t128 <= 256)) return G3_128x128;
     const long t64x128 = (long)((M + 63) / 64) * ((N + 127) / 128);
@@ -285,6 +296,9 @@ static inline hipError_t gemm3_launch_split(const Gemm3Operands& g, const Epi& e
             break;
         case G3_128x32:
             if constexpr (!Epi::PAIRED) return gemm3_launch_cfg<128, 32, 4, 1, SPLIT, 2, Epi>(g, epi, Z, st);
+            break;
+        case G3_160x128:
+            if constexpr (!Epi::PAIRED) return gemm3_launch_cfg<160, 128, 5, 2, SPLIT, 2, Epi>(g, epi, Z, st);
             break;
     }
     return hipErrorInvalidValue;
