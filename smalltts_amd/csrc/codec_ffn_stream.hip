@@ -4,19 +4,19 @@
 // Same wave-level structure as codec_ffn_wave.hip — each wave owns 32 frames, both products are computed transposed
 // (lane = frame), the normalised input and the 4C-wide hidden live in registers, v_permlane32_swap turns GELU'd
 // accumulators into the B fragments of the second product — but the weights stream through an LDS ring:
-//   slot(t) = [ W1 rows 32t..32t+32 (32 x C) | W2 columns 32t..32t+32 (C x 32, from a tile-major repack) ], hi and lo,
-// i.e. exactly what hidden tile t needs.  All waves of the workgroup consume slot t for their own frames, so the
-// ring is joined by one s_barrier per hidden tile (gemm3's protocol: own DMA pieces landed -> barrier -> refill the
-// slot everybody just left).  The workgroup is persistent (walks passes of NW x 32 frames) and the ring keeps
+//   slot(i) = [ W1 rows 32i..32i+32 (32 x C) | W2 columns of hidden tile i-2 (C x 32, from a tile-major repack) ], hi and lo,
+// i.e. exactly what pipeline step i needs (first product of tile i, second product of tile i-2; see the kernel).  All
+// waves of the workgroup consume slot i for their own frames, so the ring is joined by one s_barrier per step (gemm3's
+// protocol: own DMA pieces landed -> barrier -> refill the slot everybody just left).  The workgroup is persistent (walks passes of NW x 32 frames) and the ring keeps
 // running across passes.  Per pass the L2 -> LDS weight traffic is 32 C^2 bytes for NW x 32 frames: 4x (C = 128) less
 // per frame than codec_ffn_kernel, and nothing but x itself touches HBM (the unfused C = 256 path moved the 4C-wide
 // hidden through HBM twice).
 #include "gemm3.hpp"
 #include "kernels.hpp"
 #include "prof.hpp"
+#include <type_traits>
 
 typedef float f32x2s __attribute__((ext_vector_type(2)));
-
 typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
 // (a, b) -> packed bf16 pair in one v_cvt_pk_bf16_f32; split_pair also returns the packed bf16 of the two residuals
 __device__ __forceinline__ unsigned cvt_pk_bf16(float a, float b) {
@@ -27,39 +27,6 @@ __device__ __forceinline__ unsigned cvt_pk_bf16(float a, float b) {
 __device__ __forceinline__ void split_pair(float a, float b, unsigned& hi, unsigned& lo) {
     hi = cvt_pk_bf16(a, b);
     lo = cvt_pk_bf16(a - __uint_as_float(hi << 16), b - __uint_as_float(hi & 0xffff0000u));
-}
-
-#ifdef GELU_SCALAR
-__device__ __forceinline__ float gelu1_(float x) {
-    const float t = fast_rcp(fmaf(fabsf(x), 0.3275911f * 0.70710678118654752f, 1.0f));
-    const float poly = t * fmaf(t, fmaf(t, fmaf(t, fmaf(t, 1.061405429f, -1.453152027f), 1.421413741f), -0.284496736f), 0.254829592f);
-    const float e = __builtin_amdgcn_exp2f((x * x) * (-0.5f * 1.4426950408889634f));
-    const float u = fmaf(-poly, e, 1.0f);
-    const float hx = 0.5f * x;
-    return fmaf(fabsf(hx), u, hx);
-}
-#endif
-__device__ __forceinline__ f32x2s gelu2s(f32x2s x) {
-#ifdef GELU_SCALAR
-    { f32x2s r; r.x = gelu1_(x.x); r.y = gelu1_(x.y); return r; }
-#endif
-    // exact-erf GELU, A&S 7.1.26 (|erf error| <= 1.5e-7): erfc(z) = t (a1 + t (a2 + ...)) exp(-z^2), t = 1 / (1 + p z),
-    // z = |x| / sqrt 2.  gelu(x) = x/2 (1 + erf(x / sqrt 2)) = x/2 + |x|/2 (1 - erfc(z)): no compare / select, the |.| are
-    // free source modifiers, the polynomial runs on v_pk_* ops (two values per instruction).
-    f32x2s t;
-    t.x = fast_rcp(fmaf(fabsf(x.x), 0.3275911f * 0.70710678118654752f, 1.0f));
-    t.y = fast_rcp(fmaf(fabsf(x.y), 0.3275911f * 0.70710678118654752f, 1.0f));
-    const f32x2s poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
-    const f32x2s ea = (x * x) * (-0.5f * 1.4426950408889634f);  // exp(-z^2) = exp2(-x^2/2 log2 e)
-    f32x2s e;
-    e.x = __builtin_amdgcn_exp2f(ea.x);
-    e.y = __builtin_amdgcn_exp2f(ea.y);
-    const f32x2s u = 1.0f - poly * e;  // erf(z)
-    const f32x2s hx = 0.5f * x;
-    f32x2s r;
-    r.x = fmaf(fabsf(hx.x), u.x, hx.x);
-    r.y = fmaf(fabsf(hx.y), u.y, hx.y);
-    return r;
 }
 
 struct FfnStreamArgs {
@@ -77,26 +44,36 @@ struct FfnStreamArgs {
     float eps;
 };
 
-template <int C, int SPLIT, int NW, int S, int TPB>
+// ---------------------------------------------------------------------------------------------------------------------
+// Software pipeline: ring step i of a pass runs  P1(i) || GELU(i-1) || P2(i-2)  (first product of hidden tile i,
+// activation + bf16 split of tile i-1, second product of tile i-2), i = 0 .. NT1+1.  The three are independent, so the
+// whole GELU — written with plain (non-packed) fp32 instructions, which unlike v_pk_* run in the shadow of MFMAs
+// (tools/ubench/mfma_valu.hip) — is cut into 42 small tasks that are dealt out one after each MFMA.  Ring slot i holds
+// {W1 tile i, W2 tile i-2}; one barrier per step as before.  Weight fragments are read two MFMA groups ahead.
+// ---------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned cvt_pk_bf16s(float a, float b) { return cvt_pk_bf16(a, b); }
+
+template <int C, int SPLIT, int NW, int S>
 __global__ __launch_bounds__(NW * 64) void codec_ffn_stream_kernel(FfnStreamArgs a) {
     constexpr int F = 4 * C;
     constexpr int KK1 = C / 16;             // k16 steps of the first product
     constexpr int NT1 = F / 32;             // hidden tiles
     constexpr int NOT = C / 32;             // output (channel) tiles
     constexpr int NARR = SPLIT == 3 ? 2 : 1;
+    constexpr int NPASS = SPLIT == 3 ? 3 : 1;
     constexpr int RB1 = 2 * C;              // bytes per W1 row (256 / 512)
     constexpr int CPR1 = RB1 / 16;          // 16-B chunks per W1 row (16 / 32)
     constexpr int W1T = 32 * RB1;           // bytes of one W1 tile image per array (= 64 C)
     constexpr int W2T = C * 64;             // bytes of one W2 tile image per array (C rows x 64 B)
-    constexpr int SUB = NARR * (W1T + W2T); // one hidden tile's weights
-    constexpr int SLOT = TPB * SUB;         // a ring slot holds TPB consecutive hidden tiles (one barrier per slot)
-    constexpr int NST = NT1 / TPB;          // slots per pass
+    constexpr int SLOT = NARR * (W1T + W2T);
+    constexpr int NSTEP = NT1 + 2;          // ring steps per pass
     constexpr int PIECES = SLOT / 1024;     // DMA pieces per slot
     constexpr int PW = PIECES / NW;         // per wave
     constexpr int HALF = NARR * (W1T / 1024);  // pieces [0, HALF) are W1, [HALF, PIECES) W2
     constexpr int OFF_V = S * SLOT;         // b1[F] b2[C] gamma[C] norm_w[C] (fp32)
     static_assert(PW * NW == PIECES, "DMA pieces must divide over the waves");
     static_assert((S - 2) * PW <= 63 && S >= 2, "vmcnt immediate");
+    static_assert(NT1 % 2 == 0 && NT1 >= 4, "pipeline assumes an even number of hidden tiles");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -111,72 +88,70 @@ __global__ __launch_bounds__(NW * 64) void codec_ffn_stream_kernel(FfnStreamArgs
     for (int i = tid; i < C; i += NW * 64) { vb2[i] = a.b2[i]; vga[i] = a.gamma[i]; vnw[i] = a.norm_w[i]; }
 
     // ---- this wave's DMA pieces: source pointer at hidden tile 0 and LDS offset inside a slot -------------------
-    const bf16_t* src[PW];
+    unsigned soff[PW];  // per-lane BYTE offset inside the array's tile (the array base + tile offset are scalar)
     unsigned dst[PW];
 #pragma unroll
     for (int i = 0; i < PW; ++i) {
-        const int qq = wave * PW + i;  // wave-uniform
-        const int u = qq / (SUB / 1024), q = qq % (SUB / 1024);  // hidden tile inside the slot, piece inside the tile
+        const int q = wave * PW + i;  // wave-uniform piece index inside the slot
         if (q < HALF) {               // W1 tile: rows of RB1 bytes, 1024 / RB1 rows per piece
             const int arr = q / (W1T / 1024), j = q % (W1T / 1024);
             const int r = j * (1024 / RB1) + lane / CPR1, pos = lane % CPR1;
             const int c = (pos & ~15) | ((pos ^ r) & 15);
-            src[i] = (arr ? a.w1lo : a.w1hi) + (long)r * C + c * 8 + (long)u * 32 * C;
-            dst[i] = u * SUB + arr * W1T + j * 1024;
+            soff[i] = (unsigned)(r * C + c * 8) * 2u;
+            dst[i] = arr * W1T + j * 1024;
         } else {                      // W2 tile: 64-B rows, 16 rows per piece
             const int q2 = q - HALF;
             const int arr = q2 / (W2T / 1024), j = q2 % (W2T / 1024);
             const int r = j * 16 + (lane >> 2), pos = lane & 3;
             const int c = pos ^ ((r >> 2) & 3);
-            src[i] = (arr ? a.w2tlo : a.w2thi) + (long)r * 32 + c * 8 + (long)u * 32 * C;
-            dst[i] = u * SUB + NARR * W1T + arr * W2T + j * 1024;
+            soff[i] = (unsigned)(r * 32 + c * 8) * 2u;
+            dst[i] = NARR * W1T + arr * W2T + j * 1024;
         }
     }
-    auto dma16 = [&](const void* gsrc, unsigned lds_dst) {
+    auto dma16 = [&](const bf16_t* sbase, unsigned voff, unsigned lds_dst) {  // scalar base + 32-bit lane offset
         unsigned keep;
         asm volatile(
             "s_mov_b32 %0, m0\n\t"
-            "s_mov_b32 m0, %2\n\t"
+            "s_mov_b32 m0, %3\n\t"
             "s_nop 0\n\t"
-            "global_load_lds_dwordx4 %1, off\n\t"
+            "global_load_lds_dwordx4 %1, %2\n\t"
             "s_mov_b32 m0, %0"
             : "=&s"(keep)
-            : "v"(gsrc), "s"(lds_dst)
+            : "v"(voff), "s"(sbase), "s"(lds_dst)
             : "memory");
     };
-    // hidden tile t of either matrix starts 32 * C elements after tile t - 1; slot index i covers tiles TPB * (i % NST) ..
+    // ring position i -> step si = i % NSTEP of a pass: W1 tile si (clamped, unused in the last two steps), W2 tile si - 2
     auto issue = [&](int i) {
-        const int t = (i % NST) * TPB;
+        const int si = i % NSTEP;
+        const int t1 = si < NT1 ? si : NT1 - 1, t2 = si >= 2 ? si - 2 : 0;
         const unsigned st = lds0 + (unsigned)((i % S) * SLOT);
 #pragma unroll
-        for (int p = 0; p < PW; ++p)
-            dma16(src[p] + (long)t * 32 * C, st + (unsigned)__builtin_amdgcn_readfirstlane((int)dst[p]));
+        for (int p = 0; p < PW; ++p) {
+            const int q = wave * PW + p;  // wave-uniform
+            const bool is_w2 = q >= HALF;
+            const int arr = is_w2 ? (q - HALF) / (W2T / 1024) : q / (W1T / 1024);
+            const bf16_t* base = is_w2 ? (arr ? a.w2tlo : a.w2thi) : (arr ? a.w1lo : a.w1hi);
+            dma16(base + (long)(is_w2 ? t2 : t1) * 32 * C, soff[p], st + (unsigned)__builtin_amdgcn_readfirstlane((int)dst[p]));
+        }
     };
 
     const int npass_total = (a.M + NW * 32 - 1) / (NW * 32);
     const int my_passes = blockIdx.x < npass_total ? (npass_total - blockIdx.x + gridDim.x - 1) / gridDim.x : 0;
-    const int total = my_passes * NST;  // ring slots this workgroup will consume
+    const int total = my_passes * NSTEP;  // ring slots this workgroup will consume
 #pragma unroll 1
     for (int s = 0; s < S - 1; ++s)
         if (s < total) issue(s);
 
     // fragment byte offsets inside a slot
-    int w1_off[KK1];
+    // W1 fragment of k16 step kk: row fr, 16-B chunk c = 2 kk + fh stored at (c & ~15) | ((c ^ fr) & 15).  (c ^ fr) & 15 =
+    // (2 kk & 15) ^ ((fh ^ fr) & 15), and fr * RB1 has no bits below 256, so the byte offset is (w1_a0 ^ ((2 kk & 15) << 4)) +
+    // (2 kk >> 4) * 256: one v_xor with a constant per read instead of KK1 address registers
+    const int w1_a0 = fr * RB1 + (((fh ^ fr) & 15) << 4);
+    int w2_off[2];  // (s, ot): w2_off[s] + ot * 32 * 64  (the swizzle term (row >> 2) & 3 is the same for row and row + 32)
 #pragma unroll
-    for (int kk = 0; kk < KK1; ++kk) {
-        const int c = 2 * kk + fh;
-        w1_off[kk] = fr * RB1 + (((c & ~15) | ((c ^ fr) & 15)) << 4);
-    }
-    int w2_off[NOT][2];
-#pragma unroll
-    for (int ot = 0; ot < NOT; ++ot)
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            const int row = 32 * ot + fr;
-            w2_off[ot][s] = NARR * W1T + row * 64 + (((2 * s + fh) ^ ((row >> 2) & 3)) << 4);
-        }
+    for (int s = 0; s < 2; ++s) w2_off[s] = NARR * W1T + fr * 64 + (((2 * s + fh) ^ ((fr >> 2) & 3)) << 4);
 
-    int it = 0;  // global hidden-tile counter (ring position)
+    int it = 0;  // ring position
 #pragma unroll 1
     for (int p = 0; p < my_passes; ++p) {
         const int pass = blockIdx.x + p * gridDim.x;
@@ -220,103 +195,137 @@ __global__ __launch_bounds__(NW * 64) void codec_ffn_stream_kernel(FfnStreamArgs
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc2[ot][r] = 0.f;
 
-#pragma unroll 1
-        for (int t = 0; t < NT1; ++t) {
-          if (t % TPB == 0) {
-            // this wave's pieces of slot `it` have landed: younger = the (S-2) tiles issued after it (none near the end)
+        struct Frags { bf16x8 h[2], l[2]; };  // B fragments (two k16 steps) of one activated hidden tile
+        floatx16 H0, H1;
+        Frags F0, F1;
+
+        // one ring step; ti = hidden tile of the first product (step index), do_* select what the step contains
+        auto step = [&](auto do_p1, auto do_g, auto do_p2, int ti, floatx16& hw, const floatx16& hr, Frags& fw, const Frags& fr_) {
+            constexpr bool P1 = decltype(do_p1)::value, G = decltype(do_g)::value, P2 = decltype(do_p2)::value;
+            // ---- ring hand-over (one barrier per step) ----
             if (it + S - 1 <= total)
                 wait_vmcnt<(S - 2) * PW>();
             else
                 wait_vmcnt<0>();
-            __builtin_amdgcn_s_barrier();  // everybody's pieces landed; everybody left tile it-1 -> its slot is free
+            __builtin_amdgcn_s_barrier();  // everybody's pieces of slot `it` landed; everybody left slot it-1 -> it is free
             if (it + S - 1 < total) issue(it + S - 1);
+            const char* sl = smem + (it % S) * SLOT;
             ++it;
-          }
-            const char* sl = smem + ((it - 1) % S) * SLOT + (t % TPB) * SUB;
 
-            // ---- H^T tile: hidden rows 32 t .. +32 x this wave's 32 frames ----------------------------------------------
-            floatx16 acc1;
+            constexpr int NG1 = P1 ? KK1 : 0, NG2 = P2 ? 2 * NOT : 0, NG = NG1 + NG2, NCH = NG * NPASS;
+            // weight fragment of MFMA group g: first product k16 step g, or second product (s, ot) = ((g - NG1) / NOT, (g - NG1) % NOT)
+            constexpr int PFD = C >= 256 ? 3 : 1;  // fragment reads run PFD MFMA groups ahead (PFD + 1 register buffers)
+            constexpr int NB = PFD + 1;
+            bf16x8 wf[NB][2];
+            auto read_frag = [&](int g) {
+                const char* ad;
+                int lo;
+                if (g < NG1) { ad = sl + (w1_a0 ^ (((2 * g) & 15) << 4)) + ((2 * g) >> 4) * 256; lo = W1T; }
+                else { const int g2 = g - NG1; ad = sl + w2_off[g2 / NOT] + (g2 % NOT) * 32 * 64; lo = W2T; }
+                wf[g % NB][0] = *reinterpret_cast<const bf16x8*>(ad);
+                if (SPLIT == 3) wf[g % NB][1] = *reinterpret_cast<const bf16x8*>(ad + lo);
+            };
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc1[r] = 0.f;
-            // fragment reads run one k16 step ahead of the MFMAs that consume them (the compiler keeps this order and counts
-            // lgkmcnt, so the LDS latency of step kk+1 hides under the three MFMAs of step kk)
-            bf16x8 w1f[2][2];  // [buffer kk & 1][hi | lo]: compile-time ping-pong, no register copies
-            w1f[0][0] = *reinterpret_cast<const bf16x8*>(sl + w1_off[0]);
-            if (SPLIT == 3) w1f[0][1] = *reinterpret_cast<const bf16x8*>(sl + W1T + w1_off[0]);
+            for (int g = 0; g < PFD; ++g)
+                if (g < NG) read_frag(g);
+            if (P1) {  // accumulators start from b1: row r of tile ti is hidden unit 32 ti + (r & 3) + 8 (r >> 2) + 4 fh
 #pragma unroll
-            for (int kk = 0; kk < KK1; ++kk) {
-                if (kk + 1 < KK1) {
-                    w1f[(kk + 1) & 1][0] = *reinterpret_cast<const bf16x8*>(sl + w1_off[kk + 1]);
-                    if (SPLIT == 3) w1f[(kk + 1) & 1][1] = *reinterpret_cast<const bf16x8*>(sl + W1T + w1_off[kk + 1]);
+                for (int q = 0; q < 4; ++q) {
+                    const float4 bv = *reinterpret_cast<const float4*>(vb1 + 32 * ti + 8 * q + 4 * fh);
+                    hw[4 * q + 0] = bv.x; hw[4 * q + 1] = bv.y; hw[4 * q + 2] = bv.z; hw[4 * q + 3] = bv.w;
                 }
-                __builtin_amdgcn_sched_barrier(0);  // keep the reads above the MFMAs below
-                if (SPLIT == 3) {
-                    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1f[kk & 1][1], nh[kk], acc1, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1f[kk & 1][0], nl[kk], acc1, 0, 0, 0);
-                }
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1f[kk & 1][0], nh[kk], acc1, 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
             }
-            // W2 fragments are read one (k16 step, channel tile) pair ahead as well; the first pair is requested before the
-            // GELU so it lands under it
-            auto w2_addr = [&](int ot, int s) { return sl + w2_off[ot][s]; };
-            constexpr int W2LO = W2T;
-            bf16x8 w2f[2][2];  // [buffer][hi | lo], buffer = (s * NOT + ot) & 1
-            w2f[0][0] = *reinterpret_cast<const bf16x8*>(w2_addr(0, 0));
-            if (SPLIT == 3) w2f[0][1] = *reinterpret_cast<const bf16x8*>(w2_addr(0, 0) + W2LO);
+            // ---- GELU of tile ti-1 as 42 tasks: exact-erf A&S 7.1.26, gelu(x) = x/2 + |x/2| erf(|x| / sqrt 2) ----
+            // two halves of 42 micro-tasks (<= 4 VALU instructions each, so a task fits the 32-cycle shadow of ONE MFMA next to its
+            // issue): values 8 s2 .. 8 s2 + 7 (= k16 step s2 of the second product) run S1a/b x8, S2a/b x8, four pair splits in two
+            // parts and the lane swap in two parts before the other half starts, so only 8 values' temporaries are live
+            float tt[8], ee[8];   // tt: t, then the result (in place)
+            unsigned hiP[4], loP[4];
+            auto task = [&](int k0) {
+                const int s2 = k0 / 42, k = k0 % 42;
+                if (k < 16) {                 // S1: t = 1 / (1 + p |x| / sqrt 2) | e = exp2(-x^2 / 2 log2 e)
+                    const int v = k >> 1;
+                    const float x = hr[8 * s2 + v];
+                    if (k & 1) ee[v] = __builtin_amdgcn_exp2f((x * x) * (-0.5f * 1.4426950408889634f));
+                    else tt[v] = fast_rcp(fmaf(fabsf(x), 0.3275911f * 0.70710678118654752f, 1.0f));
+                } else if (k < 32) {          // S2: erfc polynomial (Horner, 4 fma) | erf and the result (4)
+                    const int v = (k - 16) >> 1;
+                    if (!(k & 1)) {
+                        const float t = tt[v];
+                        tt[v] = t * fmaf(t, fmaf(t, fmaf(t, fmaf(t, 1.061405429f, -1.453152027f), 1.421413741f), -0.284496736f), 0.254829592f);
+                    } else {
+                        const float u = fmaf(-tt[v], ee[v], 1.0f);
+                        const float hx = 0.5f * hr[8 * s2 + v];
+                        tt[v] = fmaf(fabsf(hx), u, hx);
+                    }
+                } else if (k < 40) {          // S3: bf16 split of the four value pairs: hi | residual
+                    const int j = (k - 32) >> 1;
+                    const float rx = tt[2 * j], ry = tt[2 * j + 1];
+                    if (!(k & 1)) hiP[j] = cvt_pk_bf16s(rx, ry);
+                    else if (SPLIT == 3) loP[j] = cvt_pk_bf16s(rx - __uint_as_float(hiP[j] << 16), ry - __uint_as_float(hiP[j] & 0xffff0000u));
+                } else {                      // lane swap of this k16 step: hi | lo
+                    // lane half 0 needs hidden 0..7 of the k16 step, half 1 hidden 8..15: swap upper half of X with lower half of Y
+                    if (k == 40) {
+                        unsigned fhh[4];
+#pragma unroll
+                        for (int e = 0; e < 2; ++e) {
+                            auto rh = __builtin_amdgcn_permlane32_swap(hiP[e], hiP[2 + e], false, false);
+                            fhh[e] = rh[0]; fhh[2 + e] = rh[1];
+                        }
+                        fw.h[s2] = __builtin_bit_cast(bf16x8, *reinterpret_cast<uint4*>(fhh));
+                    } else if (SPLIT == 3) {
+                        unsigned fll[4];
+#pragma unroll
+                        for (int e = 0; e < 2; ++e) {
+                            auto rl = __builtin_amdgcn_permlane32_swap(loP[e], loP[2 + e], false, false);
+                            fll[e] = rl[0]; fll[2 + e] = rl[1];
+                        }
+                        fw.l[s2] = __builtin_bit_cast(bf16x8, *reinterpret_cast<uint4*>(fll));
+                    }
+                }
+            };
+            constexpr int NTASK = 84;
+            if (NG == 0) {
+                // (no such step: the first step has P1, the last has P2)
+            }
+#pragma unroll
+            for (int g = 0; g < NG; ++g) {
+                if (g + PFD < NG) read_frag(g + PFD);
+#pragma unroll
+                for (int ps = 0; ps < NPASS; ++ps) {
+                    const int c = g * NPASS + ps;
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (g < NG1) {
+                        // pass order: the two cross terms first, hi . hi last
+                        if (SPLIT == 3 && ps == 0) hw = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[g % NB][1], nh[g < NG1 ? g : 0], hw, 0, 0, 0);
+                        else if (SPLIT == 3 && ps == 1) hw = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[g % NB][0], nl[g < NG1 ? g : 0], hw, 0, 0, 0);
+                        else hw = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[g % NB][0], nh[g < NG1 ? g : 0], hw, 0, 0, 0);
+                    } else {
+                        const int g2 = g - NG1, s2 = g2 / NOT, ot = g2 % NOT;
+                        if (SPLIT == 3 && ps == 0) acc2[ot] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[g % NB][1], fr_.h[s2], acc2[ot], 0, 0, 0);
+                        else if (SPLIT == 3 && ps == 1) acc2[ot] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[g % NB][0], fr_.l[s2], acc2[ot], 0, 0, 0);
+                        else acc2[ot] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[g % NB][0], fr_.h[s2], acc2[ot], 0, 0, 0);
+                    }
+                    if (G)
+#pragma unroll
+                        for (int k = NTASK * c / NCH; k < NTASK * (c + 1) / NCH; ++k) task(k);
+                }
+            }
             __builtin_amdgcn_sched_barrier(0);
-            // ---- bias + GELU in place: row(r) = hidden 32 t + (r & 3) + 8 (r >> 2) + 4 fh -----------------------------
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const float4 bv = *reinterpret_cast<const float4*>(vb1 + 32 * t + 8 * q + 4 * fh);
-                f32x2s u0, u1;
-                u0.x = acc1[4 * q + 0] + bv.x; u0.y = acc1[4 * q + 1] + bv.y;
-                u1.x = acc1[4 * q + 2] + bv.z; u1.y = acc1[4 * q + 3] + bv.w;
-                u0 = gelu2s(u0);
-                u1 = gelu2s(u1);
-                acc1[4 * q + 0] = u0.x; acc1[4 * q + 1] = u0.y; acc1[4 * q + 2] = u1.x; acc1[4 * q + 3] = u1.y;
-            }
-            // ---- Out^T += W2[:, tile t] . H^T tile: two k16 steps ---------------------------------------------------------
-#pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                const int r0 = 8 * s;
-                unsigned xh[2], yh[2], xl[2], yl[2];
-#pragma unroll
-                for (int e = 0; e < 2; ++e) {
-                    split_pair(acc1[r0 + 2 * e], acc1[r0 + 2 * e + 1], xh[e], xl[e]);
-                    split_pair(acc1[r0 + 4 + 2 * e], acc1[r0 + 4 + 2 * e + 1], yh[e], yl[e]);
-                }
-                unsigned fhh[4], fll[4];
-#pragma unroll
-                for (int e = 0; e < 2; ++e) {
-                    auto rh = __builtin_amdgcn_permlane32_swap(xh[e], yh[e], false, false);
-                    fhh[e] = rh[0]; fhh[2 + e] = rh[1];
-                    if (SPLIT == 3) {
-                        auto rl = __builtin_amdgcn_permlane32_swap(xl[e], yl[e], false, false);
-                        fll[e] = rl[0]; fll[2 + e] = rl[1];
-                    }
-                }
-                const bf16x8 ph = __builtin_bit_cast(bf16x8, *reinterpret_cast<uint4*>(fhh));
-                bf16x8 pl;
-                if (SPLIT == 3) pl = __builtin_bit_cast(bf16x8, *reinterpret_cast<uint4*>(fll));
-#pragma unroll
-                for (int ot = 0; ot < NOT; ++ot) {
-                    const int cur = (s * NOT + ot) & 1, nxt = cur ^ 1;
-                    if (ot + 1 < NOT || s == 0) {
-                        const char* nx = ot + 1 < NOT ? w2_addr(ot + 1, s) : w2_addr(0, 1);
-                        w2f[nxt][0] = *reinterpret_cast<const bf16x8*>(nx);
-                        if (SPLIT == 3) w2f[nxt][1] = *reinterpret_cast<const bf16x8*>(nx + W2LO);
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-                    if (SPLIT == 3) {
-                        acc2[ot] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w2f[cur][1], ph, acc2[ot], 0, 0, 0);
-                        acc2[ot] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w2f[cur][0], pl, acc2[ot], 0, 0, 0);
-                    }
-                    acc2[ot] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w2f[cur][0], ph, acc2[ot], 0, 0, 0);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-            }
+        };
+        using T_ = std::true_type;
+        using F_ = std::false_type;
+        // step i: P1 -> H[i & 1]; GELU: H[(i+1) & 1] -> Fr[(i+1) & 1]; P2 reads Fr[i & 1]
+        step(T_{}, F_{}, F_{}, 0, H0, H1, F1, F0);
+        step(T_{}, T_{}, F_{}, 1, H1, H0, F0, F1);
+#pragma unroll 1
+        for (int i = 2; i < NT1; i += 2) {
+            step(T_{}, T_{}, T_{}, i, H0, H1, F1, F0);
+            step(T_{}, T_{}, T_{}, i + 1, H1, H0, F0, F1);
         }
+        step(F_{}, T_{}, T_{}, NT1, H0, H1, F1, F0);
+        step(F_{}, F_{}, T_{}, NT1 + 1, H1, H0, F0, F1);
+
         // ---- epilogue: x[frame][c] += gamma[c] (out + b2[c]); channel(r) = 32 ot + (r & 3) + 8 (r >> 2) + 4 fh ----------
         if (m_cur < a.M) {
             float* xr = a.x + a.img.at(m_cur);
@@ -339,18 +348,17 @@ __global__ __launch_bounds__(NW * 64) void codec_ffn_stream_kernel(FfnStreamArgs
                 }
             }
         }
-        // the counted waits of the tile loop assume only DMA pieces are outstanding: drain this pass's loads / stores
-        // (and with them the S-1 tiles already prefetched for the next pass, which have had a whole epilogue to land)
+        // the counted waits of the step loop assume only DMA pieces are outstanding: drain this pass's loads / stores
         wait_vmcnt<0>();
     }
 }
 
-template <int C, int SPLIT, int NW, int S, int TPB>
+template <int C, int SPLIT, int NW, int S>
 static hipError_t ffn_stream_go(const FfnStreamArgs& a, hipStream_t st) {
     constexpr int NARR = SPLIT == 3 ? 2 : 1;
-    constexpr size_t lds = (size_t)S * TPB * NARR * 128 * C + (size_t)7 * C * 4;
+    constexpr size_t lds = (size_t)S * NARR * 128 * C + (size_t)7 * C * 4;
     static_assert(lds <= 160 * 1024, "ring exceeds LDS");
-    auto kern = codec_ffn_stream_kernel<C, SPLIT, NW, S, TPB>;
+    auto kern = codec_ffn_stream_kernel<C, SPLIT, NW, S>;
     static bool done = false;
     static int cus = 256;
     if (!done) {
@@ -375,8 +383,8 @@ hipError_t launch_codec_ffn_stream(float* x, RowMap img, const float* norm_w, co
     if (M <= 0) return hipSuccess;
     FfnStreamArgs a{x, img, norm_w, w1hi, w1lo, b1, w2thi, w2tlo, b2, gamma, M, eps};
     ProfScope ps(st, C == 128 ? "codec_ffn_stream<128>" : "codec_ffn_stream<256>", 4.0 * M * (double)C * F, 8.0 * M * C + 8.0 * (double)C * F);
-    if (C == 128) return split == 3 ? ffn_stream_go<128, 3, 8, 4, 1>(a, st) : ffn_stream_go<128, 1, 8, 4, 1>(a, st);
-    return split == 3 ? ffn_stream_go<256, 3, 4, 2, 1>(a, st) : ffn_stream_go<256, 1, 4, 4, 1>(a, st);
+    if (C == 128) return split == 3 ? ffn_stream_go<128, 3, 8, 4>(a, st) : ffn_stream_go<128, 1, 8, 4>(a, st);
+    return split == 3 ? ffn_stream_go<256, 3, 4, 2>(a, st) : ffn_stream_go<256, 1, 4, 4>(a, st);
 }
 
 // out[(t * C + c) * 32 + k] = in[c * F + 32 t + k]   (W2 [C][F] -> hidden-tile-major)

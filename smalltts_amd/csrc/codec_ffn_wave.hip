@@ -31,39 +31,6 @@ __device__ __forceinline__ void split_pair(float a, float b, unsigned& hi, unsig
     lo = cvt_pk_bf16(a - __uint_as_float(hi << 16), b - __uint_as_float(hi & 0xffff0000u));
 }
 
-#ifdef GELU_SCALAR
-__device__ __forceinline__ float gelu1_(float x) {
-    const float t = fast_rcp(fmaf(fabsf(x), 0.3275911f * 0.70710678118654752f, 1.0f));
-    const float poly = t * fmaf(t, fmaf(t, fmaf(t, fmaf(t, 1.061405429f, -1.453152027f), 1.421413741f), -0.284496736f), 0.254829592f);
-    const float e = __builtin_amdgcn_exp2f((x * x) * (-0.5f * 1.4426950408889634f));
-    const float u = fmaf(-poly, e, 1.0f);
-    const float hx = 0.5f * x;
-    return fmaf(fabsf(hx), u, hx);
-}
-#endif
-__device__ __forceinline__ f32x2 gelu2(f32x2 x) {
-#ifdef GELU_SCALAR
-    { f32x2 r; r.x = gelu1_(x.x); r.y = gelu1_(x.y); return r; }
-#endif
-    // exact-erf GELU, A&S 7.1.26 (|erf error| <= 1.5e-7): erfc(z) = t (a1 + t (a2 + ...)) exp(-z^2), t = 1 / (1 + p z),
-    // z = |x| / sqrt 2.  gelu(x) = x/2 (1 + erf(x / sqrt 2)) = x/2 + |x|/2 (1 - erfc(z)): no compare / select, the |.| are
-    // free source modifiers, the polynomial runs on v_pk_* ops (two values per instruction).
-    f32x2 t;
-    t.x = fast_rcp(fmaf(fabsf(x.x), 0.3275911f * 0.70710678118654752f, 1.0f));
-    t.y = fast_rcp(fmaf(fabsf(x.y), 0.3275911f * 0.70710678118654752f, 1.0f));
-    const f32x2 poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
-    const f32x2 ea = (x * x) * (-0.5f * 1.4426950408889634f);  // exp(-z^2) = exp2(-x^2/2 log2 e)
-    f32x2 e;
-    e.x = __builtin_amdgcn_exp2f(ea.x);
-    e.y = __builtin_amdgcn_exp2f(ea.y);
-    const f32x2 u = 1.0f - poly * e;  // erf(z)
-    const f32x2 hx = 0.5f * x;
-    f32x2 r;
-    r.x = fmaf(fabsf(hx.x), u.x, hx.x);
-    r.y = fmaf(fabsf(hx.y), u.y, hx.y);
-    return r;
-}
-
 struct FfnWaveArgs {
     float* x;
     RowMap img;            // row m of x
