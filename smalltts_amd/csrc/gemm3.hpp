@@ -268,6 +268,15 @@ static inline int gemm3_pick_cfg(int M, int N, bool paired) {
     extern int g_gemm3_t160;
     const long t160 = (long)((M + 159) / 160) * ((N + 127) / 128);
     if (g_gemm3_t160 && M <= 640 && M > 480 && t160 > 128 && t160 <= 256) return G3_160x128;
+    if (g_gemm3_t160 && M > 640 && N >= 128) {
+        // rounds x measured time of one k-tile round (us: 64x128 1.03, 128x128 2.0, 160x128 2.37; one workgroup per CU each):
+        // the 160-row tile wins where it saves a round, e.g. 4800 x 1024: 600 tiles of 64x128 = 3 rounds vs 240 = 1 round
+        auto rounds = [](long t) { return (double)((t + 255) / 256); };
+        const double c64 = rounds((long)((M + 63) / 64) * ((N + 127) / 128)) * 1.03;
+        const double c128 = rounds((long)((M + 127) / 128) * ((N + 127) / 128)) * 2.0;
+        const double c160 = rounds(t160) * 2.37;
+        if (c160 < 0.96 * c64 && c160 < 0.96 * c128) return G3_160x128;
+    }
     const long t128 = (long)((M + 127) / 128) * ((N + 127) / 128);
     if (t128 >= 512 || (t128 >= 128 && t128 <= 256)) return G3_128x128;
     const long t64x128 = (long)((M + 63) / 64) * ((N + 127) / 128);
