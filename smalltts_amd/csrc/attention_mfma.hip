@@ -227,24 +227,23 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(AttnArgs a) {
         const float inv = l_run > 0.f ? 1.0f / l_run : 0.f;
         const long gbase = (long)b * a.bs + (long)n * a.rs + h * DH;
         const long obase = (long)b * a.obs + (long)n * a.ors + h * DH;
-        float gv[16];
+        // accumulator rows 4 q .. 4 q + 3 are four consecutive dims 32 w + 8 q + 4 fh + (0..3): one 16-B gate load and one
+        // 8-B store per array for each group (DH % 4 == 0, so a group is entirely inside or outside the head)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int d = 32 * w + (r & 3) + 8 * (r >> 2) + 4 * fh;
-            gv[r] = d < DH ? a.gate[gbase + d] : 0.f;
-        }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int d = 32 * w + (r & 3) + 8 * (r >> 2) + 4 * fh;
-            if (d < DH) {
-                const float val = oacc[r] * inv * sigmoid_f(gv[r]);
+        for (int q = 0; q < 4; ++q) {
+            const int d0 = 32 * w + 8 * q + 4 * fh;
+            if (d0 < DH) {
+                const float4 g4 = *reinterpret_cast<const float4*>(a.gate + gbase + d0);
+                const float val[4] = {oacc[4 * q + 0] * inv * sigmoid_f(g4.x), oacc[4 * q + 1] * inv * sigmoid_f(g4.y),
+                                      oacc[4 * q + 2] * inv * sigmoid_f(g4.z), oacc[4 * q + 3] * inv * sigmoid_f(g4.w)};
                 if (a.out_hi) {
-                    bf16_t hh, ll;
-                    split1(val, hh, ll);
-                    a.out_hi[obase + d] = hh;
-                    if (a.out_lo) a.out_lo[obase + d] = ll;
+                    bf16x4 hh, ll;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { bf16_t x, y; split1(val[e], x, y); hh[e] = x; ll[e] = y; }
+                    *reinterpret_cast<bf16x4*>(a.out_hi + obase + d0) = hh;
+                    if (a.out_lo) *reinterpret_cast<bf16x4*>(a.out_lo + obase + d0) = ll;
                 } else {
-                    a.out[obase + d] = val;
+                    *reinterpret_cast<float4*>(a.out + obase + d0) = make_float4(val[0], val[1], val[2], val[3]);
                 }
             }
         }
@@ -271,7 +270,7 @@ static hipError_t attn_mfma_go(const AttnArgs& a, hipStream_t st) {
 // requires a.prenormed (q, k already RMS-normalised + rotated by launch_qk_prep) and 16-B aligned rows
 hipError_t launch_attention_mfma(const AttnArgs& a, hipStream_t st) {
     if (a.N <= 0 || a.B <= 0) return hipSuccess;
-    if (!a.prenormed || (a.rs % 4) || (a.bs % 4) || (a.dh % 4)) return hipErrorInvalidValue;
+    if (!a.prenormed || (a.rs % 4) || (a.bs % 4) || (a.dh % 4) || (a.ors % 4) || (a.obs % 4)) return hipErrorInvalidValue;
     const double kt = a.N + (a.k_ref ? a.R : 0) + (a.k_text ? a.P : 0);
     const double bh = (double)a.B * a.H;
     ProfScope ps(st, a.dh == 120 ? "attention_mfma<120>" : a.dh == 64 ? "attention_mfma<64>" : "attention_mfma<128>",
