@@ -59,15 +59,16 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(AttnArgs a) {
     for (int c0 = 0; c0 < Ktot; c0 += KC) {
         __syncthreads();  // previous chunk consumed (and Q image visible on the first pass)
         // ---- stage K chunk [key][dim] and V^T chunk [dim][key], split hi/lo.  All global loads of the chunk are
-        // issued before the first LDS store (one memory round trip per chunk, not one per item). --------------------
+        // issued before the first LDS store (one memory round trip per chunk, not one per item).  A thread owns 4 dims of
+        // ITEMS CONSECUTIVE keys, so its V^T output is one 16-B (8 keys) or 8-B (4 keys) piece per dim row. ------------------
         {
-            constexpr int ITEMS = KC * (DHP / 4) / 256;  // float4 items per thread (4 or 8)
+            constexpr int TPR = DHP / 4;                 // threads per key row (16 or 32)
+            constexpr int ITEMS = KC * TPR / 256;        // keys per thread (4 or 8)
+            const int r0 = (tid / TPR) * ITEMS, d = (tid % TPR) * 4;
             float4 kq[ITEMS], vq[ITEMS];
 #pragma unroll
             for (int it = 0; it < ITEMS; ++it) {
-                const int i = it * 256 + tid;
-                const int r = i / (DHP / 4), d = (i % (DHP / 4)) * 4;
-                int gk = c0 + r;
+                int gk = c0 + r0 + it;
                 gk = gk < Ktot ? gk : Ktot - 1;          // clamp: always a readable row; masked out by vmask
                 const int dc = d < DH ? d : DH - 4;      // clamp inside the row; pad dims are zeroed below
                 const float* kp;
@@ -85,13 +86,12 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(AttnArgs a) {
                 kq[it] = *reinterpret_cast<const float4*>(kp);
                 vq[it] = *reinterpret_cast<const float4*>(vp);
             }
+            float vt[4][ITEMS];  // [dim e][key]
 #pragma unroll
             for (int it = 0; it < ITEMS; ++it) {
-                const int i = it * 256 + tid;
-                const int r = i / (DHP / 4), d = (i % (DHP / 4)) * 4;
+                const int r = r0 + it;
                 const bool real = (c0 + r < Ktot) && d < DH;
                 const float kf[4] = {kq[it].x, kq[it].y, kq[it].z, kq[it].w};
-                const float vf[4] = {vq[it].x, vq[it].y, vq[it].z, vq[it].w};
                 bf16x4 kh, kl;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
@@ -102,15 +102,22 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(AttnArgs a) {
                 const int koff = r * QPITCH + (swz(r, d >> 3) << 4) + (d & 7) * 2;
                 *reinterpret_cast<bf16x4*>(smem + OFF_K + koff) = kh;
                 *reinterpret_cast<bf16x4*>(smem + OFF_K + K_ARR + koff) = kl;
+                vt[0][it] = real ? vq[it].x : 0.f; vt[1][it] = real ? vq[it].y : 0.f;
+                vt[2][it] = real ? vq[it].z : 0.f; vt[3][it] = real ? vq[it].w : 0.f;
+            }
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {  // transpose: Vt[dim][key]; 128-B rows, chunk = key >> 3
-                    const int dr = d + e;
-                    const float vv = real ? vf[e] : 0.f;
-                    const bf16_t vh = (bf16_t)vv, vl = (bf16_t)(vv - (float)vh);
-                    const int voff = dr * 128 + (((r >> 3) ^ ((dr >> 1) & 7)) << 4) + (r & 7) * 2;
-                    *reinterpret_cast<bf16_t*>(smem + OFF_V + voff) = vh;
-                    *reinterpret_cast<bf16_t*>(smem + OFF_V + V_ARR + voff) = vl;
+            for (int e = 0; e < 4; ++e) {  // transpose: Vt[dim][key]; 128-B rows, 16-B chunk = key >> 3
+                const int dr = d + e;
+                const int voff = dr * 128 + (((r0 >> 3) ^ ((dr >> 1) & 7)) << 4) + (r0 & 7) * 2;
+                typedef bf16_t bf16xI __attribute__((ext_vector_type(ITEMS)));
+                bf16xI vh, vl;
+#pragma unroll
+                for (int it = 0; it < ITEMS; ++it) {
+                    vh[it] = (bf16_t)vt[e][it];
+                    vl[it] = (bf16_t)(vt[e][it] - (float)vh[it]);
                 }
+                *reinterpret_cast<bf16xI*>(smem + OFF_V + voff) = vh;
+                *reinterpret_cast<bf16xI*>(smem + OFF_V + V_ARR + voff) = vl;
             }
         }
         // key validity of this chunk as a 64-bit mask (lane = key), identical in every wave
