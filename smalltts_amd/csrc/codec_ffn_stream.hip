@@ -316,7 +316,7 @@ __global__ __launch_bounds__(NW * 64) void codec_ffn_stream_kernel(FfnStreamArgs
         using T_ = std::true_type;
         using F_ = std::false_type;
         // step i: P1 -> H[i & 1]; GELU: H[(i+1) & 1] -> Fr[(i+1) & 1]; P2 reads Fr[i & 1]
-        step(T_{}, F_{}, F_{}, 0, H0, H1, F1, F0);
+        step(T_{}, F_{}, F_{}, 0, H0, H0, F1, F0);  // (no GELU / second product yet: hr, fr_ unused)
         step(T_{}, T_{}, F_{}, 1, H1, H0, F0, F1);
 #pragma unroll 1
         for (int i = 2; i < NT1; i += 2) {

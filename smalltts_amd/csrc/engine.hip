@@ -1187,7 +1187,11 @@ int Engine::codec_decode(hipStream_t st, const float* latents, int B, int T, flo
             HIPC(launch_zero_pad_frames(w.nb, B, Tn, Cn, pad, st));
             RowMap am = rowmap_batched(C, Ti, (long)(pad + Ti) * C, (long)(pad - 1) * C);
             RowMap om = rowmap_batched((long)r * Cn, Ti, (long)(pad + Tn) * Cn, (long)pad * Cn);
-            HIPC(gemm_store(ops(x, am, sg.resample, B * Ti), ACT_NONE, store_to(xn, om, sg.resample_bias), 1, split_, st));
+            if (fused_ffn_ && codec_upsample_wave_ok(sg.resample.K, sg.resample.N) && sg.resample.K == 2 * C && sg.resample.N == r * Cn)
+                HIPC(launch_codec_upsample_wave(x, am, sg.resample.hi, sg.resample.lo, sg.resample.K, sg.resample_bias, xn, om,
+                                                B * Ti, sg.resample.K, sg.resample.N, split_, st));
+            else
+                HIPC(gemm_store(ops(x, am, sg.resample, B * Ti), ACT_NONE, store_to(xn, om, sg.resample_bias), 1, split_, st));
             float* t = x; x = xn; xn = t;
             Ti = Tn;
             C = Cn;

@@ -122,6 +122,10 @@ hipError_t launch_w2_tile_pack(const bf16_t* in, bf16_t* out, int C, int F, hipS
 // x[m][n] += mask(m) * gate[(grow0 + (m / rows_per_batch) * grstride) * gld + n] * (sum_s part[s][m][n] + bias[n])
 // (gate == null -> 1; fixed summation order s = 0..S-1).  Closes a split-K GEMM (see gemm3_resid_splitk).
 // split-K reduce + gated residual, then LayerNorm * (1 + scale) + shift of the updated row -> split bf16 (the next AdaLN)
+// Streaming ConvTranspose1d-as-GEMM for the two finest codec stages (W resident in LDS, one wave per 32 rows): codec_upsample.hip
+bool codec_upsample_wave_ok(int K, int N);
+hipError_t launch_codec_upsample_wave(const float* x, RowMap amap, const bf16_t* whi, const bf16_t* wlo, int ldw, const float* bias,
+                                      float* out, RowMap omap, int M, int K, int N, int split, hipStream_t st);
 hipError_t launch_splitk_resid_ln(const float* part, int S, float* x, const float* bias, const float* gate, long gld,
                                   int grow0, int grstride, int rows_per_batch, const uint8_t* rowmask, int M, int N, float eps,
                                   const float* shift, const float* scale, bf16_t* yhi, bf16_t* ylo, hipStream_t st,

@@ -19,6 +19,9 @@ def prof_name(kernel: str):
     m = re.match(r"codec_ffn_(stream|wave)_kernel<(\d+),", k)
     if m:
         return f"codec_ffn_{m.group(1)}<{m.group(2)}>"
+    m = re.match(r"(?:\(anonymous namespace\)::)?codec_upsample_wave_kernel<(\d+), (\d+),", k)
+    if m:
+        return f"codec_upsample_wave<{m.group(1)}x{m.group(2)}>"
     m = re.match(r"(attention_mfma|attention|qk_prep)_kernel<(\d+)>", k)
     if m:
         return f"{m.group(1)}<{m.group(2)}>" if m.group(1) == "attention_mfma" else m.group(1)
