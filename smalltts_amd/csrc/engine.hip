@@ -1190,7 +1190,13 @@ int Engine::codec_decode(hipStream_t st, const float* latents, int B, int T, flo
             if (fused_ffn_ && codec_upsample_wave_ok(sg.resample.K, sg.resample.N) && sg.resample.K == 2 * C && sg.resample.N == r * Cn)
                 HIPC(launch_codec_upsample_wave(x, am, sg.resample.hi, sg.resample.lo, sg.resample.K, sg.resample_bias, xn, om,
                                                 B * Ti, sg.resample.K, sg.resample.N, split_, st));
-            else
+            else if (fused_ffn_ && sg.resample.K % 64 == 0 && sg.resample.K >= 2048 && C % 8 == 0 && (size_t)B * (pad + Ti) * C <= max_img) {
+                // widest stages (K >= 2048; measured: 215 -> 148 us and 216 -> 193 us, no gain at K <= 1024): split the image once (pads included: they are the causal zeros) and run the DMA-ring GEMM on
+                // the overlapping rows of the split pair (n2 is free between blocks)
+                SplitBuf xs{w.n2hi, w.n2lo};
+                HIPC(launch_to_split(x, rowmap_plain(C), xs.hi, xs.lo, rowmap_plain(C), B * (pad + Ti), C, st));
+                HIPC(gemm3_store(ops3(xs, am, sg.resample, B * Ti), ACT_NONE, store_to(xn, om, sg.resample_bias), 1, split_, st));
+            } else
                 HIPC(gemm_store(ops(x, am, sg.resample, B * Ti), ACT_NONE, store_to(xn, om, sg.resample_bias), 1, split_, st));
             float* t = x; x = xn; xn = t;
             Ti = Tn;
