@@ -75,7 +75,8 @@ def test_gemm_v1_repeatable(eng):
 
 
 G3_SHAPES = [(600, 3840, 960), (600, 960, 2432), (600, 64, 960), (120, 2048, 512), (75, 60, 1984), (37, 100, 64),
-             (1000, 32, 128), (5000, 128, 64), (300, 8192, 2048), (129, 130, 192), (240, 23040, 960)]
+             (1000, 32, 128), (5000, 128, 64), (300, 8192, 2048), (129, 130, 192), (240, 23040, 960),
+             (600, 8192, 512), (4800, 1024, 256), (601, 8200, 128)]  # the last three pick the 160x128 one-round tile
 
 
 @pytest.mark.parametrize("M,N,K", G3_SHAPES)
@@ -87,7 +88,7 @@ def test_gemm3_hot_path_kernel(eng, M, N, K):
     assert err < 2e-5, f"gemm3 {M}x{N}x{K}: {err:.3e}"
 
 
-@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4])
+@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 5])   # 5 = 160x128 (10 waves, surplus DMA slots)
 @pytest.mark.parametrize("K", [64, 128, 192, 960])
 def test_gemm3_every_config_and_short_k(eng, cfg, K):
     M, N = 333, 200
