@@ -1039,6 +1039,7 @@ int Engine::codec_block(hipStream_t st, const CodecBlockW& w, float** xp, float*
     const RowMap img = rowmap_batched(C, T, (long)(pad + T) * C, (long)pad * C);
     const int F = cspec_.ffn_mult * C;
     const RowMap rc = rowmap_plain(C), rf = rowmap_plain(F);
+    bool n2_done = false;  // the FFN's normalised input was already produced by the fused depthwise-conv kernel
     // mixer: RMSNorm -> causal depthwise conv -> LayerScale residual
     if (C <= 256 && 256 % (C / 4) == 0 && cspec_.kernel <= 7 && fused_ffn_) {  // narrow stages: one out-of-place kernel, then swap images
         HIPC(launch_mixer_fused(x, *xaltp, w.norm_w, w.dw_w, w.dw_b, w.gamma, B, T, C, cspec_.kernel, pad, cspec_.eps, st));
@@ -1047,7 +1048,13 @@ int Engine::codec_block(hipStream_t st, const CodecBlockW& w, float** xp, float*
         x = *xp;
     } else {
         HIPC(launch_rmsnorm(x, img, nbuf, nullptr, nullptr, img, M, C, cspec_.eps, w.norm_w, st));
-        HIPC(launch_dwconv_resid(x, nbuf, w.dw_w, w.dw_b, w.gamma, B, T, C, cspec_.kernel, pad, st));
+        if (fused_ffn_ && C % 64 == 0 && F % 64 == 0 && C <= 2048) {  // + the FFN's RMSNorm of the updated rows (split pair n2)
+            HIPC(launch_dwconv_resid_rms(x, nbuf, w.dw_w, w.dw_b, w.gamma, B, T, C, cspec_.kernel, pad, cspec_.eps, w.ffn_norm_w,
+                                         n2hi, n2lo, rowmap_plain(C), st));
+            n2_done = true;
+        } else {
+            HIPC(launch_dwconv_resid(x, nbuf, w.dw_w, w.dw_b, w.gamma, B, T, C, cspec_.kernel, pad, st));
+        }
     }
     // FFN: RMSNorm -> Linear 4x -> GELU -> Linear -> LayerScale residual
     if (fused_ffn_ && (C == 32 || C == 64) && F == 4 * C && w.w1.K == C && w.w2.K == F) {
@@ -1075,7 +1082,7 @@ int Engine::codec_block(hipStream_t st, const CodecBlockW& w, float** xp, float*
     }
     if (C % 64 == 0) {
         SplitBuf n2{n2hi, n2lo};
-        HIPC(launch_rmsnorm(x, img, nullptr, n2hi, n2lo, rc, M, C, cspec_.eps, w.ffn_norm_w, st));
+        if (!n2_done) HIPC(launch_rmsnorm(x, img, nullptr, n2hi, n2lo, rc, M, C, cspec_.eps, w.ffn_norm_w, st));
         HIPC(gemm3_store(ops3(n2, rc, w.w1, M), ACT_GELU, store_split_to(hid, rf, w.b1), 1, split_, st));
     } else {  // K = C < 64 (last stage, C = 32): one k-tile on the fp32-A kernel, still writing the split hidden
         HIPC(launch_rmsnorm(x, img, nbuf, nullptr, nullptr, img, M, C, cspec_.eps, w.ffn_norm_w, st));

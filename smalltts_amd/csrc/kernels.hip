@@ -426,6 +426,90 @@ hipError_t launch_dwconv_resid(float* x, const float* n, const float* w, const f
     LAUNCH_CHECK();
 }
 
+// dwconv_resid followed by the FFN's RMSNorm of the updated row in one pass (wide codec stages): one wave per frame, the row
+// stays in registers for the norm.  Same arithmetic as dwconv_resid_kernel + rmsnorm_kernel.
+template <int LPR, int NV4>  // LPR lanes per frame (64: one wave, 256: the whole workgroup — few rows of many channels)
+__global__ __launch_bounds__(256) void dwconv_resid_rms_kernel(float* __restrict__ x, const float* __restrict__ nrm,
+                                                               const float* __restrict__ w, const float* __restrict__ bias,
+                                                               const float* __restrict__ gamma, int B, int T, int C4, int K,
+                                                               int pad, float eps, const float* __restrict__ nw,
+                                                               bf16_t* __restrict__ yhi, bf16_t* __restrict__ ylo, RowMap ymap) {
+    constexpr int RPB = 256 / LPR;
+    __shared__ float red[4];
+    const int sub = threadIdx.x % LPR;
+    const long row = (long)blockIdx.x * RPB + threadIdx.x / LPR;
+    const bool live = row < (long)B * T;
+    const int t = live ? (int)(row % T) : 0, b = live ? (int)(row / T) : 0;
+    const long frame0 = (long)b * (pad + T) + pad + t - (K - 1);
+    const float4* n4 = reinterpret_cast<const float4*>(nrm);
+    const float4* w4 = reinterpret_cast<const float4*>(w);
+    float4* xr = reinterpret_cast<float4*>(x) + ((long)b * (pad + T) + pad + t) * C4;
+    float4 v[NV4];
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV4; ++i) {
+        const int c = sub + LPR * i;
+        v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (live && c < C4) {
+            float4 nv[7];  // all taps of this channel group in flight together (K <= 7, checked by the launcher)
+#pragma unroll
+            for (int k = 0; k < 7; ++k) nv[k] = k < K ? n4[(frame0 + k) * C4 + c] : make_float4(0.f, 0.f, 0.f, 0.f);
+            float4 acc = reinterpret_cast<const float4*>(bias)[c];
+#pragma unroll
+            for (int k = 0; k < 7; ++k)
+                if (k < K) {
+                    const float4 wv = w4[(long)k * C4 + c];
+                    acc.x += wv.x * nv[k].x; acc.y += wv.y * nv[k].y; acc.z += wv.z * nv[k].z; acc.w += wv.w * nv[k].w;
+                }
+            const float4 g = reinterpret_cast<const float4*>(gamma)[c];
+            float4 xv = xr[c];
+            xv.x += g.x * acc.x; xv.y += g.y * acc.y; xv.z += g.z * acc.z; xv.w += g.w * acc.w;
+            xr[c] = xv;
+            v[i] = xv;
+        }
+        ss += v[i].x * v[i].x + v[i].y * v[i].y + v[i].z * v[i].z + v[i].w * v[i].w;
+    }
+    if (LPR == 64) {
+        ss = group_sum<64>(ss);
+    } else {  // fixed-order sum of the four waves' partials
+        ss = wave_sum(ss);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = ss;
+        __syncthreads();
+        ss = (red[0] + red[1]) + (red[2] + red[3]);
+    }
+    const float rstd = 1.0f / sqrtf(ss / (float)(C4 * 4) + eps);
+    if (!live) return;
+    const long yo = ymap.at((int)row);
+    const float4* nw4 = reinterpret_cast<const float4*>(nw);
+#pragma unroll
+    for (int i = 0; i < NV4; ++i) {
+        const int c = sub + LPR * i;
+        if (c < C4) {
+            const float4 g = nw4[c];
+            store_split4(yhi, ylo, yo + c * 4, make_float4(v[i].x * rstd * g.x, v[i].y * rstd * g.y, v[i].z * rstd * g.z, v[i].w * rstd * g.w));
+        }
+    }
+}
+hipError_t launch_dwconv_resid_rms(float* x, const float* n, const float* w, const float* bias, const float* gamma, int B, int T,
+                                   int C, int K, int pad, float eps, const float* norm_w, bf16_t* yhi, bf16_t* ylo, RowMap ymap,
+                                   hipStream_t st) {
+    const int c4 = C / 4;
+    if (C % 4 || pad < K - 1 || K > 7 || c4 > 512 || !yhi || !ylo) return hipErrorInvalidValue;
+    const long rows = (long)B * T;
+    if (rows == 0) return hipSuccess;
+    ProfScope ps(st, "dwconv_resid_rms", 2.0 * B * T * C * (K + 3), 16.0 * B * T * C);
+#define DWR_GO(LPR, NV) hipLaunchKernelGGL((dwconv_resid_rms_kernel<LPR, NV>), dim3((unsigned)((rows + 256 / LPR - 1) / (256 / LPR))), dim3(256), 0, st, x, n, w, bias, gamma, B, T, c4, K, pad, eps, norm_w, yhi, ylo, ymap)
+    if (rows < 4096 && c4 > 128) {  // few frames of many channels: a whole workgroup per frame
+        if (c4 <= 256) DWR_GO(256, 1);
+        else DWR_GO(256, 2);
+    } else if (c4 <= 64) DWR_GO(64, 1);
+    else if (c4 <= 128) DWR_GO(64, 2);
+    else if (c4 <= 256) DWR_GO(64, 4);
+    else DWR_GO(64, 8);
+#undef DWR_GO
+    LAUNCH_CHECK();
+}
+
 // head conv to 1 channel: weights packed [K][C]; 8 lanes cooperate on one output sample
 __global__ __launch_bounds__(256) void head_conv_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                         float bias, float* __restrict__ audio, int B, int T, int C,

@@ -97,6 +97,10 @@ hipError_t launch_rope_cossin(const float* ang, float* c, float* s, int n, hipSt
 // x[b][t][c] += gamma[c] * (sum_k w[c][k] * n[b][t - (K-1) + k][c] + bias[c])   (causal depthwise conv)
 hipError_t launch_dwconv_resid(float* x, const float* n, const float* w, const float* bias, const float* gamma,
                                int B, int T, int C, int K, int pad, hipStream_t st);
+// dwconv_resid + the RMSNorm (weight norm_w) of the updated rows written as a split bf16 pair (the next GEMM's A operand)
+hipError_t launch_dwconv_resid_rms(float* x, const float* n, const float* w, const float* bias, const float* gamma, int B, int T,
+                                   int C, int K, int pad, float eps, const float* norm_w, bf16_t* yhi, bf16_t* ylo, RowMap ymap,
+                                   hipStream_t st);
 // audio[b][t] = bias + sum_{k,c} w[k][c] * x[b][t - (K-1) + k][c]    (head conv, Cout = 1)
 hipError_t launch_head_conv(const float* x, const float* w, float bias, float* audio, int B, int T, int C, int K,
                             int pad, hipStream_t st);
