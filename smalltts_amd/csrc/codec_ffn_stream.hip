@@ -7,10 +7,10 @@
 //   slot(i) = [ W1 rows 32i..32i+32 (32 x C) | W2 columns of hidden tile i-2 (C x 32, from a tile-major repack) ], hi and lo,
 // i.e. exactly what pipeline step i needs (first product of tile i, second product of tile i-2; see the kernel).  All
 // waves of the workgroup consume slot i for their own frames, so the ring is joined by one s_barrier per step (gemm3's
-// protocol: own DMA pieces landed -> barrier -> refill the slot everybody just left).  The workgroup is persistent (walks passes of NW x 32 frames) and the ring keeps
-// running across passes.  Per pass the L2 -> LDS weight traffic is 32 C^2 bytes for NW x 32 frames: 4x (C = 128) less
-// per frame than codec_ffn_kernel, and nothing but x itself touches HBM (the unfused C = 256 path moved the 4C-wide
-// hidden through HBM twice).
+// protocol: own DMA pieces landed -> barrier -> refill the slot everybody just left).  The workgroup is persistent (walks
+// passes of NW x 32 frames) and the ring keeps running across passes.  Per pass the L2 -> LDS weight traffic is 32 C^2
+// bytes for NW x 32 frames, and nothing but x itself touches HBM (the unfused C = 256 path moved the 4C-wide hidden
+// through HBM twice).
 #include "gemm3.hpp"
 #include "kernels.hpp"
 #include "prof.hpp"

@@ -10,8 +10,9 @@
 //   accumulator rows it holds are exactly what v_permlane32_swap turns into the B fragments of the second product
 //   (same trick as attention_mfma.hip), so the 4C-wide hidden never leaves the register file;
 //   Out^T[channel][frame] += W2 . H^T   A = W2 fragments (LDS), one 32-row hidden tile at a time.
-// The waves of a CU drift apart, so one wave's GELU (VALU) overlaps another's MFMAs without any scheduling effort.
-// Replaces codec_ffn_kernel<64> (C = 64 and the zero-padded C = 32 case, which wasted half of every MFMA).
+// The hidden tiles are software-pipelined inside each wave (see the kernel): two waves that share a SIMD do not overlap one
+// wave's GELU with the other's MFMAs by themselves (measured: tools/ubench/mfma_valu.hip), and packed fp32 instructions never
+// run next to MFMAs at all.
 #include "gemm3.hpp"
 #include "kernels.hpp"
 #include "prof.hpp"
