@@ -229,13 +229,32 @@ def main():
 
     if rank == 0 and not args.no_roofline:
         # per-kernel HIP-event timing on the launch stream, separate (untimed) passes
-        eng.profile(True)
+        eng.profile(True, tagged=True)   # names come back as "<phase>/<kernel>" (enc, mod, dit, dec.s<i>, cenc.s<i>)
         reps = min(args.steps, 5)   # same workload as the timed region, events on the launch stream
         for i in range(reps):
             one_step(eng, inp, 900 + i, None, args.workload)
         torch.cuda.synchronize()
-        rows = eng.profile_report()
+        tagged = eng.profile_report()
         eng.profile(False)
+        merged, phases = {}, {}
+        for r in tagged:
+            ph, _, kname = r["name"].partition("/") if "/" in r["name"] else ("-", "", r["name"])
+            k = merged.setdefault(kname, {"name": kname, "ms": 0.0, "launches": 0, "flops": 0.0, "bytes": 0.0})
+            group = "dit_sampler" if ph in ("dit", "mod") else "cond_encoders" if ph == "enc" else \
+                    "codec_encode" if ph.startswith("cenc") else "codec_decode"   # untagged: head conv / stem of the decoder
+            g_ = phases.setdefault(group, {"ms": 0.0, "flops": 0.0, "bytes": 0.0})
+            for d_ in (k, g_):
+                d_["ms"] += r["ms"]; d_["flops"] += r["flops"]; d_["bytes"] += r["bytes"]
+            k["launches"] += r["launches"]
+        rows = list(merged.values())
+        # DiT and codec roofline fractions separately.  Algorithmic flops (counted once, not x3 for the split) and
+        # algorithmic bytes of the phase's kernels / the sum of their HIP-event times per batch.
+        res["phase_roofline"] = {
+            g: {"ms_per_step": round(v["ms"] / reps, 3), "TFLOPs": round(v["flops"] / max(v["ms"], 1e-9) / 1e9, 2),
+                "GBs": round(v["bytes"] / max(v["ms"], 1e-9) / 1e6, 1),
+                "mfma_frac": round(v["flops"] / max(v["ms"], 1e-9) / 1e9 / MFMA_BF16_PEAK_TF, 5),
+                "hbm_frac": round(v["bytes"] / max(v["ms"], 1e-9) / 1e6 / HBM_PEAK_GBS, 5)}
+            for g, v in sorted(phases.items(), key=lambda kv: -kv[1]["ms"])}
         rows.sort(key=lambda r: -r["ms"])
         tot = sum(r["ms"] for r in rows)
         top = rows[0]
