@@ -87,6 +87,26 @@ def test_full_spec_decode_10s_vs_oracle(eng, golden_seed):
     assert torch.equal(g2[0], got[0]) and torch.equal(g2[1, :, :40 * 3200], got[0, :, :40 * 3200])
 
 
+def test_full_spec_decode_bench_batch_vs_oracle(eng, golden_seed):
+    """The bench's codec workload exactly: 8 x 75 frames.  At this size the coarse stages take the paths a single utterance
+    never sees (M = 600 / 4800: 160x128 one-round tiles, split-K second product + RowMap reduce, gemm3 upsampling on the
+    split image), so it gets its own check: two utterances against the CPU oracle, all eight against the single-utterance
+    GPU result (different tile shapes -> different summation order, hence a bound instead of bit equality)."""
+    wd = O.to_torch(synth_state_dict(codec_decoder_param_specs(DEFAULT_CODEC), golden_seed))
+    lat = torch.randn(8, 75, 64, generator=torch.Generator().manual_seed(11))
+    got = eng.codec_decode(lat).cpu()
+    assert tuple(got.shape) == (8, 1, 240000)
+    with torch.no_grad():
+        for b in (0, 5):
+            ref = CO.decode(wd, lat[b:b + 1], DEFAULT_CODEC)
+            s = snr_db(got[b:b + 1].numpy(), ref.numpy())
+            assert s > 60.0, f"utterance {b} of the batch of 8: decode SNR {s:.1f} dB"
+    for b in range(8):
+        one = eng.codec_decode(lat[b:b + 1]).cpu()
+        s = snr_db(got[b:b + 1].numpy(), one.numpy())
+        assert s > 90.0, f"utterance {b}: batch-of-8 vs single SNR {s:.1f} dB"
+
+
 @pytest.mark.parametrize("B,T", [(1, 1), (3, 2), (2, 5)])
 def test_full_spec_decode_odd_frame_counts_vs_oracle(eng, golden_seed, B, T):
     """Partial tiles of the fused FFN kernels: at T = 1 the C = 256 stage has 200 frames (1.56 passes of 128), the
