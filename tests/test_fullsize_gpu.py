@@ -149,6 +149,25 @@ def test_full_spec_encode_2s_vs_oracle(eng, golden_seed):
     assert s > 60.0, f"encode SNR {s:.1f} dB"
 
 
+def test_full_spec_encode_bench_batch_vs_oracle(eng, golden_seed):
+    """The clone workload's codec encode exactly: 8 reference clips of 2 s (bench.rs:5) in one batch."""
+    we = O.to_torch(synth_state_dict(codec_encoder_param_specs(DEFAULT_CODEC), golden_seed))
+    t = torch.arange(48000, dtype=torch.float32) / 24000.0
+    g = torch.Generator().manual_seed(12)
+    audio = torch.stack([torch.sin(2 * np.pi * (220.0 + 55.0 * i) * t) * 0.8 + 0.05 * torch.randn(48000, generator=g)
+                         for i in range(8)])[:, None]
+    got = eng.codec_encode(audio).cpu()
+    assert tuple(got.shape) == (8, 15, 64)
+    with torch.no_grad():
+        ref = CO.encode(we, audio[3:4], DEFAULT_CODEC)
+    s = snr_db(got[3:4].numpy(), ref.numpy())
+    assert s > 60.0, f"utterance 3 of the batch of 8: encode SNR {s:.1f} dB"
+    for b in range(8):
+        one = eng.codec_encode(audio[b:b + 1]).cpu()
+        s = snr_db(got[b:b + 1].numpy(), one.numpy())
+        assert s > 90.0, f"utterance {b}: batch-of-8 vs single encode SNR {s:.1f} dB"
+
+
 def test_batch_of_eight_equals_eight_singles_through_the_whole_path(eng):
     """BASELINE 'batch=8' semantics: the reference runs 8 sequential batch-1 calls (bench.rs:42-44); the batched GPU
     path must give each utterance the same audio."""
