@@ -831,6 +831,9 @@ int Engine::denoise_core(hipStream_t st, const float* x_t, const uint8_t* mask, 
     // (split-K reduction + gated residual + LayerNorm-modulate in one pass); only the very first one runs alone.
     HIPC(launch_ln_modulate(w.x, nullptr, w.y.hi, w.y.lo, M, kHidden, 1e-6f, mod + 0 * kHidden, mod + 1 * kHidden, kModLd,
                             mod_row0, mod_rstride, N, st));
+    // split-K exists to fill the chip at M = 600 (150 tiles of 64x64 for N = 960); the 3B-row CFG batches of the teacher
+    // sampler (M = 1800: 435 tiles) fill it without, and the fused epilogue is cheaper than partials + reduce (495 -> 454 ms)
+    const int ks_out = M > 1024 ? 1 : ksplit_out_, ks_ff2 = M > 1024 ? 1 : ksplit_ff2_;
     for (int l = 0; l < kBlocks; ++l) {
         const DitBlockW& b = blocks_[l];
         const float* m = mod + (long)l * kModPerBlock;
@@ -854,8 +857,8 @@ int Engine::denoise_core(hipStream_t st, const float* x_t, const uint8_t* mask, 
         // to_out + mask + gated residual (dit.py:117-118,198), then the MLP AdaLN (dit.py:199)
         EpiResid<0> r1{w.x, rh, nullptr, m + 2 * kHidden, kModLd, mod_row0, mod_rstride, N, mask};
         NextLN ln1{m + 3 * kHidden, m + 4 * kHidden, w.y.hi, w.y.lo};
-        if (ksplit_out_ > 1) {
-            HIPC(gemm3_resid_splitk(ops3(w.o, rh, b.out, M), r1, w.part, ksplit_out_, split_, st, ln1));
+        if (ks_out > 1) {
+            HIPC(gemm3_resid_splitk(ops3(w.o, rh, b.out, M), r1, w.part, ks_out, split_, st, ln1));
         } else {
             HIPC(gemm3_resid(ops3(w.o, rh, b.out, M), 1, r1, split_, st));
             HIPC(launch_ln_modulate(w.x, nullptr, w.y.hi, w.y.lo, M, kHidden, 1e-6f, ln1.shift, ln1.scale, kModLd, mod_row0,
@@ -870,8 +873,8 @@ int Engine::denoise_core(hipStream_t st, const float* x_t, const uint8_t* mask, 
         const float* mn = m + kModPerBlock;  // next block's modulation (or the final norm's [scale | shift])
         NextLN ln2 = l + 1 < kBlocks ? NextLN{mn + 0 * kHidden, mn + 1 * kHidden, w.y.hi, w.y.lo}
                                      : NextLN{mn + kHidden, mn, w.y.hi, w.y.lo};
-        if (ksplit_ff2_ > 1) {
-            HIPC(gemm3_resid_splitk(ops3(w.ffh, rowmap_plain(kFFp), b.ff2, M), r2, w.part, ksplit_ff2_, split_, st, ln2));
+        if (ks_ff2 > 1) {
+            HIPC(gemm3_resid_splitk(ops3(w.ffh, rowmap_plain(kFFp), b.ff2, M), r2, w.part, ks_ff2, split_, st, ln2));
         } else {
             HIPC(gemm3_resid(ops3(w.ffh, rowmap_plain(kFFp), b.ff2, M), 1, r2, split_, st));
             HIPC(launch_ln_modulate(w.x, nullptr, w.y.hi, w.y.lo, M, kHidden, 1e-6f, ln2.shift, ln2.scale, kModLd, mod_row0,

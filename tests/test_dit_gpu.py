@@ -140,6 +140,26 @@ def test_teacher_ode_cfg_vs_oracle(eng, dit_weights):
     assert err < 5 * TOL, f"teacher ODE rel L2 {err:.3e}"
 
 
+def test_teacher_cfg_at_bench_size_vs_oracle(eng, dit_weights):
+    """Config 5's row count: B = 8 x N = 75 with CFG = 1800 rows per denoiser call.  Above 1024 rows the two N = 960
+    projections run unsplit with fused epilogues (no split-K partials), a path the M = 600 workloads never take."""
+    gen = torch.Generator().manual_seed(15)
+    B, N, R, P, steps = 8, 75, 15, 30, 2
+    ref = torch.randn(B, R, 64, generator=gen)
+    ids = torch.randint(1, 198, (B, P), generator=gen)
+    pm = torch.ones(B, P, dtype=torch.bool); rl = torch.full((B,), R)
+    mask = torch.ones(B, N, dtype=torch.bool)
+    noise = torch.randn(B, N, 64, generator=gen)
+    ref3, len3, ids3, pm3 = O.cfg_conditions(ref, rl, ids, pm)
+    with torch.no_grad():
+        oc = O.encode_conditions(dit_weights, ref3, len3, ids3, pm3)
+        ox = O.sample_teacher_ode(dit_weights, oc, pm3, mask, noise, steps)
+    cache3 = eng.cond_encode(ref3, len3, ids3, pm3)
+    x = eng.sample(cache3, mask, num_steps=steps, mode="ode", cfg=True, noise=noise).cpu().numpy()
+    err = rel_l2(x, ox.numpy())
+    assert err < 5 * TOL, f"teacher ODE at 1800 rows: rel L2 {err:.3e}"
+
+
 def test_on_device_noise_is_seeded_and_reproducible(eng):
     ref, ref_len, ids, pm, mask, _ = _bench_inputs(B=2, N=20)
     cache = eng.cond_encode(ref, ref_len, ids, pm)
