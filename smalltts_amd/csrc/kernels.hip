@@ -529,12 +529,51 @@ __global__ __launch_bounds__(256) void head_conv_kernel(const float* __restrict_
     acc = group_sum<8>(acc);
     if (live && sub == 0) audio[s] = acc + bias;
 }
+// C = 32 (the full-rate stage of the default spec): a workgroup stages 256 + K - 1 frames in LDS once (rows padded to 33 floats:
+// lane t reads frame t + k, channel c without bank conflicts) and every thread then produces one sample from LDS, the K x 32
+// weights coming from LDS as broadcasts — each frame is read from memory once instead of K times through L1.
+__global__ __launch_bounds__(256) void head_conv32_kernel(const float* __restrict__ x, const float* __restrict__ w, float bias,
+                                                          float* __restrict__ audio, int T, int K, int pad, int tiles_per_b) {
+    constexpr int C = 32, TT = 256;
+    extern __shared__ __attribute__((aligned(16))) float hsm[];
+    float* xs = hsm;                        // [(TT + K - 1)][33]
+    float* ws = hsm + (TT + 6) * 33 + 32;   // [K][32]  (K <= 7)
+    const int b = blockIdx.x / tiles_per_b, t0 = (blockIdx.x % tiles_per_b) * TT;
+    const int H = K - 1;
+    const int nfr = (T - t0 < TT ? T - t0 : TT) + H;
+    const float* x0 = x + ((long)b * (pad + T) + pad + t0 - H) * C;   // first halo frame (inside the zero pad for t0 = 0)
+    for (int i = threadIdx.x; i < nfr * (C / 4); i += 256) {
+        const int f = i / (C / 4), c4 = i % (C / 4);
+        const float4 v = reinterpret_cast<const float4*>(x0 + (long)f * C)[c4];
+        float* d = xs + f * 33 + c4 * 4;
+        d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+    }
+    for (int i = threadIdx.x; i < K * C; i += 256) ws[i] = w[i];
+    __syncthreads();
+    const int t = threadIdx.x;
+    if (t0 + t >= T) return;
+    float acc = 0.f;
+    for (int k = 0; k < K; ++k) {
+        const float* xr = xs + (t + k) * 33;
+        const float* wr = ws + k * C;
+#pragma unroll
+        for (int c = 0; c < C; ++c) acc = fmaf(xr[c], wr[c], acc);
+    }
+    audio[(long)b * T + t0 + t] = acc + bias;
+}
+
 hipError_t launch_head_conv(const float* x, const float* w, float bias, float* audio, int B, int T, int C, int K,
                             int pad, hipStream_t st) {
     if (C % 4 || pad < K - 1) return hipErrorInvalidValue;
     long threads = (long)B * T * 8;
     if (threads == 0) return hipSuccess;
     ProfScope ps(st, "head_conv", 2.0 * B * T * C * K, 4.0 * B * T * (C + 1));
+    if (C == 32 && K <= 7 && T >= 256) {
+        const int tiles = (T + 255) / 256;
+        const size_t lds = ((size_t)(256 + 6) * 33 + 32 + 7 * 32) * sizeof(float);
+        hipLaunchKernelGGL(head_conv32_kernel, dim3((unsigned)(B * tiles)), dim3(256), lds, st, x, w, bias, audio, T, K, pad, tiles);
+        LAUNCH_CHECK();
+    }
     hipLaunchKernelGGL(head_conv_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, x, w, bias, audio, B, T, C,
                        K, pad);
     LAUNCH_CHECK();
