@@ -117,7 +117,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--precision", default="bf16x3", choices=["bf16x3", "bf16"])
+    ap.add_argument("--precision", default="f16",
+                    help="f16 (default: one fp16 MFMA per product on the block / encoder / codec-FFN GEMMs, split-bf16 on the "
+                         "conditioning and in / out projections), bf16x3 (split-bf16 everywhere), bf16; site overrides as f16,cond=f16")
     ap.add_argument("--workload", default="dmd4", choices=list(WORKLOADS),
                     help="dmd4 = the headline configuration; clone / teacher128 = BASELINE.json configs[2] / configs[4]")
     ap.add_argument("--in-flight", type=int, default=3,
@@ -215,7 +217,10 @@ def main():
         "value": round(audio_s / dt, 2), "unit": "audio-seconds/sec", "n_gpus": n_gpus, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None,
-        "dtype": "bf16 MFMA x3 split (fp32-class), fp32 accumulate/residual" if args.precision == "bf16x3" else "bf16",
+        "dtype": {"f16": "fp16 MFMA single pass on block/encoder/codec-FFN GEMMs + split-bf16 (x3) MFMA on conditioning and in/out "
+                         "projections; fp32 accumulate, residual stream, norms, softmax, sampler state",
+                  "bf16x3": "bf16 MFMA x3 split (fp32-class), fp32 accumulate/residual",
+                  "bf16": "bf16 MFMA single pass, fp32 accumulate/residual"}.get(args.precision, args.precision),
         "data": "synthetic (seeded inputs + seeded random weights; no released weights offline)",
         "rtf": round(dt / audio_s, 7),
         "config": {"workload": WORKLOADS[args.workload] + ", B=8 x 10 s per GPU "

@@ -50,8 +50,16 @@ int smtts_get_tensor(smtts_handle h, const char* name, float* host_out, int64_t 
 int smtts_set_codec_spec(smtts_handle h, int latent_dim, int n_filters, int kernel, int ffn_mult, float eps,
                          const int* ratios, int n_ratios, const int* depths /* n_ratios + 1 */);
 int smtts_finalize(smtts_handle h);
-/* 3 = split-bf16 MFMA (fp32-class accuracy, default) ; 1 = single-pass bf16 MFMA */
-int smtts_set_precision(smtts_handle h, int split);
+/* GEMM operand precision preset (fp32 accumulation, fp32 residual stream / norms / softmax / sampler state in all of them):
+ *   3 = split-bf16 everywhere: x = hi + lo, three bf16 MFMAs per product (fp32-class results; engine default)
+ *   2 = "f16 mixed": ONE fp16 MFMA per product on the DiT-block / encoder / cross-KV / codec-FFN GEMMs (>= 95 % of the flops and
+ *       weight bytes), split-bf16 on the conditioning chain, latent in / out projections and codec resampling convs
+ *       (measured: latent rel-L2 ~1.5e-4 vs the fp32 oracle; smalltts_amd default)
+ *   1 = single-pass bf16 everywhere (latent rel-L2 ~4e-3: outside the 1e-3 contract, kept for A/B) */
+int smtts_set_precision(smtts_handle h, int preset);
+/* one GEMM site group at a time: site 0 DiT blocks, 1 encoders, 2 cross-KV, 3 conditioning / in / out projections,
+ * 4 codec FFNs, 5 codec stem / resampling convs; prec 1 bf16, 2 fp16, 3 split-bf16 (call after smtts_set_precision) */
+int smtts_set_site_precision(smtts_handle h, int site, int prec);
 int smtts_has_part(smtts_handle h, int part); /* 0 dit, 1 codec decoder, 2 codec encoder */
 
 /* ---- condition encoder ---------------------------------------------------------------------- */

@@ -30,6 +30,7 @@ SIGNATURES: Dict[str, Tuple[object, List[object]]] = {
     "smtts_set_codec_spec": (i32, [vp, i32, i32, i32, i32, f32, C.POINTER(i32), i32, C.POINTER(i32)]),
     "smtts_finalize": (i32, [vp]),
     "smtts_set_precision": (i32, [vp, i32]),
+    "smtts_set_site_precision": (i32, [vp, i32, i32]),
     "smtts_has_part": (i32, [vp, i32]),
     "smtts_cond_workspace_bytes": (sz, [vp, i32, i32, i32]),
     "smtts_cond_encode": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, sz, vp, vp]),

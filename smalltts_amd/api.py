@@ -20,8 +20,8 @@ from typing import Dict, Iterable, List, Optional, Sequence
 import numpy as np
 import torch
 
-from .engine import HipEngine
-from .weights import DEFAULT_CODEC, CodecSpec, clean_state_dict_keys, load_weight_file
+from .engine import DEFAULT_PRECISION, HipEngine
+from .weights import DEFAULT_CODEC, CodecSpec, all_param_specs, load_weight_file
 
 SAMPLE_RATE = 24_000
 HOP_SIZE = 3_200
@@ -36,33 +36,74 @@ def estimate_duration(text: str, min_sec: float = 0.5, max_sec: float = 30.0) ->
     return max(min_sec, min(len(text) / CHARS_PER_SECOND, max_sec))
 
 
-def _load_weights_into(eng: HipEngine, weights: str, parts: Sequence[str]) -> None:
-    if weights.startswith("synthetic"):
-        seed = int(weights.split(":", 1)[1]) if ":" in weights else 0
-        eng.load_synthetic(seed, parts=parts)
-    elif weights.endswith((".pt", ".pth", ".ckpt")):
-        ck = torch.load(weights, map_location="cpu")
-        for key in ("student_model", "model"):
-            if isinstance(ck, dict) and key in ck:
-                ck = ck[key]
-        eng.load_state_dict({k: v for k, v in clean_state_dict_keys(ck).items() if hasattr(v, "shape")})
-    else:
-        if not os.path.exists(weights):
+def _split_sources(weights) -> List[str]:
+    if isinstance(weights, (list, tuple)):
+        return [str(w) for w in weights]
+    return [w for w in str(weights).split("+") if w]
+
+
+def _validated(tensors: Dict[str, object], source: str, codec: CodecSpec) -> Dict[str, object]:
+    """Reject a tensor whose shape is not the inventory's BEFORE it reaches the packers: the kernels assume the model's
+    strides (960 / 2400 / 512 ...), so a checkpoint of another model size must be a clean error naming the tensor."""
+    want = dict(all_param_specs(codec))
+    bad = [(k, tuple(v.shape), want[k]) for k, v in tensors.items() if k in want and tuple(v.shape) != tuple(want[k])]
+    if bad:
+        k, got, exp = bad[0]
+        raise ValueError(f"{source}: tensor {k!r} has shape {got}, this build expects {exp} "
+                         f"({len(bad)} mismatching tensor{'s' if len(bad) > 1 else ''}) — not a DiTModel(64) / CodecSpec checkpoint")
+    unknown = [k for k in tensors if k not in want]
+    if unknown and len(unknown) == len(tensors):
+        raise ValueError(f"{source}: none of its {len(tensors)} tensors is a parameter of this build (first: {unknown[0]!r})")
+    return {k: v for k, v in tensors.items() if k in want}
+
+
+def _load_weights_into(eng: HipEngine, weights, parts: Sequence[str]) -> None:
+    """`weights`: one source or several joined with '+' (or a list), applied in order:
+      * ``*.pt / *.pth / *.ckpt``  torch checkpoint holding the reference's ``DiTModel`` state_dict, bare or under
+        ``"student_model"`` / ``"model"`` with the wrapper prefixes of distill.py:47-54 (codec.* keys are taken too);
+      * any other path             flat weight file (`weights.save_weight_file`, written by `smalltts_amd.convert`);
+      * ``synthetic[:seed]``       seeded random weights for every requested part NOT provided by an earlier source.
+    e.g. ``"dmd.pt+codec.smtts"`` (DiT checkpoint + separately converted codec) or ``"dmd.pt+synthetic:7"``."""
+    have: set = set()
+    prefixes = {"dit": ("velocity.",), "decoder": ("codec.decoder.",), "encoder": ("codec.encoder.",)}
+    codec = eng.codec_spec
+
+    def note(names):
+        for part, pre in prefixes.items():
+            if any(n.startswith(pre) for n in names):
+                have.add(part)
+
+    for src in _split_sources(weights):
+        if src.startswith("synthetic"):
+            seed = int(src.split(":", 1)[1]) if ":" in src else 0
+            todo = [p for p in parts if p not in have]
+            if todo:
+                eng.load_synthetic(seed, parts=todo)
+                have.update(todo)
+            continue
+        if not os.path.exists(src):
             raise FileNotFoundError(
-                f"weight file {weights!r} not found. The reference downloads its ONNX weights from HuggingFace "
+                f"weight file {src!r} not found. The reference downloads its ONNX weights from HuggingFace "
                 "(assets/ensure.py); offline, pass weights='synthetic:<seed>' or a converted weight file.")
-        tensors, codec = load_weight_file(weights)
-        if codec:
-            eng.set_codec_spec(CodecSpec(**codec))
+        if src.endswith((".pt", ".pth", ".ckpt")):
+            from .convert import state_dict_from_checkpoint
+            tensors = state_dict_from_checkpoint(torch.load(src, map_location="cpu", weights_only=True))
+        else:
+            tensors, cdict = load_weight_file(src)
+            if cdict:
+                codec = CodecSpec(**cdict)
+                eng.set_codec_spec(codec)
+        tensors = _validated(tensors, src, codec)
         eng.load_state_dict(tensors)
+        note(tensors)
     eng.finalize()
 
 
-def get_engine(weights: Optional[str] = None, device: int = 0, precision: str = "bf16x3",
+def get_engine(weights: Optional[str] = None, device: int = 0, precision: str = DEFAULT_PRECISION,
                parts: Sequence[str] = ("dit", "decoder", "encoder")) -> HipEngine:
     """One engine (one weight copy) per (weights, device, parts); shared by SmallTTS/Encoder/Decoder."""
     weights = weights or DEFAULT_WEIGHTS
-    key = (weights, int(device), tuple(sorted(parts)))
+    key = ("+".join(_split_sources(weights)), int(device), tuple(sorted(parts)))
     eng = _ENGINES.get(key)
     if eng is None:
         eng = HipEngine(device, precision)
@@ -84,7 +125,7 @@ class SmallTTS:
                  denoiser_path: str = "assets/dmd/denoiser.onnx",
                  codec_decoder_path: str = "assets/codec/decoder.onnx",
                  providers: Optional[Iterable[str]] = None, *, weights: Optional[str] = None, device: int = 0,
-                 precision: str = "bf16x3", num_steps: int = NUM_STEPS, seed: Optional[int] = None,
+                 precision: str = DEFAULT_PRECISION, num_steps: int = NUM_STEPS, seed: Optional[int] = None,
                  engine: Optional[HipEngine] = None) -> None:
         self.engine = engine or get_engine(weights, device, precision, parts=("dit", "decoder", "encoder"))
         if not (self.engine.has("dit") and self.engine.has("decoder")):
@@ -191,7 +232,7 @@ class _CodecRunner:
     _part = ""
 
     def __init__(self, path: str, providers: Optional[Iterable[str]] = None, *, weights: Optional[str] = None,
-                 device: int = 0, precision: str = "bf16x3", engine: Optional[HipEngine] = None) -> None:
+                 device: int = 0, precision: str = DEFAULT_PRECISION, engine: Optional[HipEngine] = None) -> None:
         self.engine = engine or get_engine(weights, device, precision, parts=("dit", "decoder", "encoder"))
         if not self.engine.has(self._part):
             raise RuntimeError(f"codec {self._part} weights are not loaded")

@@ -81,7 +81,7 @@ def state_dict_from_checkpoint(obj, key: Optional[str] = None) -> Dict[str, np.n
 
 def convert_checkpoint(path: str, out: str, key: Optional[str] = None, allow_partial: bool = False) -> ConversionReport:
     import torch
-    ck = torch.load(path, map_location="cpu", weights_only=False)
+    ck = torch.load(path, map_location="cpu", weights_only=True)
     tensors = state_dict_from_checkpoint(ck, key)
     rep = check_against_specs(tensors, dit_param_specs())
     if not rep.ok and not allow_partial:

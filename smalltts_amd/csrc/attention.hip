@@ -305,10 +305,7 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnArgs a) {
                     const float val = o[qi][i] * inv * sigmoid_f(gv[qi][i]);
                     const long oo = (long)b * a.obs + (long)n * a.ors + h * DH + d;
                     if (a.out_hi) {
-                        bf16_t hh, ll;
-                        split1(val, hh, ll);
-                        a.out_hi[oo] = hh;
-                        if (a.out_lo) a.out_lo[oo] = ll;
+                        store_act1(a.out_hi, a.out_lo, oo, val);
                     } else {
                         a.out[oo] = val;
                     }

@@ -244,11 +244,7 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(AttnArgs a) {
                 const float val[4] = {oacc[4 * q + 0] * inv * sigmoid_f(g4.x), oacc[4 * q + 1] * inv * sigmoid_f(g4.y),
                                       oacc[4 * q + 2] * inv * sigmoid_f(g4.z), oacc[4 * q + 3] * inv * sigmoid_f(g4.w)};
                 if (a.out_hi) {
-                    bf16x4 hh, ll;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) { bf16_t x, y; split1(val[e], x, y); hh[e] = x; ll[e] = y; }
-                    *reinterpret_cast<bf16x4*>(a.out_hi + obase + d0) = hh;
-                    if (a.out_lo) *reinterpret_cast<bf16x4*>(a.out_lo + obase + d0) = ll;
+                    store_split4(a.out_hi, a.out_lo, obase + d0, make_float4(val[0], val[1], val[2], val[3]));
                 } else {
                     *reinterpret_cast<float4*>(a.out + obase + d0) = make_float4(val[0], val[1], val[2], val[3]);
                 }
@@ -262,13 +258,11 @@ static hipError_t attn_mfma_go(const AttnArgs& a, hipStream_t st) {
     constexpr int DHP = DH <= 64 ? 64 : 128;
     constexpr size_t lds = 2 * (32 * DHP * 2) + 2 * (64 * DHP * 2) + 2 * (DHP * 128);
     auto kern = attention_mfma_kernel<DH>;
-    static bool done = false;
-    if (!done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           (int)lds);
-        if (e != hipSuccess) return e;
-        done = true;
-    }
+    static DevOnce once;
+    hipError_t e = once.ensure([&] {
+        return hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    });
+    if (e != hipSuccess) return e;
     dim3 grid((a.N + 31) / 32, a.H, a.B);
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, a);
     return hipGetLastError();

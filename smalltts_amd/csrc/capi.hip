@@ -13,6 +13,9 @@ struct smtts_engine {
 static thread_local std::string g_create_err;
 
 #define E (h->e)
+// every entry point that takes a handle rejects NULL with an error code (message via smtts_last_error(NULL))
+#define NULLCHK if (!h) { g_create_err = std::string(__func__) + ": null handle"; return 1; }
+#define NULLCHK0 if (!h) { g_create_err = std::string(__func__) + ": null handle"; return 0; }
 #define ST(s) static_cast<hipStream_t>(s)
 
 extern "C" {
@@ -33,27 +36,27 @@ int smtts_create(int device_id, smtts_handle* out) {
     *out = new smtts_engine(device_id);
     return 0;
 }
-int smtts_destroy(smtts_handle h) { delete h; return 0; }
+int smtts_destroy(smtts_handle h) { delete h; return 0; }  // NULL is a no-op, like free()
 const char* smtts_last_error(smtts_handle h) { return h ? E.last_error().c_str() : g_create_err.c_str(); }
 
-int smtts_set_tensor(smtts_handle h, const char* name, const float* data, const int64_t* shape, int ndim, int on_dev) {
+int smtts_set_tensor(smtts_handle h, const char* name, const float* data, const int64_t* shape, int ndim, int on_dev) { NULLCHK;
     long sh[8];
     if (ndim > 8) return E.fail("set_tensor: ndim > 8");
     for (int i = 0; i < ndim; ++i) sh[i] = (long)shape[i];
     return E.set_tensor(name, data, sh, ndim, on_dev != 0);
 }
 int smtts_synth_tensor(smtts_handle h, const char* name, const int64_t* shape, int ndim, uint64_t key, float mean,
-                       float half_range) {
+                       float half_range) { NULLCHK;
     long sh[8];
     if (ndim > 8) return E.fail("synth_tensor: ndim > 8");
     for (int i = 0; i < ndim; ++i) sh[i] = (long)shape[i];
     return E.synth_tensor(name, sh, ndim, key, mean, half_range);
 }
-int smtts_get_tensor(smtts_handle h, const char* name, float* host_out, int64_t numel) {
+int smtts_get_tensor(smtts_handle h, const char* name, float* host_out, int64_t numel) { NULLCHK;
     return E.get_tensor(name, host_out, (long)numel);
 }
 int smtts_set_codec_spec(smtts_handle h, int latent_dim, int n_filters, int kernel, int ffn_mult, float eps,
-                         const int* ratios, int n_ratios, const int* depths) {
+                         const int* ratios, int n_ratios, const int* depths) { NULLCHK;
     CodecSpecC s;
     if (n_ratios < 1 || n_ratios > 7) return E.fail("codec spec: 1..7 ratios supported");
     s.latent_dim = latent_dim; s.n_filters = n_filters; s.kernel = kernel; s.ffn_mult = ffn_mult; s.eps = eps;
@@ -62,57 +65,58 @@ int smtts_set_codec_spec(smtts_handle h, int latent_dim, int n_filters, int kern
     for (int i = 0; i < 9; ++i) s.depths[i] = i <= n_ratios ? depths[i] : 0;
     return E.set_codec_spec(s);
 }
-int smtts_finalize(smtts_handle h) { return E.finalize(); }
-int smtts_set_precision(smtts_handle h, int split) {
-    if (split != 1 && split != 3) return E.fail("precision must be 1 (bf16) or 3 (split-bf16)");
-    E.set_precision(split);
+int smtts_finalize(smtts_handle h) { NULLCHK; return E.finalize(); }
+int smtts_set_precision(smtts_handle h, int preset) { NULLCHK;
+    if (preset < 1 || preset > 3) return E.fail("precision preset must be 1 (bf16), 2 (f16 mixed) or 3 (split-bf16)");
+    E.set_precision(preset);
     return 0;
 }
-int smtts_has_part(smtts_handle h, int part) {
+int smtts_set_site_precision(smtts_handle h, int site, int prec) { NULLCHK; return E.set_site_precision(site, prec); }
+int smtts_has_part(smtts_handle h, int part) { NULLCHK0;
     return part == 0 ? E.has_dit() : part == 1 ? E.has_decoder() : part == 2 ? E.has_encoder() : 0;
 }
 
-size_t smtts_cond_workspace_bytes(smtts_handle h, int B, int R, int P) { return E.cond_ws_bytes(B, R, P); }
+size_t smtts_cond_workspace_bytes(smtts_handle h, int B, int R, int P) { NULLCHK0; return E.cond_ws_bytes(B, R, P); }
 int smtts_cond_encode(smtts_handle h, void* stream, const float* ref, const int64_t* ref_len, const int64_t* phonemes,
                       const uint8_t* ph_mask, int B, int R, int P, float* k_ref, float* v_ref, uint8_t* ref_mask,
-                      float* k_text, float* v_text, void* ws, size_t ws_bytes, float* ref_seq_out, float* mem_out) {
+                      float* k_text, float* v_text, void* ws, size_t ws_bytes, float* ref_seq_out, float* mem_out) { NULLCHK;
     return E.cond_encode(ST(stream), ref, ref_len, phonemes, ph_mask, B, R, P, k_ref, v_ref, ref_mask, k_text, v_text, ws,
                          ws_bytes, ref_seq_out, mem_out);
 }
 
-size_t smtts_denoise_workspace_bytes(smtts_handle h, int B, int N) { return E.denoise_ws_bytes(B, N, B); }
+size_t smtts_denoise_workspace_bytes(smtts_handle h, int B, int N) { NULLCHK0; return E.denoise_ws_bytes(B, N, B); }
 int smtts_denoise_step(smtts_handle h, void* stream, const float* x_t, const uint8_t* mask, const float* t,
                        const float* k_ref, const float* v_ref, const uint8_t* ref_mask, const float* k_text,
                        const float* v_text, const uint8_t* ph_mask, const float* rope, int B, int N, int R, int P,
-                       float* velocity, void* ws, size_t ws_bytes) {
+                       float* velocity, void* ws, size_t ws_bytes) { NULLCHK;
     return E.denoise_step(ST(stream), x_t, mask, t, k_ref, v_ref, ref_mask, k_text, v_text, ph_mask, rope, B, N, R, P,
                           velocity, ws, ws_bytes);
 }
 
-size_t smtts_sample_workspace_bytes(smtts_handle h, int B, int N, int n_steps, int cfg) {
+size_t smtts_sample_workspace_bytes(smtts_handle h, int B, int N, int n_steps, int cfg) { NULLCHK0;
     return E.sample_ws_bytes(B, N, n_steps, cfg);
 }
 int smtts_sample(smtts_handle h, void* stream, int mode, int n_steps, int cfg, float s_text, float s_spk,
                  const uint8_t* mask, const float* k_ref, const float* v_ref, const uint8_t* ref_mask,
                  const float* k_text, const float* v_text, const uint8_t* ph_mask, int B, int N, int R, int P,
-                 const float* noise, uint64_t seed, float* x_out, float* steps_out, void* ws, size_t ws_bytes) {
+                 const float* noise, uint64_t seed, float* x_out, float* steps_out, void* ws, size_t ws_bytes) { NULLCHK;
     return E.sample(ST(stream), mode, n_steps, cfg, s_text, s_spk, mask, k_ref, v_ref, ref_mask, k_text, v_text, ph_mask,
                     B, N, R, P, noise, seed, x_out, steps_out, ws, ws_bytes);
 }
 
-int smtts_codec_hop(smtts_handle h) { return E.codec_spec().hop(); }
-size_t smtts_decode_workspace_bytes(smtts_handle h, int B, int T) { return E.decode_ws_bytes(B, T); }
+int smtts_codec_hop(smtts_handle h) { NULLCHK0; return E.codec_spec().hop(); }
+size_t smtts_decode_workspace_bytes(smtts_handle h, int B, int T) { NULLCHK0; return E.decode_ws_bytes(B, T); }
 int smtts_codec_decode(smtts_handle h, void* stream, const float* latents, int B, int T, float* audio, void* ws,
-                       size_t ws_bytes) {
+                       size_t ws_bytes) { NULLCHK;
     return E.codec_decode(ST(stream), latents, B, T, audio, ws, ws_bytes);
 }
-size_t smtts_encode_workspace_bytes(smtts_handle h, int B, int S) { return E.encode_ws_bytes(B, S); }
+size_t smtts_encode_workspace_bytes(smtts_handle h, int B, int S) { NULLCHK0; return E.encode_ws_bytes(B, S); }
 int smtts_codec_encode(smtts_handle h, void* stream, const float* audio, int B, int S, float* latents, void* ws,
-                       size_t ws_bytes) {
+                       size_t ws_bytes) { NULLCHK;
     return E.codec_encode(ST(stream), audio, B, S, latents, ws, ws_bytes);
 }
 
-int smtts_randn(smtts_handle h, void* stream, float* out, int64_t n, uint64_t seed, uint64_t stream_id) {
+int smtts_randn(smtts_handle h, void* stream, float* out, int64_t n, uint64_t seed, uint64_t stream_id) { NULLCHK;
     hipError_t e = launch_randn(out, (long)n, seed, stream_id, ST(stream));
     return e == hipSuccess ? 0 : E.fail_hip(e, "randn");
 }
@@ -120,47 +124,47 @@ int smtts_randn(smtts_handle h, void* stream, float* out, int64_t n, uint64_t se
 void smtts_alpha_sigma(float t, float* alpha, float* sigma) { alpha_sigma_host(t, *alpha, *sigma); }
 
 int smtts_resample_poly(smtts_handle h, void* stream, const float* x, int channels, int64_t n_in, const float* bank, int up,
-                        int down, int klen, int width, float* y, int64_t n_out) {
+                        int down, int klen, int width, float* y, int64_t n_out) { NULLCHK;
     if (up <= 0 || down <= 0 || klen <= 0 || channels <= 0) return E.fail("resample_poly: bad arguments");
     hipError_t e = launch_resample_poly(x, n_in, bank, up, down, klen, width, y, n_out, channels, ST(stream));
     return e == hipSuccess ? 0 : E.fail_hip(e, "resample_poly");
 }
-int smtts_pcm16(smtts_handle h, void* stream, const float* x, int64_t n, int16_t* y) {
+int smtts_pcm16(smtts_handle h, void* stream, const float* x, int64_t n, int16_t* y) { NULLCHK;
     hipError_t e = launch_pcm16(x, y, n, ST(stream));
     return e == hipSuccess ? 0 : E.fail_hip(e, "pcm16");
 }
-int smtts_set_dual_stream(smtts_handle h, int on) { E.set_dual_stream(on != 0); return 0; }
-int smtts_profile_enable(smtts_handle h, int on) { E.profile_enable(on); return 0; }
-int smtts_profile_report(smtts_handle h, char* buf, size_t cap) {
+int smtts_set_dual_stream(smtts_handle h, int on) { NULLCHK; E.set_dual_stream(on != 0); return 0; }
+int smtts_profile_enable(smtts_handle h, int on) { NULLCHK; E.profile_enable(on); return 0; }
+int smtts_profile_report(smtts_handle h, char* buf, size_t cap) { NULLCHK;
     std::string r = E.profile_report();
     if (r.size() + 1 > cap) return E.fail("profile_report: buffer too small");
     memcpy(buf, r.c_str(), r.size() + 1);
     return 0;
 }
 
-int smtts_bench_gemm(smtts_handle h, int M, int N, int K, int epi, int split, int cfg, int iters, int ver, float* avg_us) {
+int smtts_bench_gemm(smtts_handle h, int M, int N, int K, int epi, int split, int cfg, int iters, int ver, float* avg_us) { NULLCHK;
     return E.bench_gemm(M, N, K, epi, split, cfg, iters, ver, avg_us);
 }
 int smtts_test_gemm3(smtts_handle h, void* stream, const float* A, const float* W, const float* bias, int M, int N, int K,
-                     int act, int split, int cfg, float* C) {
+                     int act, int split, int cfg, float* C) { NULLCHK;
     return E.test_gemm3(ST(stream), A, W, bias, M, N, K, act, split, cfg, C);
 }
-int smtts_test_set_fused_ffn(smtts_handle h, int on) { E.set_fused_ffn(on != 0); return 0; }
-int smtts_test_set_attention_mfma(smtts_handle h, int on) { E.set_attn_mfma(on != 0); return 0; }
+int smtts_test_set_fused_ffn(smtts_handle h, int on) { NULLCHK; E.set_fused_ffn(on != 0); return 0; }
+int smtts_test_set_attention_mfma(smtts_handle h, int on) { NULLCHK; E.set_attn_mfma(on != 0); return 0; }
 
 // ---- test hooks -------------------------------------------------------------------------------
 int smtts_test_gemm(smtts_handle h, void* stream, const float* A, int lda, const float* W, const float* bias, int M,
-                    int N, int K, int act, int split, int cfg, float* C, int ldc) {
+                    int N, int K, int act, int split, int cfg, float* C, int ldc) { NULLCHK;
     return E.test_gemm(ST(stream), A, lda, W, bias, M, N, K, act, split, cfg, C, ldc);
 }
 int smtts_test_swiglu(smtts_handle h, void* stream, const float* A, const float* W1, const float* W3, const float* b1,
-                      const float* b3, int M, int F, int K, int split, float* out) {
+                      const float* b3, int M, int F, int K, int split, float* out) { NULLCHK;
     return E.test_swiglu(ST(stream), A, W1, W3, b1, b3, M, F, K, split, out);
 }
 int smtts_test_attention(smtts_handle h, void* stream, const float* qkvg, const float* qw, const float* kw, float eps,
                          const float* rope, int rot_dim, const float* k_ref, const float* v_ref, int R,
                          const float* k_text, const float* v_text, int P, const uint8_t* mask_self,
-                         const uint8_t* mask_ref, const uint8_t* mask_text, int B, int N, int H, int dh, float* out) {
+                         const uint8_t* mask_ref, const uint8_t* mask_text, int B, int N, int H, int dh, float* out) { NULLCHK;
     AttnArgs a{};
     const int D = H * dh;
     a.q = qkvg; a.k = qkvg + D; a.v = qkvg + 2 * D; a.gate = qkvg + 3 * D;
@@ -186,7 +190,7 @@ int smtts_test_attention(smtts_handle h, void* stream, const float* qkvg, const 
 int smtts_test_attention_mfma(smtts_handle h, void* stream, const float* qkvg, const float* qw, const float* kw, float eps,
                               const float* rope, int rot_dim, const float* k_ref, const float* v_ref, int R,
                               const float* k_text, const float* v_text, int P, const uint8_t* mask_self,
-                              const uint8_t* mask_ref, const uint8_t* mask_text, int B, int N, int H, int dh, float* out) {
+                              const uint8_t* mask_ref, const uint8_t* mask_text, int B, int N, int H, int dh, float* out) { NULLCHK;
     AttnArgs a{};
     const int D = H * dh;
     float *tmp = nullptr, *rc = nullptr, *rs = nullptr;

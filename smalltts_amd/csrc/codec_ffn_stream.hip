@@ -184,7 +184,10 @@ __global__ __launch_bounds__(NW * 64) void codec_ffn_stream_kernel(FfnStreamArgs
                                     xa[kk][1].x * rstd * g1.x, xa[kk][1].y * rstd * g1.y, xa[kk][1].z * rstd * g1.z, xa[kk][1].w * rstd * g1.w};
                 unsigned nhp[4], nlp[4];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) split_pair(v[2 * e], v[2 * e + 1], nhp[e], nlp[e]);
+                for (int e = 0; e < 4; ++e) {
+                    if (SPLIT == PREC_F16) { nhp[e] = cvt_pk_f16_sat(v[2 * e], v[2 * e + 1]); nlp[e] = 0; }
+                    else split_pair(v[2 * e], v[2 * e + 1], nhp[e], nlp[e]);
+                }
                 nh[kk] = __builtin_bit_cast(bf16x8, *reinterpret_cast<uint4*>(nhp));
                 nl[kk] = __builtin_bit_cast(bf16x8, *reinterpret_cast<uint4*>(nlp));
             }
@@ -261,7 +264,7 @@ __global__ __launch_bounds__(NW * 64) void codec_ffn_stream_kernel(FfnStreamArgs
                 } else if (k < 40) {          // S3: bf16 split of the four value pairs: hi | residual
                     const int j = (k - 32) >> 1;
                     const float rx = tt[2 * j], ry = tt[2 * j + 1];
-                    if (!(k & 1)) hiP[j] = cvt_pk_bf16s(rx, ry);
+                    if (!(k & 1)) hiP[j] = SPLIT == PREC_F16 ? cvt_pk_f16_satpos(rx, ry) : cvt_pk_bf16s(rx, ry);
                     else if (SPLIT == 3) loP[j] = cvt_pk_bf16s(rx - __uint_as_float(hiP[j] << 16), ry - __uint_as_float(hiP[j] & 0xffff0000u));
                 } else {                      // lane swap of this k16 step: hi | lo
                     // lane half 0 needs hidden 0..7 of the k16 step, half 1 hidden 8..15: swap upper half of X with lower half of Y
@@ -297,14 +300,14 @@ __global__ __launch_bounds__(NW * 64) void codec_ffn_stream_kernel(FfnStreamArgs
                     __builtin_amdgcn_sched_barrier(0);
                     if (g < NG1) {
                         // pass order: the two cross terms first, hi . hi last
-                        if (SPLIT == 3 && ps == 0) hw = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[g % NB][1], nh[g < NG1 ? g : 0], hw, 0, 0, 0);
-                        else if (SPLIT == 3 && ps == 1) hw = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[g % NB][0], nl[g < NG1 ? g : 0], hw, 0, 0, 0);
-                        else hw = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[g % NB][0], nh[g < NG1 ? g : 0], hw, 0, 0, 0);
+                        if (SPLIT == 3 && ps == 0) hw = mfma16<SPLIT>(wf[g % NB][1], nh[g < NG1 ? g : 0], hw);
+                        else if (SPLIT == 3 && ps == 1) hw = mfma16<SPLIT>(wf[g % NB][0], nl[g < NG1 ? g : 0], hw);
+                        else hw = mfma16<SPLIT>(wf[g % NB][0], nh[g < NG1 ? g : 0], hw);
                     } else {
                         const int g2 = g - NG1, s2 = g2 / NOT, ot = g2 % NOT;
-                        if (SPLIT == 3 && ps == 0) acc2[ot] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[g % NB][1], fr_.h[s2], acc2[ot], 0, 0, 0);
-                        else if (SPLIT == 3 && ps == 1) acc2[ot] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[g % NB][0], fr_.l[s2], acc2[ot], 0, 0, 0);
-                        else acc2[ot] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[g % NB][0], fr_.h[s2], acc2[ot], 0, 0, 0);
+                        if (SPLIT == 3 && ps == 0) acc2[ot] = mfma16<SPLIT>(wf[g % NB][1], fr_.h[s2], acc2[ot]);
+                        else if (SPLIT == 3 && ps == 1) acc2[ot] = mfma16<SPLIT>(wf[g % NB][0], fr_.l[s2], acc2[ot]);
+                        else acc2[ot] = mfma16<SPLIT>(wf[g % NB][0], fr_.h[s2], acc2[ot]);
                     }
                     if (G)
 #pragma unroll
@@ -359,16 +362,12 @@ static hipError_t ffn_stream_go(const FfnStreamArgs& a, hipStream_t st) {
     constexpr size_t lds = (size_t)S * NARR * 128 * C + (size_t)7 * C * 4;
     static_assert(lds <= 160 * 1024, "ring exceeds LDS");
     auto kern = codec_ffn_stream_kernel<C, SPLIT, NW, S>;
-    static bool done = false;
-    static int cus = 256;
-    if (!done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        int dev = 0, n = 0;
-        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0)
-            cus = n;
-        done = true;
-    }
+    static DevOnce once;
+    int cus = 256;
+    hipError_t e = once.ensure([&] {
+        return hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    }, &cus);
+    if (e != hipSuccess) return e;
     const int npass = (a.M + NW * 32 - 1) / (NW * 32);
     const int grid = npass < cus ? npass : cus;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), lds, st, a);
@@ -383,8 +382,8 @@ hipError_t launch_codec_ffn_stream(float* x, RowMap img, const float* norm_w, co
     if (M <= 0) return hipSuccess;
     FfnStreamArgs a{x, img, norm_w, w1hi, w1lo, b1, w2thi, w2tlo, b2, gamma, M, eps};
     ProfScope ps(st, C == 128 ? "codec_ffn_stream<128>" : "codec_ffn_stream<256>", 4.0 * M * (double)C * F, 8.0 * M * C + 8.0 * (double)C * F);
-    if (C == 128) return split == 3 ? ffn_stream_go<128, 3, 8, 4>(a, st) : ffn_stream_go<128, 1, 8, 4>(a, st);
-    return split == 3 ? ffn_stream_go<256, 3, 4, 2>(a, st) : ffn_stream_go<256, 1, 4, 4>(a, st);
+    if (C == 128) return split == 3 ? ffn_stream_go<128, 3, 8, 4>(a, st) : split == PREC_F16 ? ffn_stream_go<128, 2, 8, 4>(a, st) : ffn_stream_go<128, 1, 8, 4>(a, st);
+    return split == 3 ? ffn_stream_go<256, 3, 4, 2>(a, st) : split == PREC_F16 ? ffn_stream_go<256, 2, 4, 4>(a, st) : ffn_stream_go<256, 1, 4, 4>(a, st);
 }
 
 // out[(t * C + c) * 32 + k] = in[c * F + 32 t + k]   (W2 [C][F] -> hidden-tile-major)

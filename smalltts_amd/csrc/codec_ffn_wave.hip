@@ -139,7 +139,10 @@ __global__ __launch_bounds__(512) void codec_ffn_wave_kernel(FfnWaveArgs a) {
                                 xa[kk][1].x * rstd * g1.x, xa[kk][1].y * rstd * g1.y, xa[kk][1].z * rstd * g1.z, xa[kk][1].w * rstd * g1.w};
             unsigned nhp[4], nlp[4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) split_pair(v[2 * e], v[2 * e + 1], nhp[e], nlp[e]);
+            for (int e = 0; e < 4; ++e) {
+                if (SPLIT == PREC_F16) { nhp[e] = cvt_pk_f16_sat(v[2 * e], v[2 * e + 1]); nlp[e] = 0; }
+                else split_pair(v[2 * e], v[2 * e + 1], nhp[e], nlp[e]);
+            }
             nh[kk] = __builtin_bit_cast(bf16x8, *reinterpret_cast<uint4*>(nhp));
             nl[kk] = __builtin_bit_cast(bf16x8, *reinterpret_cast<uint4*>(nlp));
         }
@@ -162,9 +165,9 @@ __global__ __launch_bounds__(512) void codec_ffn_wave_kernel(FfnWaveArgs a) {
         struct Frags { bf16x8 h[2], l[2]; };   // B fragments (two k16 steps) of one GELU'd hidden tile
         auto mfma3 = [&](floatx16& acc, const bf16x8 (&w)[2], const bf16x8& bh, const bf16x8& bl, int pass) {
             // pass order: the two cross terms first, hi . hi last (as before)
-            if (SPLIT == 3 && pass == 0) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[1], bh, acc, 0, 0, 0);
-            else if (SPLIT == 3 && pass == 1) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[0], bl, acc, 0, 0, 0);
-            else acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[0], bh, acc, 0, 0, 0);
+            if (SPLIT == 3 && pass == 0) acc = mfma16<SPLIT>(w[1], bh, acc);
+            else if (SPLIT == 3 && pass == 1) acc = mfma16<SPLIT>(w[0], bl, acc);
+            else acc = mfma16<SPLIT>(w[0], bh, acc);
         };
         // accumulator row r of hidden tile t is hidden unit 32 t + (r & 3) + 8 (r >> 2) + 4 fh
         auto bias_init = [&](floatx16& acc, int t) {
@@ -246,7 +249,7 @@ __global__ __launch_bounds__(512) void codec_ffn_wave_kernel(FfnWaveArgs a) {
             auto finish = [&](int pr) {
                 const float rx = fmaf(fabsf(hx[pr].x), uu[pr].x, hx[pr].x);
                 const float ry = fmaf(fabsf(hx[pr].y), uu[pr].y, hx[pr].y);
-                hiP[pr] = cvt_pk_bf16(rx, ry);
+                hiP[pr] = SPLIT == PREC_F16 ? cvt_pk_f16_satpos(rx, ry) : cvt_pk_bf16(rx, ry);
                 if (SPLIT == 3) {
                     f32x2 rr, hf;
                     rr.x = rx; rr.y = ry;
@@ -380,16 +383,12 @@ static hipError_t ffn_wave_go(const FfnWaveArgs& a, hipStream_t st) {
     constexpr size_t lds = (size_t)(SPLIT == 3 ? 2 : 1) * 2 * (8 * C * C) + (size_t)(4 * C + 3 * C) * 4;
     static_assert(lds <= 160 * 1024, "weights must fit LDS");
     auto kern = codec_ffn_wave_kernel<C, SPLIT>;
-    static bool done = false;
-    static int cus = 256;
-    if (!done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        int dev = 0, n = 0;
-        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0)
-            cus = n;
-        done = true;
-    }
+    static DevOnce once;
+    int cus = 256;
+    hipError_t e = once.ensure([&] {
+        return hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    }, &cus);
+    if (e != hipSuccess) return e;
     const int ntiles = (a.M + 31) / 32;
     const int per_cu = lds * 2 <= 160 * 1024 ? 2 : 1;  // persistent: as many workgroups as fit, each wave walks tiles
     int grid = (ntiles + 7) / 8;
@@ -406,6 +405,6 @@ hipError_t launch_codec_ffn_wave(float* x, RowMap img, const float* norm_w, cons
     if (M <= 0) return hipSuccess;
     FfnWaveArgs a{x, img, norm_w, w1hi, w1lo, ld1, b1, w2hi, w2lo, b2, gamma, M, eps};
     ProfScope ps(st, C == 64 ? "codec_ffn_wave<64>" : "codec_ffn_wave<32>", 4.0 * M * (double)C * F, 8.0 * M * C + 8.0 * (double)C * F);
-    if (C == 64) return split == 3 ? ffn_wave_go<64, 3>(a, st) : ffn_wave_go<64, 1>(a, st);
-    return split == 3 ? ffn_wave_go<32, 3>(a, st) : ffn_wave_go<32, 1>(a, st);
+    if (C == 64) return split == 3 ? ffn_wave_go<64, 3>(a, st) : split == PREC_F16 ? ffn_wave_go<64, 2>(a, st) : ffn_wave_go<64, 1>(a, st);
+    return split == 3 ? ffn_wave_go<32, 3>(a, st) : split == PREC_F16 ? ffn_wave_go<32, 2>(a, st) : ffn_wave_go<32, 1>(a, st);
 }

@@ -144,16 +144,12 @@ hipError_t upsample_go(const UpsampleArgs& a, hipStream_t st) {
     constexpr size_t lds = (size_t)(SPLIT == 3 ? 2 : 1) * N * 2 * K + (size_t)N * 4;
     static_assert(lds <= 160 * 1024, "weights must fit LDS");
     auto kern = codec_upsample_wave_kernel<K, N, SPLIT>;
-    static bool done = false;
-    static int cus = 256;
-    if (!done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        int dev = 0, n = 0;
-        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0)
-            cus = n;
-        done = true;
-    }
+    static DevOnce once;
+    int cus = 256;
+    hipError_t e = once.ensure([&] {
+        return hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    }, &cus);
+    if (e != hipSuccess) return e;
     const int ntiles = (a.M + 31) / 32;
     const int per_cu = lds * 2 <= 160 * 1024 ? 2 : 1;
     int grid = (ntiles + 7) / 8;

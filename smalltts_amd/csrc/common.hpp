@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <atomic>
 
 typedef __bf16 bf16_t;
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -10,6 +11,30 @@ typedef float floatx16 __attribute__((ext_vector_type(16)));
 typedef float floatx4 __attribute__((ext_vector_type(4)));
 
 #define SMTTS_WAVE 64
+
+// One-time launch setup PER DEVICE: hipFuncSetAttribute(MaxDynamicSharedMemorySize) and the CU count belong to a device, and a
+// process may hold engines on several (smtts_create(device_id)).  Thread-safe: the bit is published after the setup
+// succeeded; two threads racing on a new device at worst both run the idempotent setup.
+struct DevOnce {
+    std::atomic<unsigned> mask{0};
+    int cus[16] = {};
+    template <class F>
+    hipError_t ensure(F&& setup, int* cu_out = nullptr) {
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        dev &= 15;
+        if (!((mask.load(std::memory_order_acquire) >> dev) & 1u)) {
+            hipError_t e = setup();
+            if (e != hipSuccess) return e;
+            int n = 0;
+            if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+            cus[dev] = n;
+            mask.fetch_or(1u << dev, std::memory_order_release);
+        }
+        if (cu_out) *cu_out = cus[dev];
+        return hipSuccess;
+    }
+};
 
 // Row addressing shared by GEMM operands/outputs: logical row m -> element offset.
 // rpb == 0: off + m*ld.  rpb > 0 (batched rows with per-batch padding):
@@ -75,18 +100,85 @@ __device__ __forceinline__ float apply_act(float x) {
     return x;
 }
 
+// ---- GEMM operand precisions ------------------------------------------------------------------------------------------
+// Every GEMM site runs in one of three operand formats (fp32 accumulation always); the engine picks one per site:
+//   PREC_BF16X3  x = hi + lo, both bf16; acc += A_lo W_hi + A_hi W_lo + A_hi W_hi   (3 MFMAs, ~2^-17 operand error)
+//   PREC_F16     one fp16 array per operand (11 significant bits, saturating convert), 1 MFMA
+//   PREC_BF16    one bf16 array per operand, 1 MFMA
+// Activation buffers are written by their producer in the format of the CONSUMING GEMM.  The format travels with the
+// (hi, lo) pointer pair every producer already takes: lo == null -> bf16 single, lo == SM_F16_TAG -> fp16 single (16-bit
+// storage is shared: an fp16 array is addressed through the same bf16_t* type), anything else -> split pair.
+enum { PREC_BF16 = 1, PREC_F16 = 2, PREC_BF16X3 = 3 };
+typedef _Float16 half_t;
+typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
+typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
+typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+#define SM_F16_TAG (reinterpret_cast<bf16_t*>((uintptr_t)2))
+__host__ __device__ __forceinline__ bool sm_is_f16(const bf16_t* lo) { return lo == SM_F16_TAG; }
+__host__ __device__ __forceinline__ bool sm_is_split(const bf16_t* lo) { return lo != nullptr && lo != SM_F16_TAG; }
+// lo pointer that tells a producer which format to write for a consumer of precision `prec`
+static inline bf16_t* sm_lo_for(int prec, bf16_t* lo) { return prec == PREC_BF16X3 ? lo : prec == PREC_F16 ? SM_F16_TAG : nullptr; }
+
+// (a, b) -> packed fp16 pair, round to nearest even, saturating at +-65504 (v_cvt_pk_f16_f32 + v_pk_min/max_f16)
+__device__ __forceinline__ unsigned cvt_pk_f16_sat(float a, float b) {
+    f32x2_t v;
+    v.x = a; v.y = b;
+    half2_t h = __builtin_convertvector(v, half2_t);
+    const half2_t mx = {(half_t)65504.f, (half_t)65504.f};
+    h = __builtin_elementwise_max(__builtin_elementwise_min(h, mx), -mx);
+    return __builtin_bit_cast(unsigned, h);
+}
+// same for values bounded below (GELU / SiLU-gated outputs): only +inf can occur, one v_pk_min_f16
+__device__ __forceinline__ unsigned cvt_pk_f16_satpos(float a, float b) {
+    f32x2_t v;
+    v.x = a; v.y = b;
+    half2_t h = __builtin_convertvector(v, half2_t);
+    const half2_t mx = {(half_t)65504.f, (half_t)65504.f};
+    return __builtin_bit_cast(unsigned, __builtin_elementwise_min(h, mx));
+}
+__device__ __forceinline__ unsigned short cvt_f16_sat(float a) {
+    return (unsigned short)(cvt_pk_f16_sat(a, 0.f) & 0xffffu);
+}
+
 // fp32 -> (bf16 hi, bf16 lo) with x ~= hi + lo
 __device__ __forceinline__ void split1(float v, bf16_t& h, bf16_t& l) {
     h = (bf16_t)v;
     l = (bf16_t)(v - (float)h);
 }
+// one activation value / four consecutive ones in the GEMM-operand format selected by `lo` (see above)
+__device__ __forceinline__ void store_act1(bf16_t* hi, bf16_t* lo, long off, float v) {
+    if (sm_is_f16(lo)) {
+        reinterpret_cast<unsigned short*>(hi)[off] = cvt_f16_sat(v);
+        return;
+    }
+    bf16_t h, l;
+    split1(v, h, l);
+    hi[off] = h;
+    if (lo) lo[off] = l;
+}
 __device__ __forceinline__ void store_split4(bf16_t* hi, bf16_t* lo, long off, const float4& v) {
+    if (sm_is_f16(lo)) {
+        uint2 p;
+        p.x = cvt_pk_f16_sat(v.x, v.y);
+        p.y = cvt_pk_f16_sat(v.z, v.w);
+        *reinterpret_cast<uint2*>(hi + off) = p;
+        return;
+    }
     bf16x4 h, l;
     h[0] = (bf16_t)v.x; h[1] = (bf16_t)v.y; h[2] = (bf16_t)v.z; h[3] = (bf16_t)v.w;
     l[0] = (bf16_t)(v.x - (float)h[0]); l[1] = (bf16_t)(v.y - (float)h[1]);
     l[2] = (bf16_t)(v.z - (float)h[2]); l[3] = (bf16_t)(v.w - (float)h[3]);
     *reinterpret_cast<bf16x4*>(hi + off) = h;
     if (lo) *reinterpret_cast<bf16x4*>(lo + off) = l;
+}
+// one 32x32x16 MFMA on 16-bit fragments held as bf16x8 registers: fp16 when SPLIT == PREC_F16, bf16 otherwise
+template <int SPLIT>
+__device__ __forceinline__ floatx16 mfma16(const bf16x8& a, const bf16x8& b, const floatx16& c) {
+    if constexpr (SPLIT == PREC_F16)
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8_t, a), __builtin_bit_cast(half8_t, b), c, 0, 0, 0);
+    else
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
 }
 
 // LDS pointer for direct-to-LDS DMA operands and a counted wait on this wave's outstanding vector-memory operations

@@ -74,6 +74,7 @@ Engine::~Engine() {
     if (ev_fork_) (void)hipEventDestroy(ev_fork_);
     if (ev_join_) (void)hipEventDestroy(ev_join_);
     for (void* p : allocs_) (void)hipFree(p);
+    for (void* p : pack_allocs_) (void)hipFree(p);
 }
 
 int Engine::fail_hip(hipError_t e, const char* what) {
@@ -84,8 +85,22 @@ int Engine::fail_hip(hipError_t e, const char* what) {
 void* Engine::dalloc(size_t bytes) {
     void* p = nullptr;
     if (hipMalloc(&p, bytes ? bytes : 16) != hipSuccess) return nullptr;
-    allocs_.push_back(p);
+    (packing_ ? pack_allocs_ : allocs_).push_back(p);
     return p;
+}
+
+void Engine::free_packs() {
+    for (void* p : pack_allocs_) (void)hipFree(p);
+    pack_allocs_.clear();
+}
+
+int Engine::check_shape(const std::string& name, std::initializer_list<long> want) {
+    const RawTensor* t = raw(name);
+    if (!t) return fail("missing tensor " + name);
+    if (t->shape.size() == want.size() && std::equal(want.begin(), want.end(), t->shape.begin())) return 0;
+    auto str = [](auto b, auto e) { std::string o = "("; for (auto i = b; i != e; ++i) o += (i == b ? "" : ", ") + std::to_string(*i); return o + ")"; };
+    return fail("tensor " + name + " has shape " + str(t->shape.begin(), t->shape.end()) + ", this build expects " +
+                str(want.begin(), want.end()));
 }
 
 const RawTensor* Engine::raw(const std::string& n) const {
@@ -114,7 +129,7 @@ int Engine::set_tensor(const char* name, const float* data, const long* shape, i
     }
     HIPC(hipMemcpy(t.d, data, t.numel * sizeof(float), src_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice));
     raw_[name] = t;
-    finalized_ = false;
+    invalidate();
     return 0;
 }
 
@@ -127,7 +142,7 @@ int Engine::synth_tensor(const char* name, const long* shape, int ndim, uint64_t
     if (!t.d) return fail("out of device memory for tensor " + std::string(name));
     HIPC(launch_synth(t.d, t.numel, key, mean, half_range, 0));
     raw_[name] = t;
-    finalized_ = false;
+    invalidate();
     return 0;
 }
 
@@ -143,7 +158,7 @@ int Engine::get_tensor(const char* name, float* host_out, long numel) {
 int Engine::set_codec_spec(const CodecSpecC& s) {
     if (s.n_ratios < 1 || s.n_ratios > 7) return fail("codec spec: 1..7 ratios supported");
     cspec_ = s;
-    finalized_ = false;
+    invalidate();
     return 0;
 }
 
@@ -158,12 +173,14 @@ PW Engine::pack_from_f32(const float* src, int N, int K, int k_pad, int n_pad) {
     w.K = Kp;
     w.hi = static_cast<bf16_t*>(dalloc((size_t)Np * Kp * 2));
     w.lo = static_cast<bf16_t*>(dalloc((size_t)Np * Kp * 2));
-    if (!w.hi || !w.lo) { w.N = 0; return w; }
+    w.h16 = static_cast<bf16_t*>(dalloc((size_t)Np * Kp * 2));
+    if (!w.hi || !w.lo || !w.h16) { w.N = 0; return w; }
     if (Kp != K || Np != N) {
         (void)hipMemsetAsync(w.hi, 0, (size_t)Np * Kp * 2, 0);
         (void)hipMemsetAsync(w.lo, 0, (size_t)Np * Kp * 2, 0);
+        (void)hipMemsetAsync(w.h16, 0, (size_t)Np * Kp * 2, 0);
     }
-    if (launch_split_rows(src, K, w.hi, w.lo, Kp, N, K, nullptr, 0) != hipSuccess) w.N = 0;
+    if (launch_split_rows(src, K, w.hi, w.lo, Kp, N, K, nullptr, 0, w.h16) != hipSuccess) w.N = 0;
     return w;
 }
 
@@ -195,7 +212,8 @@ PW Engine::pack_rows(const std::vector<std::string>& names, const std::vector<in
     w.K = K;
     w.hi = static_cast<bf16_t*>(dalloc((size_t)Ntot * K * 2));
     w.lo = static_cast<bf16_t*>(dalloc((size_t)Ntot * K * 2));
-    if (!w.hi || !w.lo || launch_split_rows(tmp, K, w.hi, w.lo, K, Ntot, K, dperm, 0) != hipSuccess) w.N = 0;
+    w.h16 = static_cast<bf16_t*>(dalloc((size_t)Ntot * K * 2));
+    if (!w.hi || !w.lo || !w.h16 || launch_split_rows(tmp, K, w.hi, w.lo, K, Ntot, K, dperm, 0, w.h16) != hipSuccess) w.N = 0;
     (void)hipStreamSynchronize(0);
     (void)hipFree(tmp);
     if (dperm) (void)hipFree(dperm);
@@ -242,6 +260,13 @@ int Engine::build_encoder(EncoderW& e, const std::string& prefix, int dim, int h
     e.blocks.clear();
     for (int i = 0; i < layers; ++i) {
         std::string p = sidx(prefix + ".blocks.", i, "");
+        for (const char* n : {"wq", "wk", "wv", "wo", "gate"})
+            if (check_shape(p + ".attention." + n + ".weight", {dim, dim})) return 1;
+        if (check_shape(p + ".attention.q_norm.weight", {heads, dim / heads}) || check_shape(p + ".attention.k_norm.weight", {heads, dim / heads}) ||
+            check_shape(p + ".mlp.w1.weight", {ff, dim}) || check_shape(p + ".mlp.w3.weight", {ff, dim}) ||
+            check_shape(p + ".mlp.w2.weight", {dim, ff}) || check_shape(p + ".attention_norm.weight", {dim}) ||
+            check_shape(p + ".mlp_norm.weight", {dim}))
+            return 1;
         EncBlockW b;
         b.qkvg = pack_rows({p + ".attention.wq.weight", p + ".attention.wk.weight", p + ".attention.wv.weight",
                             p + ".attention.gate.weight"});
@@ -277,6 +302,40 @@ int Engine::make_rope(int dim, float** cos_out, float** sin_out) {
 
 int Engine::finalize_dit() {
     const std::string T = "dit.transformer_blocks.";
+    // shape contract of DiTModel(64).state_dict() (reference model.py:33-54): the kernels assume these strides, so a checkpoint
+    // of another model size must fail here with the tensor's name instead of reading out of bounds later
+    {
+        const long H = kHidden, FF = kFF;
+        struct { const char* n; std::initializer_list<long> sh; } g[] = {
+            {"time_embedding.mlp.0.weight", {H, 256}}, {"time_embedding.mlp.0.bias", {H}},
+            {"time_embedding.mlp.2.weight", {H, H}}, {"time_embedding.mlp.2.bias", {H}},
+            {"dit.emb_proj.0.weight", {2 * H, H}}, {"dit.emb_proj.0.bias", {2 * H}},
+            {"dit.emb_proj.2.weight", {H, 2 * H}}, {"dit.emb_proj.2.bias", {H}},
+            {"dit.input_embed.proj.weight", {H, kLatent}}, {"dit.input_embed.proj.bias", {H}},
+            {"dit.input_embed.conv_pos_embed.conv1.bias", {H}}, {"dit.input_embed.conv_pos_embed.conv2.bias", {H}},
+            {"dit.phoneme_proj.weight", {H, 512}}, {"dit.phoneme_proj.bias", {H}},
+            {"dit.norm_out.linear.weight", {2 * H, H}}, {"dit.norm_out.linear.bias", {2 * H}},
+            {"velocity.weight", {kLatent, H}}, {"velocity.bias", {kLatent}},
+            {"style_encoder.in_proj.weight", {512, kLatent}}, {"style_encoder.in_proj.bias", {512}},
+            {"style_encoder.out_proj.weight", {H, 512}}, {"style_encoder.out_proj.bias", {H}},
+            {"style_encoder.log_scale", {}}, {"phoneme_embedding.text_embedding.weight", {198, 512}},
+        };
+        for (auto& t : g)
+            if (check_shape(t.n, t.sh)) return 1;
+        for (int i = 0; i < kBlocks; ++i) {
+            const std::string p = sidx(T, i, "");
+            for (const char* n : {"to_q", "to_k_self", "to_v_self", "to_k_ref", "to_v_ref", "to_k_text", "to_v_text"})
+                if (check_shape(p + ".attn." + n + ".weight", {H, H}) || check_shape(p + ".attn." + n + ".bias", {H})) return 1;
+            if (check_shape(p + ".attn.gate.weight", {H, H}) || check_shape(p + ".attn.to_out.0.weight", {H, H})) return 1;
+            for (const char* n : {"q_norm", "k_norm", "k_norm_cross"})
+                if (check_shape(p + ".attn." + n + ".weight", {kHeads, kDh})) return 1;
+            if (check_shape(p + ".attn_norm.linear.weight", {6 * H, H}) || check_shape(p + ".attn_norm.linear.bias", {6 * H})) return 1;
+            if (check_shape(p + ".ff.w1.weight", {FF, H}) || check_shape(p + ".ff.w1.bias", {FF}) ||
+                check_shape(p + ".ff.w3.weight", {FF, H}) || check_shape(p + ".ff.w3.bias", {FF}) ||
+                check_shape(p + ".ff.w2.weight", {H, FF}) || check_shape(p + ".ff.w2.bias", {H}))
+                return 1;
+        }
+    }
     time0_ = pack_rows({"time_embedding.mlp.0.weight"});
     time2_ = pack_rows({"time_embedding.mlp.2.weight"});
     emb0_ = pack_rows({"dit.emb_proj.0.weight"});
@@ -427,6 +486,14 @@ int Engine::finalize_codec(bool decoder) {
             b.ffn_norm_w = rawp(p + ".ffn_norm.weight"); b.b1 = rawp(p + ".ffn.w1.bias");
             b.b2 = rawp(p + ".ffn.w2.bias"); b.ffn_gamma = rawp(p + ".ffn_gamma");
             const float* mw = rawp(p + ".mixer.weight");
+            {
+                const long Fh = (long)s.ffn_mult * C;
+                if (check_shape(p + ".norm.weight", {C}) || check_shape(p + ".mixer.weight", {C, Kc}) || check_shape(p + ".mixer.bias", {C}) ||
+                    check_shape(p + ".gamma", {C}) || check_shape(p + ".ffn_norm.weight", {C}) || check_shape(p + ".ffn.w1.weight", {Fh, C}) ||
+                    check_shape(p + ".ffn.w1.bias", {Fh}) || check_shape(p + ".ffn.w2.weight", {C, Fh}) || check_shape(p + ".ffn.w2.bias", {C}) ||
+                    check_shape(p + ".ffn_gamma", {C}))
+                    return 1;
+            }
             if (!b.norm_w || !b.dw_b || !b.gamma || !b.ffn_norm_w || !b.b1 || !b.b2 || !b.ffn_gamma || !mw)
                 return fail("codec block incomplete: " + p);
             GatherSpec g{0, 0, 1, 0, Kc, Kc, C, C};
@@ -439,9 +506,11 @@ int Engine::finalize_codec(bool decoder) {
             if ((C == 128 || C == 256) && F == 4 * C && b.w1.K == C && b.w2.K == F) {  // streamed fused FFN: W2 hidden-tile-major
                 b.w2t.hi = static_cast<bf16_t*>(dalloc((size_t)C * F * 2));
                 b.w2t.lo = static_cast<bf16_t*>(dalloc((size_t)C * F * 2));
-                if (!b.w2t.hi || !b.w2t.lo) return fail("codec w2 tile pack: out of memory");
+                b.w2t.h16 = static_cast<bf16_t*>(dalloc((size_t)C * F * 2));
+                if (!b.w2t.hi || !b.w2t.lo || !b.w2t.h16) return fail("codec w2 tile pack: out of memory");
                 HIPC(launch_w2_tile_pack(b.w2.hi, b.w2t.hi, C, F, 0));
                 HIPC(launch_w2_tile_pack(b.w2.lo, b.w2t.lo, C, F, 0));
+                HIPC(launch_w2_tile_pack(b.w2.h16, b.w2t.h16, C, F, 0));
                 b.w2t.N = (F / 32) * C;
                 b.w2t.K = 32;
             }
@@ -478,6 +547,10 @@ int Engine::finalize_codec(bool decoder) {
 
 int Engine::finalize() {
     HIPC(hipSetDevice(device_));
+    HIPC(hipDeviceSynchronize());  // nothing in flight may still read the packs of an earlier finalize()
+    invalidate();
+    free_packs();
+    struct PackMode { bool& f; explicit PackMode(bool& b) : f(b) { f = true; } ~PackMode() { f = false; } } pm(packing_);
     if (raw("velocity.weight")) {
         if (finalize_dit()) return 1;
     }
@@ -510,17 +583,19 @@ static inline GemmOperands ops(const float* A, RowMap amap, const PW& w, int M, 
     g.w_zmod = 0;
     return g;
 }
-struct SplitBuf {  // activation stored as a split bf16 pair (x ~= hi + lo), the A operand of gemm3
-    bf16_t* hi;
+struct SplitBuf {  // activation buffer feeding gemm3 as its A operand: a split bf16 pair (x ~= hi + lo), or — for a consumer
+    bf16_t* hi;     // of precision PREC_F16 / PREC_BF16 — one 16-bit array in `hi` (`lo` allocated but unused)
     bf16_t* lo;
+    // the (hi, lo) pair a PRODUCER is handed so that it writes the format a consumer of precision `prec` reads (common.hpp)
+    SplitBuf as(int prec) const { return SplitBuf{hi, sm_lo_for(prec, lo)}; }
 };
-static inline Gemm3Operands ops3(SplitBuf a, RowMap amap, const PW& w, int M, int row0 = 0, int nrows = -1) {
+static inline Gemm3Operands ops3(SplitBuf a, RowMap amap, const PW& w, int M, int prec, int row0 = 0, int nrows = -1) {
     Gemm3Operands g;
     g.Ahi = a.hi;
-    g.Alo = a.lo;
+    g.Alo = prec == PREC_BF16X3 ? a.lo : nullptr;
     g.amap = amap;
-    g.Whi = w.hi + (long)row0 * w.K;
-    g.Wlo = w.lo + (long)row0 * w.K;
+    g.Whi = (prec == PREC_F16 ? w.h16 : w.hi) + (long)row0 * w.K;
+    g.Wlo = prec == PREC_BF16X3 ? w.lo + (long)row0 * w.K : nullptr;
     g.ldw = w.K;
     g.M = M;
     g.N = nrows < 0 ? w.N : nrows;
@@ -602,37 +677,39 @@ int Engine::run_encoder(hipStream_t st, const EncoderW& e, void* wsv, int B, int
     const int M = B * S, D = e.dim;
     const RowMap rd = rowmap_plain(D);
     if (e.blocks.empty()) return fail("encoder without blocks");
-    HIPC(launch_rmsnorm(w.x, rd, nullptr, w.y.hi, w.y.lo, rd, M, D, e.eps, e.blocks[0].an, st));
+    const int pe = prec_[SITE_ENCODER];
+    const SplitBuf y = w.y.as(pe), o = w.o.as(pe), ffh = w.ffh.as(pe);  // every activation here feeds a SITE_ENCODER GEMM
+    HIPC(launch_rmsnorm(w.x, rd, nullptr, y.hi, y.lo, rd, M, D, e.eps, e.blocks[0].an, st));
     for (size_t l = 0; l < e.blocks.size(); ++l) {
         const EncBlockW& b = e.blocks[l];
-        HIPC(gemm3_store(ops3(w.y, rd, b.qkvg, M), ACT_NONE, store_to(w.qkvg, rowmap_plain(4 * D), nullptr), 1, split_, st));
+        HIPC(gemm3_store(ops3(w.y, rd, b.qkvg, M, pe), ACT_NONE, store_to(w.qkvg, rowmap_plain(4 * D), nullptr), 1, pe, st));
         AttnArgs a{};
         a.q = w.qkvg; a.k = w.qkvg + D; a.v = w.qkvg + 2 * D; a.gate = w.qkvg + 3 * D;
         a.bs = (long)S * 4 * D; a.rs = 4 * D;
         a.qw = b.qn; a.kw = b.kn; a.eps = e.eps;
         a.rope_cos = e.rope_cos; a.rope_sin = e.rope_sin; a.rot_dim = e.dh;
         a.mask_self = key_mask;
-        a.out = nullptr; a.out_hi = w.o.hi; a.out_lo = w.o.lo; a.obs = (long)S * D; a.ors = D;
+        a.out = nullptr; a.out_hi = o.hi; a.out_lo = o.lo; a.obs = (long)S * D; a.ors = D;
         a.B = B; a.N = S; a.H = e.heads; a.dh = e.dh;
         a.prenormed = 1;
         HIPC(launch_qk_prep(a, st));
         HIPC(attn_mfma_ ? launch_attention_mfma(a, st) : launch_attention(a, st));
         EpiResid<0> r1{w.x, rd, nullptr, nullptr, 0, 0, 0, 1, nullptr};
-        NextLN n1{b.mn, nullptr, w.y.hi, w.y.lo, true, e.eps};
+        NextLN n1{b.mn, nullptr, y.hi, y.lo, true, e.eps};
         if (ksplit_enc_ > 1) {
-            HIPC(gemm3_resid_splitk(ops3(w.o, rd, b.wo, M), r1, w.part, ksplit_enc_, split_, st, n1));
+            HIPC(gemm3_resid_splitk(ops3(w.o, rd, b.wo, M, pe), r1, w.part, ksplit_enc_, pe, st, n1));
         } else {
-            HIPC(gemm3_resid(ops3(w.o, rd, b.wo, M), 0, r1, split_, st));
-            HIPC(launch_rmsnorm(w.x, rd, nullptr, w.y.hi, w.y.lo, rd, M, D, e.eps, n1.shift, st));
+            HIPC(gemm3_resid(ops3(w.o, rd, b.wo, M, pe), 0, r1, pe, st));
+            HIPC(launch_rmsnorm(w.x, rd, nullptr, y.hi, y.lo, rd, M, D, e.eps, n1.shift, st));
         }
-        EpiSwiGLU sw{nullptr, e.ff, nullptr, nullptr, w.ffh.hi, w.ffh.lo};
-        HIPC(gemm3_swiglu(ops3(w.y, rd, b.ff13, M), sw, split_, st));
-        NextLN n2{l + 1 < e.blocks.size() ? e.blocks[l + 1].an : e.final_norm, nullptr, w.y.hi, w.y.lo, true, e.eps};
+        EpiSwiGLU sw{nullptr, e.ff, nullptr, nullptr, ffh.hi, ffh.lo};
+        HIPC(gemm3_swiglu(ops3(w.y, rd, b.ff13, M, pe), sw, pe, st));
+        NextLN n2{l + 1 < e.blocks.size() ? e.blocks[l + 1].an : e.final_norm, nullptr, y.hi, y.lo, true, e.eps};
         if (ksplit_enc_ > 1) {
-            HIPC(gemm3_resid_splitk(ops3(w.ffh, rowmap_plain(e.ff), b.w2, M), r1, w.part, ksplit_enc_, split_, st, n2));
+            HIPC(gemm3_resid_splitk(ops3(w.ffh, rowmap_plain(e.ff), b.w2, M, pe), r1, w.part, ksplit_enc_, pe, st, n2));
         } else {
-            HIPC(gemm3_resid(ops3(w.ffh, rowmap_plain(e.ff), b.w2, M), 0, r1, split_, st));
-            HIPC(launch_rmsnorm(w.x, rd, nullptr, w.y.hi, w.y.lo, rd, M, D, e.eps, n2.shift, st));
+            HIPC(gemm3_resid(ops3(w.ffh, rowmap_plain(e.ff), b.w2, M, pe), 0, r1, pe, st));
+            HIPC(launch_rmsnorm(w.x, rd, nullptr, y.hi, y.lo, rd, M, D, e.eps, n2.shift, st));
         }
     }
     return 0;
@@ -673,6 +750,7 @@ int Engine::cond_encode(hipStream_t st, const float* ref, const int64_t* ref_len
     w.plan(bump, B * R > 0 ? B * R : 1);
     wt.plan(bump, B * P > 0 ? B * P : 1);
     const RowMap r512 = rowmap_plain(512), rh = rowmap_plain(kHidden);
+    const int pe = prec_[SITE_ENCODER], pk = prec_[SITE_CROSS_KV], pc = prec_[SITE_COND];
     const bool fork = dual_stream_ && R > 0 && P > 0;
     hipStream_t stt = st;  // stream of the text half
     if (fork) {
@@ -688,11 +766,11 @@ int Engine::cond_encode(hipStream_t st, const float* ref, const int64_t* ref_len
         HIPC(launch_embedding(ids, rawp("phoneme_embedding.text_embedding.weight"), wt.x, M, 512, 198, stt));
         if (run_encoder(stt, text_, &wt, B, P, ph_mask)) return 1;  // leaves RMSNorm(x; final_norm) in wt.y
         float* mem = mem_out ? mem_out : wt.seq;
-        HIPC(gemm3_store(ops3(wt.y, r512, phproj_, M), ACT_NONE,
-                         store_to(mem, rh, rawp("dit.phoneme_proj.bias"), 1.f, ph_mask), 1, split_, stt));
-        HIPC(launch_to_split(mem, rh, wt.seqs.hi, wt.seqs.lo, rh, M, kHidden, stt));
+        HIPC(gemm3_store(ops3(wt.y, r512, phproj_, M, pe), ACT_NONE,
+                         store_to(mem, rh, rawp("dit.phoneme_proj.bias"), 1.f, ph_mask), 1, pe, stt));
+        HIPC(launch_to_split(mem, rh, wt.seqs.hi, wt.seqs.as(pk).lo, rh, M, kHidden, stt));
         EpiKV kv{k_text, v_text, kvtext_b_, B, kHeads, kDh, P};
-        HIPC(gemm3_kv(ops3(wt.seqs, rh, kvtext_, M), kv, split_, stt));
+        HIPC(gemm3_kv(ops3(wt.seqs, rh, kvtext_, M, pk), kv, pk, stt));
         HIPC(launch_headnorm(k_text, kBlocks, B, kHeads, P, kDh, 1e-6f, knc_, stt));
     }
     if (fork) HIPC(hipEventRecord(ev_join_, aux_));
@@ -701,15 +779,15 @@ int Engine::cond_encode(hipStream_t st, const float* ref, const int64_t* ref_len
         const int M = B * R;
         HIPC(launch_len_mask(ref_len, ref_mask, B, R, st));
         HIPC(gemm_store(ops(ref, rowmap_plain(kLatent), style_in_, M), ACT_NONE,
-                        store_to(w.x, r512, rawp("style_encoder.in_proj.bias"), style_scale_), 1, split_, st));
+                        store_to(w.x, r512, rawp("style_encoder.in_proj.bias"), style_scale_), 1, pc, st));
         if (run_encoder(st, style_, &w, B, R, ref_mask)) return 1;  // leaves RMSNorm(x; final_norm) in w.y
         float* seq = ref_seq_out ? ref_seq_out : w.seq;
-        HIPC(gemm3_store(ops3(w.y, r512, style_out_, M), ACT_NONE,
-                         store_to(seq, rh, rawp("style_encoder.out_proj.bias"), 1.f, ref_mask), 1, split_, st));
+        HIPC(gemm3_store(ops3(w.y, r512, style_out_, M, pe), ACT_NONE,
+                         store_to(seq, rh, rawp("style_encoder.out_proj.bias"), 1.f, ref_mask), 1, pe, st));
         // ---- E3 cross KV for the reference tokens (dit.py:80-93) -------------------------------
-        HIPC(launch_to_split(seq, rh, w.seqs.hi, w.seqs.lo, rh, M, kHidden, st));
+        HIPC(launch_to_split(seq, rh, w.seqs.hi, w.seqs.as(pk).lo, rh, M, kHidden, st));
         EpiKV kv{k_ref, v_ref, kvref_b_, B, kHeads, kDh, R};
-        HIPC(gemm3_kv(ops3(w.seqs, rh, kvref_, M), kv, split_, st));
+        HIPC(gemm3_kv(ops3(w.seqs, rh, kvref_, M, pk), kv, pk, st));
         HIPC(launch_headnorm(k_ref, kBlocks, B, kHeads, R, kDh, 1e-6f, knc_, st));
     }
     if (fork) HIPC(hipStreamWaitEvent(st, ev_join_, 0));  // join: everything after cond_encode sees both halves
@@ -725,18 +803,19 @@ int Engine::cond_encode(hipStream_t st, const float* ref, const int64_t* ref_len
 int Engine::modulation(hipStream_t st, const float* t_dev, int rows, float* sinb, float* t1, float* temb, float* e1,
                        float* semb, float* mod) {
     ProfTag ptag("mod");
+    const int pc = prec_[SITE_COND];  // tiny-M chain on the fp32-A kernel: always split-bf16 unless the preset is plain bf16
     HIPC(launch_time_sinusoid(t_dev, sinb, rows, st));
     HIPC(gemm_store(ops(sinb, rowmap_plain(256), time0_, rows), ACT_SILU,
-                    store_to(t1, rowmap_plain(kHidden), rawp("time_embedding.mlp.0.bias")), 1, split_, st));
+                    store_to(t1, rowmap_plain(kHidden), rawp("time_embedding.mlp.0.bias")), 1, pc, st));
     HIPC(gemm_store(ops(t1, rowmap_plain(kHidden), time2_, rows), ACT_NONE,
-                    store_to(temb, rowmap_plain(kHidden), rawp("time_embedding.mlp.2.bias")), 1, split_, st));
+                    store_to(temb, rowmap_plain(kHidden), rawp("time_embedding.mlp.2.bias")), 1, pc, st));
     HIPC(gemm_store(ops(temb, rowmap_plain(kHidden), emb0_, rows), ACT_SILU,
-                    store_to(e1, rowmap_plain(2 * kHidden), rawp("dit.emb_proj.0.bias")), 1, split_, st));
+                    store_to(e1, rowmap_plain(2 * kHidden), rawp("dit.emb_proj.0.bias")), 1, pc, st));
     // AdaLN consumes silu(emb) only (dit.py:20,36), so the SiLU is fused into this epilogue
     HIPC(gemm_store(ops(e1, rowmap_plain(2 * kHidden), emb2_, rows), ACT_SILU,
-                    store_to(semb, rowmap_plain(kHidden), rawp("dit.emb_proj.2.bias")), 1, split_, st));
+                    store_to(semb, rowmap_plain(kHidden), rawp("dit.emb_proj.2.bias")), 1, pc, st));
     HIPC(gemm_store(ops(semb, rowmap_plain(kHidden), modall_, rows), ACT_NONE,
-                    store_to(mod, rowmap_plain(kModLd), modall_b_), 1, split_, st));
+                    store_to(mod, rowmap_plain(kModLd), modall_b_), 1, pc, st));
     HIPC(launch_tanh_gates(mod, rows, kModLd, kBlocks, kModPerBlock, kHidden, st));
     return 0;
 }
@@ -793,29 +872,33 @@ int Engine::denoise_core(hipStream_t st, const float* x_t, const uint8_t* mask, 
     w.plan(bump, B, N);
     const int M = B * N;
     const RowMap rh = rowmap_plain(kHidden);
+    // operand formats: the block GEMMs run at SITE_DIT_BLOCK precision, the latent in-projection / conv pos-embed / velocity
+    // head at SITE_COND; each activation buffer is written in the format of the GEMM that reads it
+    const int pb = prec_[SITE_DIT_BLOCK], pc = prec_[SITE_COND];
+    const SplitBuf gm1 = w.gm1.as(pc), gm2 = w.gm2.as(pc), yb = w.y.as(pb), ob = w.o.as(pb), ffh = w.ffh.as(pb);
     // D2 input embedding (dit.py:246-253): h = proj(x); x = mask*mish(conv2(mask*mish(conv1(mask*h)))) + h
     HIPC(gemm_store(ops(x_t, rowmap_plain(kLatent), inproj_, M), ACT_NONE,
-                    store_to(w.h, rh, rawp("dit.input_embed.proj.bias")), 1, split_, st));
-    HIPC(launch_convpos_pack(w.h, mask, w.gm1.hi, w.gm1.lo, B, N, kConvG, kConvCpg, kConvPad, kConvGs, st));
+                    store_to(w.h, rh, rawp("dit.input_embed.proj.bias")), 1, pc, st));
+    HIPC(launch_convpos_pack(w.h, mask, gm1.hi, gm1.lo, B, N, kConvG, kConvCpg, kConvPad, kConvGs, st));
     HIPC(hipMemsetAsync(w.gm2.hi, 0, w.gm_elems * 2, st));
     HIPC(hipMemsetAsync(w.gm2.lo, 0, w.gm_elems * 2, st));
     {
         // grouped conv k=31 as B*G small GEMMs: z = b*G + g, rows = frames, K = 31 taps x 64 (padded) channels
         const long zs = (long)(N + 2 * kConvPad) * kConvGs;
-        Gemm3Operands g = ops3(w.gm1, rowmap_plain(kConvGs), conv1_, N, 0, kConvCpg);
+        Gemm3Operands g = ops3(w.gm1, rowmap_plain(kConvGs), conv1_, N, pc, 0, kConvCpg);
         g.a_z = zs;
         g.w_z = (long)kConvCpg * conv1_.K;
         g.w_zmod = kConvG;
         EpiConvPos<0> e1{nullptr, nullptr, rawp("dit.input_embed.conv_pos_embed.conv1.bias"), mask, kConvG, kConvCpg, N,
-                         kConvPad, kConvGs, w.gm2.hi, w.gm2.lo};
-        HIPC(gemm3_convpos(g, false, e1, B * kConvG, split_, st));
-        g = ops3(w.gm2, rowmap_plain(kConvGs), conv2_, N, 0, kConvCpg);
+                         kConvPad, kConvGs, gm2.hi, gm2.lo};
+        HIPC(gemm3_convpos(g, false, e1, B * kConvG, pc, st));
+        g = ops3(w.gm2, rowmap_plain(kConvGs), conv2_, N, pc, 0, kConvCpg);
         g.a_z = zs;
         g.w_z = (long)kConvCpg * conv2_.K;
         g.w_zmod = kConvG;
         EpiConvPos<0> e2{w.x, w.h, rawp("dit.input_embed.conv_pos_embed.conv2.bias"), mask, kConvG, kConvCpg, N,
                          kConvPad, kConvGs, nullptr, nullptr};
-        HIPC(gemm3_convpos(g, true, e2, B * kConvG, split_, st));
+        HIPC(gemm3_convpos(g, true, e2, B * kConvG, pc, st));
     }
     // zero the padded tail columns [2400, 2432) of the FF hidden once per call
     HIPC(hipMemsetAsync(w.ffh.hi, 0, (size_t)M * kFFp * 2, st));
@@ -829,7 +912,7 @@ int Engine::denoise_core(hipStream_t st, const float* x_t, const uint8_t* mask, 
     }
     // The AdaLN in front of each GEMM is fused into the kernel that produced the residual stream it normalises
     // (split-K reduction + gated residual + LayerNorm-modulate in one pass); only the very first one runs alone.
-    HIPC(launch_ln_modulate(w.x, nullptr, w.y.hi, w.y.lo, M, kHidden, 1e-6f, mod + 0 * kHidden, mod + 1 * kHidden, kModLd,
+    HIPC(launch_ln_modulate(w.x, nullptr, yb.hi, yb.lo, M, kHidden, 1e-6f, mod + 0 * kHidden, mod + 1 * kHidden, kModLd,
                             mod_row0, mod_rstride, N, st));
     // split-K exists to fill the chip at M = 600 (150 tiles of 64x64 for N = 960); the 3B-row CFG batches of the teacher
     // sampler (M = 1800: 435 tiles) fill it without, and the fused epilogue is cheaper than partials + reduce (495 -> 454 ms)
@@ -838,8 +921,8 @@ int Engine::denoise_core(hipStream_t st, const float* x_t, const uint8_t* mask, 
         const DitBlockW& b = blocks_[l];
         const float* m = mod + (long)l * kModPerBlock;
         // D5 AdaLN-Zero (dit.py:19-25) already in w.y; D6 joint attention (dit.py:95-135)
-        HIPC(gemm3_store(ops3(w.y, rh, b.qkvg, M), ACT_NONE, store_to(w.qkvg, rowmap_plain(4 * kHidden), b.b_qkvg), 1,
-                         split_, st));
+        HIPC(gemm3_store(ops3(w.y, rh, b.qkvg, M, pb), ACT_NONE, store_to(w.qkvg, rowmap_plain(4 * kHidden), b.b_qkvg), 1,
+                         pb, st));
         AttnArgs a{};
         a.q = w.qkvg; a.k = w.qkvg + kHidden; a.v = w.qkvg + 2 * kHidden; a.gate = w.qkvg + 3 * kHidden;
         a.bs = (long)N * 4 * kHidden; a.rs = 4 * kHidden;
@@ -849,41 +932,42 @@ int Engine::denoise_core(hipStream_t st, const float* x_t, const uint8_t* mask, 
         a.k_ref = R > 0 ? k_ref + lr : nullptr; a.v_ref = R > 0 ? v_ref + lr : nullptr; a.R = R;
         a.k_text = P > 0 ? k_text + lp : nullptr; a.v_text = P > 0 ? v_text + lp : nullptr; a.P = P;
         a.mask_self = mask; a.mask_ref = ref_mask; a.mask_text = ph_mask;
-        a.out = nullptr; a.out_hi = w.o.hi; a.out_lo = w.o.lo; a.obs = (long)N * kHidden; a.ors = kHidden;
+        a.out = nullptr; a.out_hi = ob.hi; a.out_lo = ob.lo; a.obs = (long)N * kHidden; a.ors = kHidden;
         a.B = B; a.N = N; a.H = kHeads; a.dh = kDh;
         a.prenormed = 1;
         HIPC(launch_qk_prep(a, st));
         HIPC(attn_mfma_ ? launch_attention_mfma(a, st) : launch_attention(a, st));
         // to_out + mask + gated residual (dit.py:117-118,198), then the MLP AdaLN (dit.py:199)
         EpiResid<0> r1{w.x, rh, nullptr, m + 2 * kHidden, kModLd, mod_row0, mod_rstride, N, mask};
-        NextLN ln1{m + 3 * kHidden, m + 4 * kHidden, w.y.hi, w.y.lo};
+        NextLN ln1{m + 3 * kHidden, m + 4 * kHidden, yb.hi, yb.lo};
         if (ks_out > 1) {
-            HIPC(gemm3_resid_splitk(ops3(w.o, rh, b.out, M), r1, w.part, ks_out, split_, st, ln1));
+            HIPC(gemm3_resid_splitk(ops3(w.o, rh, b.out, M, pb), r1, w.part, ks_out, pb, st, ln1));
         } else {
-            HIPC(gemm3_resid(ops3(w.o, rh, b.out, M), 1, r1, split_, st));
-            HIPC(launch_ln_modulate(w.x, nullptr, w.y.hi, w.y.lo, M, kHidden, 1e-6f, ln1.shift, ln1.scale, kModLd, mod_row0,
+            HIPC(gemm3_resid(ops3(w.o, rh, b.out, M, pb), 1, r1, pb, st));
+            HIPC(launch_ln_modulate(w.x, nullptr, ln1.yhi, ln1.ylo, M, kHidden, 1e-6f, ln1.shift, ln1.scale, kModLd, mod_row0,
                                     mod_rstride, N, st));
         }
         // D7 feed-forward (dit.py:199-201)
-        EpiSwiGLU sw{nullptr, kFFp, b.b1, b.b3, w.ffh.hi, w.ffh.lo};
-        HIPC(gemm3_swiglu(ops3(w.y, rh, b.ff13, M), sw, split_, st));
+        EpiSwiGLU sw{nullptr, kFFp, b.b1, b.b3, ffh.hi, ffh.lo};
+        HIPC(gemm3_swiglu(ops3(w.y, rh, b.ff13, M, pb), sw, pb, st));
         // w2 + gated residual, then the next block's attention AdaLN — or D8's final AdaLN (chunk order scale, shift:
         // dit.py:37) after the last block
         EpiResid<0> r2{w.x, rh, b.b2, m + 5 * kHidden, kModLd, mod_row0, mod_rstride, N, nullptr};
         const float* mn = m + kModPerBlock;  // next block's modulation (or the final norm's [scale | shift])
-        NextLN ln2 = l + 1 < kBlocks ? NextLN{mn + 0 * kHidden, mn + 1 * kHidden, w.y.hi, w.y.lo}
-                                     : NextLN{mn + kHidden, mn, w.y.hi, w.y.lo};
+        const SplitBuf yv = w.y.as(pc);  // the final AdaLN feeds the velocity head (SITE_COND)
+        NextLN ln2 = l + 1 < kBlocks ? NextLN{mn + 0 * kHidden, mn + 1 * kHidden, yb.hi, yb.lo}
+                                     : NextLN{mn + kHidden, mn, yv.hi, yv.lo};
         if (ks_ff2 > 1) {
-            HIPC(gemm3_resid_splitk(ops3(w.ffh, rowmap_plain(kFFp), b.ff2, M), r2, w.part, ks_ff2, split_, st, ln2));
+            HIPC(gemm3_resid_splitk(ops3(w.ffh, rowmap_plain(kFFp), b.ff2, M, pb), r2, w.part, ks_ff2, pb, st, ln2));
         } else {
-            HIPC(gemm3_resid(ops3(w.ffh, rowmap_plain(kFFp), b.ff2, M), 1, r2, split_, st));
-            HIPC(launch_ln_modulate(w.x, nullptr, w.y.hi, w.y.lo, M, kHidden, 1e-6f, ln2.shift, ln2.scale, kModLd, mod_row0,
+            HIPC(gemm3_resid(ops3(w.ffh, rowmap_plain(kFFp), b.ff2, M, pb), 1, r2, pb, st));
+            HIPC(launch_ln_modulate(w.x, nullptr, ln2.yhi, ln2.ylo, M, kHidden, 1e-6f, ln2.shift, ln2.scale, kModLd, mod_row0,
                                     mod_rstride, N, st));
         }
     }
     // velocity head (model.py:100) on the final AdaLN output
-    HIPC(gemm3_store(ops3(w.y, rh, velocity_, M), ACT_NONE, store_to(velocity, rowmap_plain(kLatent), rawp("velocity.bias")),
-                     1, split_, st));
+    HIPC(gemm3_store(ops3(w.y, rh, velocity_, M, pc), ACT_NONE, store_to(velocity, rowmap_plain(kLatent), rawp("velocity.bias")),
+                     1, pc, st));
     return 0;
 }
 
@@ -1042,6 +1126,9 @@ int Engine::codec_block(hipStream_t st, const CodecBlockW& w, float** xp, float*
     const RowMap img = rowmap_batched(C, T, (long)(pad + T) * C, (long)pad * C);
     const int F = cspec_.ffn_mult * C;
     const RowMap rc = rowmap_plain(C), rf = rowmap_plain(F);
+    const int pf = prec_[SITE_CODEC_FFN];
+    bf16_t* const n2lo_f = sm_lo_for(pf, n2lo);  // (hi, lo) pairs handed to producers: the format the FFN GEMMs read
+    auto wsel = [pf](const PW& w) { return pf == PREC_F16 ? w.h16 : w.hi; };
     bool n2_done = false;  // the FFN's normalised input was already produced by the fused depthwise-conv kernel
     // mixer: RMSNorm -> causal depthwise conv -> LayerScale residual
     if (C <= 256 && 256 % (C / 4) == 0 && cspec_.kernel <= 7 && fused_ffn_) {  // narrow stages: one out-of-place kernel, then swap images
@@ -1053,7 +1140,7 @@ int Engine::codec_block(hipStream_t st, const CodecBlockW& w, float** xp, float*
         HIPC(launch_rmsnorm(x, img, nbuf, nullptr, nullptr, img, M, C, cspec_.eps, w.norm_w, st));
         if (fused_ffn_ && C % 64 == 0 && F % 64 == 0 && C <= 2048) {  // + the FFN's RMSNorm of the updated rows (split pair n2)
             HIPC(launch_dwconv_resid_rms(x, nbuf, w.dw_w, w.dw_b, w.gamma, B, T, C, cspec_.kernel, pad, cspec_.eps, w.ffn_norm_w,
-                                         n2hi, n2lo, rowmap_plain(C), st));
+                                         n2hi, n2lo_f, rowmap_plain(C), st));
             n2_done = true;
         } else {
             HIPC(launch_dwconv_resid(x, nbuf, w.dw_w, w.dw_b, w.gamma, B, T, C, cspec_.kernel, pad, st));
@@ -1062,14 +1149,14 @@ int Engine::codec_block(hipStream_t st, const CodecBlockW& w, float** xp, float*
     // FFN: RMSNorm -> Linear 4x -> GELU -> Linear -> LayerScale residual
     if (fused_ffn_ && (C == 32 || C == 64) && F == 4 * C && w.w1.K == C && w.w2.K == F) {
         // narrowest stages: all weights LDS-resident, one wave per 32 frames, hidden stays in registers (codec_ffn_wave.hip)
-        HIPC(launch_codec_ffn_wave(x, img, w.ffn_norm_w, w.w1.hi, w.w1.lo, w.w1.K, w.b1, w.w2.hi, w.w2.lo, w.b2, w.ffn_gamma, M,
-                                   C, F, cspec_.eps, split_, st));
+        HIPC(launch_codec_ffn_wave(x, img, w.ffn_norm_w, wsel(w.w1), w.w1.lo, w.w1.K, w.b1, wsel(w.w2), w.w2.lo, w.b2, w.ffn_gamma, M,
+                                   C, F, cspec_.eps, pf, st));
         return 0;
     }
     if (w.w2t.N && fused_ffn_) {
         // C = 128 / 256: weights stream through an LDS ring, hidden in registers (codec_ffn_stream.hip)
-        HIPC(launch_codec_ffn_stream(x, img, w.ffn_norm_w, w.w1.hi, w.w1.lo, w.b1, w.w2t.hi, w.w2t.lo, w.b2, w.ffn_gamma, M, C, F,
-                                     cspec_.eps, split_, st));
+        HIPC(launch_codec_ffn_stream(x, img, w.ffn_norm_w, wsel(w.w1), w.w1.lo, w.b1, wsel(w.w2t), w.w2t.lo, w.b2, w.ffn_gamma, M, C, F,
+                                     cspec_.eps, pf, st));
         return 0;
     }
     // wide stages: two gemm3 launches; n2 / hidden are split bf16 pairs
@@ -1078,18 +1165,18 @@ int Engine::codec_block(hipStream_t st, const CodecBlockW& w, float** xp, float*
         float* hf = reinterpret_cast<float*>(hhi);  // hhi/hlo are adjacent: 2 x F x M bf16 = F x M fp32
         if (reinterpret_cast<char*>(hlo) < reinterpret_cast<char*>(hhi) + (size_t)M * F * 2) return fail("codec ws layout");
         HIPC(launch_rmsnorm(x, img, nbuf, nullptr, nullptr, img, M, C, cspec_.eps, w.ffn_norm_w, st));
-        HIPC(gemm_store(ops(nbuf, img, w.w1, M), ACT_GELU, store_to(hf, rf, w.b1), 1, split_, st));
+        HIPC(gemm_store(ops(nbuf, img, w.w1, M), ACT_GELU, store_to(hf, rf, w.b1), 1, pf, st));
         EpiResid<0> r0{x, img, w.b2, w.ffn_gamma, 0, 0, 0, 1, nullptr};
-        HIPC(gemm_resid(ops(hf, rf, w.w2, M), 2, r0, split_, st));
+        HIPC(gemm_resid(ops(hf, rf, w.w2, M), 2, r0, pf, st));
         return 0;
     }
     if (C % 64 == 0) {
         SplitBuf n2{n2hi, n2lo};
-        if (!n2_done) HIPC(launch_rmsnorm(x, img, nullptr, n2hi, n2lo, rc, M, C, cspec_.eps, w.ffn_norm_w, st));
-        HIPC(gemm3_store(ops3(n2, rc, w.w1, M), ACT_GELU, store_split_to(hid, rf, w.b1), 1, split_, st));
+        if (!n2_done) HIPC(launch_rmsnorm(x, img, nullptr, n2hi, n2lo_f, rc, M, C, cspec_.eps, w.ffn_norm_w, st));
+        HIPC(gemm3_store(ops3(n2, rc, w.w1, M, pf), ACT_GELU, store_split_to(hid.as(pf), rf, w.b1), 1, pf, st));
     } else {  // K = C < 64 (last stage, C = 32): one k-tile on the fp32-A kernel, still writing the split hidden
         HIPC(launch_rmsnorm(x, img, nbuf, nullptr, nullptr, img, M, C, cspec_.eps, w.ffn_norm_w, st));
-        HIPC(gemm_store(ops(nbuf, img, w.w1, M), ACT_GELU, store_split_to(hid, rf, w.b1), 1, split_, st));
+        HIPC(gemm_store(ops(nbuf, img, w.w1, M), ACT_GELU, store_split_to(hid.as(pf), rf, w.b1), 1, pf, st));
     }
     EpiResid<0> r{x, img, w.b2, w.ffn_gamma, 0, 0, 0, 1, nullptr};
     {
@@ -1103,11 +1190,11 @@ int Engine::codec_block(hipStream_t st, const CodecBlockW& w, float** xp, float*
         if (splits > nk / 8) splits = nk / 8;
         if (g_gemm3_t160 && M > 480 && M <= 640 && splits >= 2 && (size_t)splits * M * C * 2 <= n2_elems && C % 4 == 0) {
             float* part = reinterpret_cast<float*>(n2hi);  // n2hi holds n2_elems bf16 = n2_elems / 2 floats
-            HIPC(gemm3_resid_splitk(ops3(hid, rf, w.w2, M), r, part, splits, split_, st, NextLN(), G3_160x128));
+            HIPC(gemm3_resid_splitk(ops3(hid, rf, w.w2, M, pf), r, part, splits, pf, st, NextLN(), G3_160x128));
             return 0;
         }
     }
-    HIPC(gemm3_resid(ops3(hid, rf, w.w2, M), 2, r, split_, st));
+    HIPC(gemm3_resid(ops3(hid, rf, w.w2, M, pf), 2, r, pf, st));
     return 0;
 }
 
@@ -1153,6 +1240,8 @@ int Engine::codec_decode(hipStream_t st, const float* latents, int B, int T, flo
     HIPC(hipSetDevice(device_));
     const CodecSpecC& s = cspec_;
     const int S = s.n_ratios + 1, pad = kCodecPad, Kc = s.kernel, L = s.latent_dim;
+    const int pcv = prec_[SITE_CODEC_CONV];
+    const int pcv3 = pcv == PREC_F16 ? PREC_BF16X3 : pcv;  // the fp32-A and streaming-upsample kernels have no fp16 variant
     // re-derive the plan
     size_t max_img = 0, max_hid = 0;
     {
@@ -1184,7 +1273,7 @@ int Engine::codec_decode(hipStream_t st, const float* latents, int B, int T, flo
     {
         RowMap am = rowmap_batched(L, Ti, (long)(pad + Ti) * L, (long)(pad - (Kc - 1)) * L);
         RowMap om = rowmap_batched(C, Ti, (long)(pad + Ti) * C, (long)pad * C);
-        HIPC(gemm_store(ops(w.lat, am, dec_.stem, B * Ti), ACT_NONE, store_to(x, om, dec_.stem_b), 1, split_, st));
+        HIPC(gemm_store(ops(w.lat, am, dec_.stem, B * Ti), ACT_NONE, store_to(x, om, dec_.stem_b), 1, pcv3, st));
     }
     static const char* kDecTags[] = {"dec.s0", "dec.s1", "dec.s2", "dec.s3", "dec.s4", "dec.s5", "dec.s6", "dec.s7"};
     for (int i = 0; i < S; ++i) {
@@ -1199,15 +1288,15 @@ int Engine::codec_decode(hipStream_t st, const float* latents, int B, int T, flo
             RowMap om = rowmap_batched((long)r * Cn, Ti, (long)(pad + Tn) * Cn, (long)pad * Cn);
             if (fused_ffn_ && codec_upsample_wave_ok(sg.resample.K, sg.resample.N) && sg.resample.K == 2 * C && sg.resample.N == r * Cn)
                 HIPC(launch_codec_upsample_wave(x, am, sg.resample.hi, sg.resample.lo, sg.resample.K, sg.resample_bias, xn, om,
-                                                B * Ti, sg.resample.K, sg.resample.N, split_, st));
+                                                B * Ti, sg.resample.K, sg.resample.N, pcv3, st));
             else if (fused_ffn_ && sg.resample.K % 64 == 0 && sg.resample.K >= 2048 && C % 8 == 0 && (size_t)B * (pad + Ti) * C <= max_img) {
                 // widest stages (K >= 2048; measured: 215 -> 148 us and 216 -> 193 us, no gain at K <= 1024): split the image once (pads included: they are the causal zeros) and run the DMA-ring GEMM on
                 // the overlapping rows of the split pair (n2 is free between blocks)
                 SplitBuf xs{w.n2hi, w.n2lo};
-                HIPC(launch_to_split(x, rowmap_plain(C), xs.hi, xs.lo, rowmap_plain(C), B * (pad + Ti), C, st));
-                HIPC(gemm3_store(ops3(xs, am, sg.resample, B * Ti), ACT_NONE, store_to(xn, om, sg.resample_bias), 1, split_, st));
+                HIPC(launch_to_split(x, rowmap_plain(C), xs.hi, xs.as(pcv).lo, rowmap_plain(C), B * (pad + Ti), C, st));
+                HIPC(gemm3_store(ops3(xs, am, sg.resample, B * Ti, pcv), ACT_NONE, store_to(xn, om, sg.resample_bias), 1, pcv, st));
             } else
-                HIPC(gemm_store(ops(x, am, sg.resample, B * Ti), ACT_NONE, store_to(xn, om, sg.resample_bias), 1, split_, st));
+                HIPC(gemm_store(ops(x, am, sg.resample, B * Ti), ACT_NONE, store_to(xn, om, sg.resample_bias), 1, pcv3, st));
             float* t = x; x = xn; xn = t;
             Ti = Tn;
             C = Cn;
@@ -1245,6 +1334,7 @@ int Engine::codec_encode(hipStream_t st, const float* audio, int B, int S_, floa
     HIPC(hipSetDevice(device_));
     const CodecSpecC& s = cspec_;
     const int S = s.n_ratios + 1, pad = kCodecPad, Kc = s.kernel;
+    const int pcv3 = prec_[SITE_CODEC_CONV] == PREC_F16 ? PREC_BF16X3 : prec_[SITE_CODEC_CONV];
     size_t max_img = 0, max_hid = 0;
     {
         long Ti = S_;
@@ -1279,7 +1369,7 @@ int Engine::codec_encode(hipStream_t st, const float* audio, int B, int S_, floa
             HIPC(launch_zero_pad_frames(w.nb, B, Tn, Cn, pad, st));
             RowMap am = rowmap_batched((long)r * C, Tn, (long)(pad + Ti) * C, (long)(pad - r) * C);
             RowMap om = rowmap_batched(Cn, Tn, (long)(pad + Tn) * Cn, (long)pad * Cn);
-            HIPC(gemm_store(ops(x, am, sg.resample, B * Tn), ACT_NONE, store_to(xn, om, sg.resample_bias), 1, split_, st));
+            HIPC(gemm_store(ops(x, am, sg.resample, B * Tn), ACT_NONE, store_to(xn, om, sg.resample_bias), 1, pcv3, st));
             float* t = x; x = xn; xn = t;
             Ti = Tn;
             C = Cn;
@@ -1290,7 +1380,7 @@ int Engine::codec_encode(hipStream_t st, const float* audio, int B, int S_, floa
     }
     RowMap am = rowmap_batched(C, Ti, (long)(pad + Ti) * C, (long)(pad - (Kc - 1)) * C);
     HIPC(gemm_store(ops(x, am, enc_.head, B * Ti), ACT_NONE, store_to(latents, rowmap_plain(s.latent_dim), enc_.head_b), 1,
-                    split_, st));
+                    pcv3, st));
     return 0;
 }
 
@@ -1321,11 +1411,12 @@ int Engine::test_gemm3(hipStream_t st, const float* A, const float* W, const flo
     HIPC(hipMalloc(&lo, (size_t)N * K * 2));
     HIPC(hipMalloc(&ahi, (size_t)M * K * 2));
     HIPC(hipMalloc(&alo, (size_t)M * K * 2));
-    HIPC(launch_split_rows(W, K, hi, lo, K, N, K, nullptr, st));
-    HIPC(launch_to_split(A, rowmap_plain(K), ahi, alo, rowmap_plain(K), M, K, st));
+    // PREC_F16: the single 16-bit arrays (hi) carry fp16
+    HIPC(launch_split_rows(W, K, split == PREC_F16 ? nullptr : hi, lo, K, N, K, nullptr, st, split == PREC_F16 ? hi : nullptr));
+    HIPC(launch_to_split(A, rowmap_plain(K), ahi, sm_lo_for(split, alo), rowmap_plain(K), M, K, st));
     PW w;
-    w.hi = hi; w.lo = lo; w.N = N; w.K = K;
-    hipError_t e = gemm3_store(ops3(SplitBuf{ahi, alo}, rowmap_plain(K), w, M), act, store_to(C, rowmap_plain(N), bias), 1,
+    w.hi = hi; w.lo = lo; w.h16 = hi; w.N = N; w.K = K;
+    hipError_t e = gemm3_store(ops3(SplitBuf{ahi, alo}, rowmap_plain(K), w, M, split), act, store_to(C, rowmap_plain(N), bias), 1,
                                split, st, cfg);
     (void)hipStreamSynchronize(st);
     for (void* p : {(void*)hi, (void*)lo, (void*)ahi, (void*)alo}) (void)hipFree(p);
@@ -1376,12 +1467,12 @@ int Engine::bench_gemm(int M, int N, int K, int epi, int split, int cfg, int ite
     HIPC(launch_synth(bias, N, 3, 0.f, 0.1f, 0));
     HIPC(launch_synth(gate, N, 4, 0.f, 0.5f, 0));
     HIPC(hipMemsetAsync(C, 0, (size_t)M * N * 4, 0));
-    HIPC(launch_split_rows(Wf, K, hi, lo, K, N, K, nullptr, 0));
+    HIPC(launch_split_rows(Wf, K, split == PREC_F16 ? nullptr : hi, lo, K, N, K, nullptr, 0, split == PREC_F16 ? hi : nullptr));
     PW w;
-    w.hi = hi; w.lo = lo; w.N = N; w.K = K;
+    w.hi = hi; w.lo = lo; w.h16 = hi; w.N = N; w.K = K;
     GemmOperands g = ops(A, rowmap_plain(K), w, M);
-    HIPC(launch_to_split(A, rowmap_plain(K), ahi, alo, rowmap_plain(K), M, K, 0));
-    Gemm3Operands g3 = ops3(SplitBuf{ahi, alo}, rowmap_plain(K), w, M);
+    HIPC(launch_to_split(A, rowmap_plain(K), ahi, sm_lo_for(split, alo), rowmap_plain(K), M, K, 0));
+    Gemm3Operands g3 = ops3(SplitBuf{ahi, alo}, rowmap_plain(K), w, M, split);
     auto run = [&]() -> hipError_t {
         if (ver == 3) {
             switch (epi) {

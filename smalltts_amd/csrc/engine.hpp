@@ -4,6 +4,7 @@
 // Single-stream, not thread-safe: one Engine per GPU (mirrors the reference's one-Session-per-
 // pipeline model, src/server/src/main.rs:24).
 #pragma once
+#include <initializer_list>
 #include <map>
 #include <string>
 #include <vector>
@@ -18,9 +19,10 @@ struct RawTensor {
     long numel = 0;
 };
 
-struct PW {  // packed GEMM weight [N][K], bf16 hi + lo
+struct PW {  // packed GEMM weight [N][K]: bf16 hi + lo (PREC_BF16X3 / PREC_BF16) and the same rows as fp16 (PREC_F16)
     bf16_t* hi = nullptr;
     bf16_t* lo = nullptr;
+    bf16_t* h16 = nullptr;
     int N = 0, K = 0;  // K = row stride = GEMM K (may be zero-padded beyond the source width)
 };
 
@@ -89,11 +91,31 @@ class Engine {
     bool has_dit() const { return dit_ready_; }
     bool has_decoder() const { return dec_.ready; }
     bool has_encoder() const { return enc_.ready; }
-    void set_precision(int split) { split_ = split == 1 ? 1 : 3; }
+    // Per-site operand precision (PREC_* of common.hpp).  Sites: the GEMMs grouped by how much latent / audio error their
+    // rounding causes (tests/studies/precision_ladder_cpu.py) and by what they cost.
+    enum Site { SITE_DIT_BLOCK = 0,   // QKVG, out-proj, FF1 (SwiGLU), FF2 of the 12 DiT blocks: 95 % of the DiT's flops and bytes
+                SITE_ENCODER = 1,     // style / text encoder blocks + their output projections
+                SITE_CROSS_KV = 2,    // cross-attention K / V projections of the condition cache
+                SITE_COND = 3,        // time / AdaLN modulation chain, latent in-projection, conv pos-embed, velocity head, style in-proj
+                SITE_CODEC_FFN = 4,   // codec block FFNs (fused kernels and the wide-stage GEMM pairs)
+                SITE_CODEC_CONV = 5,  // codec stem / resampling (ConvTranspose, strided conv) / encoder head GEMMs
+                SITE_COUNT = 6 };
+    // preset: 3 = split-bf16 everywhere (fp32-class), 1 = single-pass bf16 everywhere, 2 = "f16 mixed": single-pass fp16 on
+    // the block / encoder / cross-KV / codec-FFN GEMMs, split-bf16 on SITE_COND and SITE_CODEC_CONV
+    void set_precision(int preset) {
+        preset_ = preset == PREC_BF16 ? PREC_BF16 : preset == PREC_F16 ? PREC_F16 : PREC_BF16X3;
+        for (int i = 0; i < SITE_COUNT; ++i) prec_[i] = preset_;
+        if (preset_ == PREC_F16) prec_[SITE_COND] = prec_[SITE_CODEC_CONV] = PREC_BF16X3;
+    }
+    int set_site_precision(int site, int prec) {
+        if (site < 0 || site >= SITE_COUNT || prec < 1 || prec > 3) return fail("set_site_precision: bad site / precision");
+        prec_[site] = prec;
+        return 0;
+    }
     void set_fused_ffn(bool on) { fused_ffn_ = on; }
     void set_attn_mfma(bool on) { attn_mfma_ = on; }
     void set_dual_stream(bool on) { dual_stream_ = on; }
-    int precision() const { return split_; }
+    int precision() const { return preset_; }
 
     // ---- operators (device pointers, async on `st`) ------------------------------------------
     size_t cond_ws_bytes(int B, int R, int P) const;
@@ -162,12 +184,18 @@ class Engine {
     // runs one block; the result lives in *x on return (the fused mixer ping-pongs *x <-> *xalt)
     int codec_block(hipStream_t st, const CodecBlockW& w, float** x, float** xalt, float* nbuf, bf16_t* n2hi, bf16_t* n2lo,
                     bf16_t* hhi, bf16_t* hlo, int B, int T, int C, size_t n2_elems /* capacity of n2hi (bf16 elements) */);
+    int check_shape(const std::string& name, std::initializer_list<long> want);
+    void invalidate() { finalized_ = false; dit_ready_ = false; dec_.ready = false; enc_.ready = false; }
+    void free_packs();
 
     int device_;
     std::string err_;
     std::map<std::string, RawTensor> raw_;
-    std::vector<void*> allocs_;
-    int split_ = 3;
+    std::vector<void*> allocs_;       // raw fp32 tensors (live as long as the engine)
+    std::vector<void*> pack_allocs_;  // everything finalize() builds: freed and rebuilt by the next finalize()
+    bool packing_ = false;
+    int preset_ = PREC_BF16X3;
+    int prec_[SITE_COUNT] = {3, 3, 3, 3, 3, 3};
     bool fused_ffn_ = true;  // test hook: smtts_test_set_fused_ffn
     int ksplit_enc_ = 4;  // split-K of the encoders' residual projections (1 = fused-epilogue GEMM + separate RMSNorm)
     int ksplit_out_ = 3, ksplit_ff2_ = 3;  // (<= kSplitK; 150 tiles x 3 = 450 workgroups = one round at 2 per CU) split-K factors of the two N = 960 DiT projections (1 = fused epilogue)

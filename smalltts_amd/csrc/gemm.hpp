@@ -230,10 +230,7 @@ struct EpiStore {
                 float v = apply_act<ACT>((acc[r] + b) * scale);
                 v = rc.aux[r] ? v : 0.f;
                 if (ohi) {
-                    bf16_t hh, ll;
-                    split1(v, hh, ll);
-                    ohi[rc.off[r] + n] = hh;
-                    if (olo) olo[rc.off[r] + n] = ll;
+                    store_act1(ohi, olo, rc.off[r] + n, v);
                 } else {
                     out[rc.off[r] + n] = v;
                 }
@@ -270,10 +267,7 @@ struct EpiSwiGLU {
                 const float x = a[r] + v1;
                 const float v = silu_f(x) * (b[r] + v3);
                 if (ohi) {
-                    bf16_t hh, ll;
-                    split1(v, hh, ll);
-                    ohi[rc.off[r] + nh] = hh;
-                    if (olo) olo[rc.off[r] + nh] = ll;
+                    store_act1(ohi, olo, rc.off[r] + nh, v);
                 } else {
                     out[rc.off[r] + nh] = v;
                 }
@@ -402,10 +396,7 @@ struct EpiConvPos {
                 if (FINAL) {
                     out[rc.off[r] + ch] = v + hv[r];
                 } else if (ohi) {
-                    bf16_t hh, ll;
-                    split1(v, hh, ll);
-                    ohi[rc.off[r] + n] = hh;
-                    if (olo) olo[rc.off[r] + n] = ll;
+                    store_act1(ohi, olo, rc.off[r] + n, v);
                 } else {
                     out[rc.off[r] + n] = v;
                 }
@@ -501,12 +492,13 @@ static inline hipError_t gemm_launch_split(const GemmOperands& g, const Epi& epi
     return hipErrorInvalidValue;
 }
 
-// split: 1 = plain bf16, 3 = split-bf16 (fp32-class)
+// split: 1 = plain bf16, 3 = split-bf16 (fp32-class).  This fp32-A kernel serves the cold sites only and has no fp16
+// variant: PREC_F16 runs as split-bf16 here (its OUTPUT may still be written in any operand format, see store_act1).
 template <class Epi>
 static inline hipError_t gemm_launch(const GemmOperands& g, const Epi& epi, int Z, int split, hipStream_t st,
                                      int cfg = -1) {
     if (g.M <= 0 || g.N <= 0) return hipSuccess;
     if (cfg < 0) cfg = gemm_pick_cfg(g.M, g.N, g.K, Epi::PAIRED);
-    if (split == 3) return gemm_launch_split<3, Epi>(g, epi, Z, cfg, st);
+    if (split != PREC_BF16) return gemm_launch_split<3, Epi>(g, epi, Z, cfg, st);
     return gemm_launch_split<1, Epi>(g, epi, Z, cfg, st);
 }

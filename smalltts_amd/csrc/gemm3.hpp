@@ -223,7 +223,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm3_kernel(Gemm3Operands g, Epi
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
                     }
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = mfma16<SPLIT>(ah[i], bh[j], acc[i][j]);
                 }
         }
     }
@@ -238,13 +238,11 @@ static inline hipError_t gemm3_launch_cfg(const Gemm3Operands& g, const Epi& epi
     static_assert(lds <= 160 * 1024, "LDS ring exceeds 160 KiB");
     dim3 grid(((g.N + BN - 1) / BN) * ((g.M + BM - 1) / BM), 1, Z);  // 1-D tile index, remapped per XCD in-kernel
     auto kern = gemm3_kernel<BM, BN, WM, WN, SPLIT, S, Epi>;
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        attr_done = true;
-    }
+    static DevOnce once;
+    hipError_t e = once.ensure([&] {
+        return hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    });
+    if (e != hipSuccess) return e;
     hipLaunchKernelGGL(kern, grid, dim3(WM * WN * 64), lds, st, g, epi);
     return hipGetLastError();
 }
@@ -323,6 +321,7 @@ static inline hipError_t gemm3_launch(const Gemm3Operands& g_in, const Epi& epi,
     extern int g_gemm3_nfast;
     Gemm3Operands g = g_in;
     g.nfast = g_gemm3_nfast && (long)g.M > (long)g.N;  // the bigger operand streams, the smaller stays in L2
-    if (split == 3) return gemm3_launch_split<3, Epi>(g, epi, Z, cfg, st);
+    if (split == PREC_BF16X3) return gemm3_launch_split<3, Epi>(g, epi, Z, cfg, st);
+    if (split == PREC_F16) return gemm3_launch_split<2, Epi>(g, epi, Z, cfg, st);
     return gemm3_launch_split<1, Epi>(g, epi, Z, cfg, st);
 }

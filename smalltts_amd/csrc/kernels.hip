@@ -343,22 +343,21 @@ hipError_t launch_synth(float* out, long n, uint64_t key, float mean, float half
 
 __global__ void split_rows_kernel(const float* __restrict__ src, long src_ld, bf16_t* __restrict__ hi,
                                   bf16_t* __restrict__ lo, long dst_ld, int rows, int cols,
-                                  const int* __restrict__ perm) {
+                                  const int* __restrict__ perm, bf16_t* __restrict__ h16) {
     long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (long)rows * cols) return;
     int r = (int)(i / cols), c = (int)(i % cols);
     int sr = perm ? perm[r] : r;
     float v = sr >= 0 ? src[(long)sr * src_ld + c] : 0.f;
-    bf16_t h = (bf16_t)v;
-    hi[(long)r * dst_ld + c] = h;
-    if (lo) lo[(long)r * dst_ld + c] = (bf16_t)(v - (float)h);
+    if (hi) store_act1(hi, lo, (long)r * dst_ld + c, v);
+    if (h16) store_act1(h16, SM_F16_TAG, (long)r * dst_ld + c, v);
 }
 hipError_t launch_split_rows(const float* src, long src_ld, bf16_t* hi, bf16_t* lo, long dst_ld, int rows, int cols,
-                             const int* perm, hipStream_t st) {
+                             const int* perm, hipStream_t st, bf16_t* h16) {
     long n = (long)rows * cols;
     if (n == 0) return hipSuccess;
     hipLaunchKernelGGL(split_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, src, src_ld, hi, lo, dst_ld,
-                       rows, cols, perm);
+                       rows, cols, perm, h16);
     LAUNCH_CHECK();
 }
 
@@ -494,7 +493,7 @@ hipError_t launch_dwconv_resid_rms(float* x, const float* n, const float* w, con
                                    int C, int K, int pad, float eps, const float* norm_w, bf16_t* yhi, bf16_t* ylo, RowMap ymap,
                                    hipStream_t st) {
     const int c4 = C / 4;
-    if (C % 4 || pad < K - 1 || K > 7 || c4 > 512 || !yhi || !ylo) return hipErrorInvalidValue;
+    if (C % 4 || pad < K - 1 || K > 7 || c4 > 512 || !yhi) return hipErrorInvalidValue;
     const long rows = (long)B * T;
     if (rows == 0) return hipSuccess;
     ProfScope ps(st, "dwconv_resid_rms", 2.0 * B * T * C * (K + 3), 16.0 * B * T * C);

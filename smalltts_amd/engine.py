@@ -17,7 +17,9 @@ from .weights import (DEFAULT_CODEC, CodecSpec, codec_decoder_param_specs, codec
 
 N_LAYERS, N_HEADS, HEAD_DIM, LATENT = 12, 8, 120, 64
 ACT = {"none": 0, "silu": 1, "gelu": 2, "mish": 3}
-PRECISION = {"bf16x3": 3, "bf16": 1}
+PRECISION = {"bf16x3": 3, "f16": 2, "bf16": 1}   # presets of smtts_set_precision (include/smalltts_hip.h)
+SITES = {"dit_block": 0, "encoder": 1, "cross_kv": 2, "cond": 3, "codec_ffn": 4, "codec_conv": 5}
+DEFAULT_PRECISION = "f16"
 
 
 def _p(t: Optional[torch.Tensor]):
@@ -25,7 +27,7 @@ def _p(t: Optional[torch.Tensor]):
 
 
 class HipEngine:
-    def __init__(self, device: int = 0, precision: str = "bf16x3"):
+    def __init__(self, device: int = 0, precision: str = DEFAULT_PRECISION):
         if not torch.cuda.is_available():
             raise RuntimeError("HipEngine needs a ROCm GPU (torch.cuda.is_available() is False)")
         self.lib = _lib.load()
@@ -87,8 +89,13 @@ class HipEngine:
         self._ck(self.lib.smtts_set_dual_stream(self.h, int(bool(on))), "set_dual_stream")
 
     def set_precision(self, precision: str):
+        """Preset ("f16" mixed / "bf16x3" / "bf16"), optionally followed by per-site overrides: "f16,codec_ffn=bf16x3"."""
+        preset, *over = precision.split(",")
         self.precision = precision
-        self._ck(self.lib.smtts_set_precision(self.h, PRECISION[precision]), "set_precision")
+        self._ck(self.lib.smtts_set_precision(self.h, PRECISION[preset]), "set_precision")
+        for o in over:
+            site, prec = o.split("=")
+            self._ck(self.lib.smtts_set_site_precision(self.h, SITES[site.strip()], PRECISION[prec.strip()]), "set_site_precision")
 
     # ---- weights -------------------------------------------------------------------------------
     def set_codec_spec(self, spec: CodecSpec):

@@ -11,7 +11,7 @@ from ..phonemes import get_token_ids, parse_tokens_arg
 def add_engine_args(ap: argparse.ArgumentParser) -> None:
     ap.add_argument("--weights", default=None, help="weight file | checkpoint .pt | synthetic:<seed>")
     ap.add_argument("--device", type=int, default=0)
-    ap.add_argument("--precision", default="bf16x3", choices=["bf16x3", "bf16"])
+    ap.add_argument("--precision", default="f16", help="f16 (mixed, default) | bf16x3 (fp32-class) | bf16, optionally with site overrides")
     ap.add_argument("--steps", type=int, default=4)
     ap.add_argument("--seed", type=int, default=None)
     ap.add_argument("--tokens", default=None, help="pre-tokenised phoneme ids (comma/space separated or JSON)")

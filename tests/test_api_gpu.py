@@ -29,7 +29,7 @@ def snr_db(got, ref):
 @pytest.fixture(scope="module")
 def eng():
     from smalltts_amd.engine import HipEngine
-    e = HipEngine(0)
+    e = HipEngine(0, "bf16x3")
     e.load_synthetic(SEED, parts=("dit", "decoder", "encoder"), codec_spec=SPEC)
     e.finalize()
     return e
@@ -185,3 +185,85 @@ def test_synthesize_batches_matches_a_loop_of_synthesize_batch(eng):
     assert len(a) == len(b) == 5
     for xa, xb in zip(a, b):
         assert len(xa) == len(xb) and all(np.array_equal(u, v) for u, v in zip(xa, xb))
+
+
+# ---- N1: converted weights on the GPU (distill.py:39-57, 468-479) ---------------------------------------------
+def _reference_inputs():
+    g = torch.Generator().manual_seed(21)
+    ref = torch.randn(5, 64, generator=g).numpy()
+    toks = [4, 9, 77, 120, 33]
+    noise = torch.randn(4, 1, 9, 64, generator=g).numpy()
+    return ref, toks, noise
+
+
+def test_weight_file_and_checkpoint_load_give_the_synthetic_engines_latents(eng, tmp_path):
+    """A `.smtts` flat file and a DMD-style checkpoint ({"student_model": state_dict} with module. / _orig_mod. wrapper
+    prefixes, DiT only) + a separately converted codec file, each loaded through SmallTTS(weights=...), must reproduce the
+    latents AND audio of the engine filled by load_synthetic bit for bit: same tensors in, same packs, same kernels."""
+    from smalltts_amd import api
+    from smalltts_amd.api import SmallTTS
+    from smalltts_amd.convert import convert_checkpoint
+    from smalltts_amd.weights import save_weight_file
+    ref, toks, noise = _reference_inputs()
+    want_a, want_l = SmallTTS(engine=eng).synthesize_batch([ref], [toks], [1.2], noise=noise, return_latents=True)
+
+    dit = synth_state_dict(dit_param_specs(), SEED)
+    codec = synth_state_dict(codec_decoder_param_specs(SPEC) + codec_encoder_param_specs(SPEC), SEED)
+    # (1) one flat file with everything
+    p_all = str(tmp_path / "all.smtts")
+    save_weight_file(p_all, {**dit, **codec}, SPEC)
+    # (2) training checkpoint: wrapped key names, non-tensor entries, DiT only -> converter -> flat DiT file; codec separately
+    ck = {"student_model": {("module._orig_mod." + k): torch.from_numpy(np.ascontiguousarray(v)) for k, v in dit.items()},
+          "step": 1234, "optimizer": {"lr": 1e-4}}
+    p_ck = str(tmp_path / "checkpoint_latest.pt")
+    torch.save(ck, p_ck)
+    p_codec = str(tmp_path / "codec.smtts")
+    save_weight_file(p_codec, codec, SPEC)
+    p_conv = str(tmp_path / "dit.smtts")
+    rep = convert_checkpoint(p_ck, p_conv)
+    assert rep.ok and rep["matched"] == len(dit)
+    del ck
+    try:
+        for weights in (p_all, f"{p_ck}+{p_codec}", [p_conv, p_codec]):
+            tts = SmallTTS(weights=weights, precision="bf16x3")
+            a, l = tts.synthesize_batch([ref], [toks], [1.2], noise=noise, return_latents=True)
+            assert np.array_equal(l[0], want_l[0]), f"latents differ for weights={weights!r}"
+            assert np.array_equal(a[0], want_a[0]), f"audio differs for weights={weights!r}"
+            api._ENGINES.clear()
+            del tts
+            torch.cuda.empty_cache()
+    finally:
+        api._ENGINES.clear()
+
+
+def test_wrong_shaped_checkpoint_is_a_clean_error_naming_the_tensor(tmp_path):
+    from smalltts_amd import api
+    from smalltts_amd.api import SmallTTS
+    from smalltts_amd.engine import HipEngine
+    from smalltts_amd.weights import save_weight_file
+    small = {"velocity.weight": np.zeros((64, 512), np.float32), "velocity.bias": np.zeros(64, np.float32)}
+    p = str(tmp_path / "other_model.smtts")
+    save_weight_file(p, small)
+    with pytest.raises(ValueError, match=r"velocity\.weight.*\(64, 512\).*\(64, 960\)"):
+        SmallTTS(weights=p)
+    api._ENGINES.clear()
+    # the C ABI refuses too (a caller that bypasses the Python check): finalize names the tensor and its shape
+    e = HipEngine(0)
+    e.load_synthetic(1, parts=("dit",))
+    e.set_tensor("dit.transformer_blocks.3.ff.w1.weight", np.zeros((1200, 960), np.float32))
+    with pytest.raises(RuntimeError, match=r"dit\.transformer_blocks\.3\.ff\.w1\.weight has shape \(1200, 960\).*\(2400, 960\)"):
+        e.finalize()
+    assert not e.has("dit")
+    # repairing the tensor and finalizing again works (packs are rebuilt, the old ones freed)
+    from smalltts_amd.weights import synth_tensor
+    e.set_tensor("dit.transformer_blocks.3.ff.w1.weight", synth_tensor("dit.transformer_blocks.3.ff.w1.weight", (2400, 960), 1))
+    e.finalize()
+    assert e.has("dit")
+    # a tensor set AFTER finalize invalidates the engine until the next finalize (no stale packs)
+    e.set_tensor("velocity.bias", np.ones(64, np.float32))
+    assert not e.has("dit")
+    with pytest.raises(RuntimeError, match="not finalized"):
+        e.cond_encode(np.zeros((1, 2, 64), np.float32), np.array([2]), np.array([[1, 2]]), np.ones((1, 2), bool))
+    e.finalize()
+    assert e.has("dit")
+    e.close()

@@ -53,3 +53,24 @@ def test_missing_library_fails_loudly(monkeypatch):
     monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/libsmalltts_hip.so")
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         _lib.load()
+
+
+def test_null_handle_is_an_error_not_a_crash():
+    """Every entry point that takes a handle returns an error code for NULL (size queries: 0) and leaves a message
+    for smtts_last_error(NULL); none of them touches HIP before the check, so this runs without a GPU."""
+    _need_lib()
+    lib = _lib.load()
+    skip = {"smtts_create", "smtts_destroy", "smtts_last_error", "smtts_version", "smtts_alpha_sigma"}
+    for name, (res, args) in _lib.SIGNATURES.items():
+        if name in skip:
+            continue
+        assert args and args[0] is _lib.vp, name
+        call = [None] + [(ctypes.c_float(0) if a is _lib.f32 else None if a in (_lib.vp, _lib.cstr) or hasattr(a, "contents")
+                          or a is ctypes.c_char_p else 0) for a in args[1:]]
+        rc = getattr(lib, name)(*call)
+        if res is _lib.sz or name in ("smtts_has_part", "smtts_codec_hop"):
+            assert rc == 0, name
+        else:
+            assert rc == 1, name
+        assert name.encode() in lib.smtts_last_error(None), name
+    assert lib.smtts_destroy(None) == 0   # like free(NULL)

@@ -30,7 +30,7 @@ SPECS = {
 def test_decode_and_encode_vs_oracle(name):
     from smalltts_amd.engine import HipEngine
     spec = SPECS[name]
-    eng = HipEngine(0)
+    eng = HipEngine(0, "bf16x3")
     eng.load_synthetic(3, parts=("decoder", "encoder"), codec_spec=spec)
     eng.finalize()
     assert eng.has("decoder") and eng.has("encoder") and eng.hop == spec.hop
@@ -58,7 +58,7 @@ def test_full_spec_decode_vs_oracle():
     """The real (VibeVoice-shaped, ~344 M parameter) decoder: 2 utterances x 4 frames."""
     from smalltts_amd.engine import HipEngine
     spec = DEFAULT_CODEC
-    eng = HipEngine(0)
+    eng = HipEngine(0, "bf16x3")
     eng.load_synthetic(9, parts=("decoder",), codec_spec=spec)
     eng.finalize()
     wd = to_torch(synth_state_dict(codec_decoder_param_specs(spec), 9))

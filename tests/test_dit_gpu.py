@@ -17,7 +17,7 @@ NORTH_STAR = 1e-3
 @pytest.fixture(scope="module")
 def eng(golden_seed):
     from smalltts_amd.engine import HipEngine
-    e = HipEngine(0)
+    e = HipEngine(0, "bf16x3")
     e.load_synthetic(golden_seed, parts=("dit",))
     e.finalize()
     assert e.has("dit")
@@ -167,3 +167,56 @@ def test_on_device_noise_is_seeded_and_reproducible(eng):
     b = eng.sample(cache, mask, seed=11).cpu()
     c = eng.sample(cache, mask, seed=12).cpu()
     assert torch.equal(a, b) and not torch.equal(a, c) and torch.isfinite(a).all()
+
+
+def test_teacher_128_steps_vs_oracle_every_step(eng, dit_weights):
+    """BASELINE config 5's sampler at its real length: 128 chained ODE + CFG steps (distill.py:60-134 ingredients)
+    against O.sample_teacher_ode, asserting the x0-hat of EVERY step so error growth along the chain is visible, not just
+    the end point.  Small rows (B = 2, N = 20: 6 x 20 CFG rows) keep the CPU side to seconds."""
+    gen = torch.Generator().manual_seed(51)
+    B, N, R, P, steps = 2, 20, 6, 9, 128
+    ref = torch.randn(B, R, 64, generator=gen)
+    ids = torch.randint(1, 198, (B, P), generator=gen)
+    pm = torch.ones(B, P, dtype=torch.bool); rl = torch.full((B,), R)
+    mask = torch.ones(B, N, dtype=torch.bool); mask[1, 15:] = False
+    noise = torch.randn(B, N, 64, generator=gen)
+    ref3, len3, ids3, pm3 = O.cfg_conditions(ref, rl, ids, pm)
+    keep = []
+    with torch.no_grad():
+        oc = O.encode_conditions(dit_weights, ref3, len3, ids3, pm3)
+        ox = O.sample_teacher_ode(dit_weights, oc, pm3, mask, noise, steps, keep=keep)
+    cache3 = eng.cond_encode(ref3, len3, ids3, pm3)
+    x, per_step = eng.sample(cache3, mask, num_steps=steps, mode="ode", cfg=True, noise=noise, return_steps=True)
+    m = mask.numpy()
+    errs = [rel_l2(per_step[i].cpu().numpy()[m], keep[i].numpy()[m]) for i in range(steps)]
+    print(f"\n[teacher 128] x0-hat rel L2 vs oracle: step 0 {errs[0]:.2e}, 31 {errs[31]:.2e}, 63 {errs[63]:.2e}, "
+          f"127 {errs[127]:.2e}, max {max(errs):.2e} at step {int(np.argmax(errs))}")
+    assert max(errs) < 5 * TOL, f"drift along the 128-step chain: max {max(errs):.3e} at step {int(np.argmax(errs))}"
+    assert rel_l2(x.cpu().numpy()[m], ox.numpy()[m]) < 5 * TOL
+
+
+def test_teacher_128_steps_at_bench_size_properties(eng):
+    """Config 5 at its full size (B = 8 x 10 s, 128 steps, CFG: 1800 rows per call) cannot be followed by the CPU oracle in
+    test time; size-independent properties instead: finite, bitwise repeatable, and every utterance equal to its own B = 1 run
+    (rows are independent; different M takes different tile shapes / split-K, hence a bound and not bit equality)."""
+    gen = torch.Generator().manual_seed(52)
+    B, N, R, P, steps = 8, 75, 15, 30, 128
+    ref = torch.randn(B, R, 64, generator=gen)
+    ids = torch.arange(1, P + 1)[None].repeat(B, 1)
+    pm = torch.ones(B, P, dtype=torch.bool); rl = torch.full((B,), R)
+    mask = torch.ones(B, N, dtype=torch.bool)
+    noise = torch.randn(B, N, 64, generator=gen)
+    ref3, len3, ids3, pm3 = O.cfg_conditions(ref, rl, ids, pm)
+
+    def run(sel):
+        r3, l3, i3, p3 = O.cfg_conditions(ref[sel], rl[sel], ids[sel], pm[sel])
+        c = eng.cond_encode(r3, l3, i3, p3)
+        return eng.sample(c, mask[sel], num_steps=steps, mode="ode", cfg=True, noise=noise[sel].contiguous()).cpu()
+
+    full = run(slice(0, B))
+    assert torch.isfinite(full).all() and float(full.abs().max()) > 0
+    assert torch.equal(run(slice(0, B)), full)
+    for b in (0, 5):
+        one = run(slice(b, b + 1))
+        err = rel_l2(full[b].numpy(), one[0].numpy())
+        assert err < 5 * TOL, f"utterance {b}: batch-of-8 vs single over 128 steps: {err:.3e}"

@@ -21,7 +21,7 @@ def snr_db(got, ref):
 @pytest.fixture(scope="module")
 def eng(golden_seed):
     from smalltts_amd.engine import HipEngine
-    e = HipEngine(0)
+    e = HipEngine(0, "bf16x3")
     e.load_synthetic(golden_seed, parts=("dit", "decoder", "encoder"))
     e.finalize()
     return e

@@ -28,6 +28,18 @@ def test_resampler_identity_length_and_tone():
     assert np.abs(audio.resample_hq(hi, 16000, 8000)[500:-500]).max() < 1e-3
 
 
+@pytest.mark.parametrize("sr,target", [(16000, 24000), (44100, 24000), (48000, 16000)])
+def test_host_resampler_matches_oracle(sr, target):
+    """The host resampler of the CLI path against the closed-form float64 oracle (oracle/resample_oracle.py)."""
+    from oracle.resample_oracle import resample as oracle_resample
+    rng = np.random.default_rng(sr)
+    x = (0.4 * np.sin(2 * np.pi * 523.25 * np.arange(int(0.1 * sr)) / sr) + 0.1 * rng.standard_normal(int(0.1 * sr))).astype(np.float32)
+    want = oracle_resample(x, sr, target)
+    got = audio.resample_hq(x, sr, target)
+    assert got.shape == want.shape
+    assert np.linalg.norm(got - want) / np.linalg.norm(want) < 3e-6
+
+
 def test_weight_file_roundtrip(tmp_path):
     spec = weights.CodecSpec(n_filters=8, ratios=(4, 2), dec_depths=(1, 1, 1))
     sd = weights.synth_state_dict(weights.codec_decoder_param_specs(spec)[:7] + [("style_encoder.log_scale", ())], 3)

@@ -11,7 +11,7 @@ pytestmark = pytest.mark.gpu
 @pytest.fixture(scope="module")
 def eng():
     from smalltts_amd.engine import HipEngine
-    return HipEngine(0)
+    return HipEngine(0, "bf16x3")
 
 
 def _rand(*shape, seed=0, scale=1.0):
@@ -214,18 +214,19 @@ def test_randn_matches_oracle_philox(eng):
 
 
 @pytest.mark.parametrize("sr,target", [(16000, 24000), (44100, 24000), (48000, 24000), (22050, 24000)])
-def test_device_resampler_matches_host_restatement(eng, sr, target):
-    """the device polyphase resampler against the numpy restatement of torchaudio's Resample."""
-    from smalltts_amd.audio import resample_hq
+def test_device_resampler_matches_oracle(eng, sr, target):
+    """the device polyphase resampler against oracle/resample_oracle.py (float64, closed form per sample pair:
+    no bank, no framing — nothing shared with the product's bank builder)."""
+    from oracle.resample_oracle import resample as oracle_resample
     rng = np.random.default_rng(sr)
-    t = np.arange(int(0.37 * sr)) / sr
+    t = np.arange(int(0.2 * sr)) / sr
     x = (0.5 * np.sin(2 * np.pi * 440 * t) + 0.05 * rng.standard_normal(t.size)).astype(np.float32)
-    want = resample_hq(x, sr, target)
+    want = oracle_resample(x, sr, target)
     got = eng.resample(x, sr, target).cpu().numpy()
     assert got.shape == want.shape
-    assert rel_l2(got, want) < 2e-6
+    assert rel_l2(got, want) < 3e-6
     two = eng.resample(np.stack([x, -x]), sr, target).cpu().numpy()
-    assert two.shape == (2, want.size) and rel_l2(two[1], -want) < 2e-6
+    assert two.shape == (2, want.size) and rel_l2(two[1], -want) < 3e-6
     assert torch.equal(eng.resample(x, target, target).cpu(), torch.from_numpy(x))
 
 

@@ -1,0 +1,181 @@
+"""GPU: the product's DEFAULT operand precision ("f16" mixed: one fp16 MFMA per product on the DiT-block / encoder /
+cross-KV / codec-FFN GEMMs, split-bf16 on the conditioning chain, the latent in / out projections and the codec
+resampling convs) against the fp32 CPU oracle, at the tolerances the north star states:
+
+  latents: rel-L2 < 1e-3 is the contract (BASELINE.json north_star); the tests assert 3e-4 (>= 3x margin);
+  audio:   SNR >= 60 dB is the bound this build states (codec parity is unpinned, oracle/codec_oracle.py); the codec tests
+           assert 64 dB here.
+
+The tight 1e-4 / 60 dB-vs-96 dB checks of the split-bf16 preset stay in test_dit_gpu.py / test_fullsize_gpu.py: they prove
+the kernels' logic; these prove the shipped configuration."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import codec_oracle as CO
+from oracle import dit_oracle as O
+from smalltts_amd.weights import DEFAULT_CODEC, codec_decoder_param_specs, codec_encoder_param_specs, synth_state_dict
+from tests.conftest import golden, rel_l2
+
+pytestmark = pytest.mark.gpu
+TOL_F16 = 3e-4     # >= 3x inside the 1e-3 contract
+SNR_F16 = 64.0     # dB, decode vs CPU oracle (bound stated by the build: 60 dB)
+
+
+def snr_db(got, ref):
+    got, ref = np.asarray(got, np.float64), np.asarray(ref, np.float64)
+    return 10 * np.log10((ref ** 2).sum() / max(((got - ref) ** 2).sum(), 1e-300))
+
+
+@pytest.fixture(scope="module")
+def eng(golden_seed):
+    from smalltts_amd.engine import DEFAULT_PRECISION, HipEngine
+    e = HipEngine(0)                       # default precision: what SmallTTS() and bench.py run
+    assert e.precision == DEFAULT_PRECISION == "f16"
+    e.load_synthetic(golden_seed, parts=("dit", "decoder", "encoder"))
+    e.finalize()
+    return e
+
+
+def _bench_inputs(B=8, N=75, R=15, P=30, seed=0):
+    gen = torch.Generator().manual_seed(seed)
+    ref = torch.randn(B, R, 64, generator=gen)
+    ids = torch.arange(1, P + 1)[None].repeat(B, 1)
+    noise = torch.randn(4, B, N, 64, generator=gen)
+    return ref, torch.full((B,), R), ids, torch.ones(B, P, dtype=torch.bool), torch.ones(B, N, dtype=torch.bool), noise
+
+
+@pytest.mark.parametrize("case", ["case_small.npz", "case_cfgrows.npz", "case_bench1.npz"])
+def test_default_precision_vs_reference_golden(eng, case):
+    """velocity of one denoiser call against fixtures made by the reference's own modules (tests/golden/make_golden.py)."""
+    g = golden(case)
+    cache = eng.cond_encode(g["ref"], g["ref_len"], g["ids"], g["ph_mask"])
+    v = eng.denoise_step(g["x_t"], g["mask"], g["t"], cache).cpu().numpy()
+    m = g["mask"].astype(bool)
+    err = rel_l2(v[m], g["velocity"][m])
+    assert err < TOL_F16, f"{case}: velocity rel L2 {err:.3e}"
+
+
+def test_default_precision_sampler_vs_reference_golden(eng):
+    g = golden("case_sampler4.npz")
+    B, N = g["noise"].shape[1:3]
+    P = g["ids"].shape[1]
+    cache = eng.cond_encode(g["ref"], np.array([g["ref"].shape[1]]), g["ids"], np.ones((B, P), bool))
+    x, steps = eng.sample(cache, np.ones((B, N), bool), num_steps=4, noise=g["noise"], return_steps=True)
+    for i in range(4):
+        err = rel_l2(steps[i].cpu().numpy(), g["x_pred_steps"][i])
+        assert err < TOL_F16, f"step {i}: {err:.3e}"
+
+
+def test_default_precision_at_bench_shape_and_site_ladder(eng, dit_weights):
+    """configs[1] of BASELINE.json (B=8 x 10 s, R=15, P=30, 4 DMD steps): the default against the oracle, then the ladder —
+    what each GEMM site group costs in latent error when it alone drops from split-bf16 to one fp16 pass, and what happens
+    when the sensitive conditioning / in / out sites are dropped too (printed: this is the evidence for the default's site map)."""
+    ref, ref_len, ids, pm, mask, noise = _bench_inputs()
+    with torch.no_grad():
+        oc = O.encode_conditions(dit_weights, ref, ref_len, ids, pm)
+        ox = O.sample_dmd(dit_weights, oc, pm, mask, noise, 4).numpy()
+
+    def run():
+        return eng.sample(eng.cond_encode(ref, ref_len, ids, pm), mask, num_steps=4, noise=noise).cpu().numpy()
+
+    err = rel_l2(run(), ox)
+    rows = [("f16 (default)", err)]
+    try:
+        for site in ("dit_block", "encoder", "cross_kv", "cond"):
+            eng.set_precision(f"bf16x3,{site}=f16")
+            rows.append((f"bf16x3 + {site}=f16", rel_l2(run(), ox)))
+        eng.set_precision("f16,cond=f16")
+        rows.append(("f16 everywhere incl. cond", rel_l2(run(), ox)))
+        eng.set_precision("bf16x3")
+        rows.append(("bf16x3", rel_l2(run(), ox)))
+        eng.set_precision("bf16")
+        rows.append(("bf16", rel_l2(run(), ox)))
+    finally:
+        eng.set_precision("f16")
+    print("\n[precision ladder] latent rel-L2 vs fp32 oracle, B=8 N=75 R=15 P=30, 4 steps")
+    for k, v in rows:
+        print(f"  {k:28s} {v:.3e}")
+    assert err < TOL_F16, f"default precision latent rel L2 {err:.3e}"
+    d = dict(rows)
+    assert d["bf16x3"] < 1e-4 and d["bf16x3 + dit_block=f16"] < TOL_F16
+
+
+def test_default_precision_range_edges(eng, dit_weights):
+    for (B, N, R, P) in [(2, 75, 38, 128), (1, 225, 64, 198), (1, 1, 1, 1)]:
+        g = torch.Generator().manual_seed(100 + N)
+        ref = torch.randn(B, R, 64, generator=g)
+        ids = torch.randint(1, 198, (B, P), generator=g)
+        rl = torch.full((B,), R)
+        pm = torch.ones(B, P, dtype=torch.bool)
+        mask = torch.ones(B, N, dtype=torch.bool)
+        if B > 1:
+            rl[-1] = max(1, R // 3); pm[-1, P // 2:] = False; ids[-1, P // 2:] = 0; mask[-1, (2 * N) // 3:] = False
+        noise = torch.randn(4, B, N, 64, generator=g)
+        with torch.no_grad():
+            ox = O.sample_dmd(dit_weights, O.encode_conditions(dit_weights, ref, rl, ids, pm), pm, mask, noise, 4)
+        x = eng.sample(eng.cond_encode(ref, rl, ids, pm), mask, noise=noise).cpu().numpy()
+        m = mask.numpy()
+        err = rel_l2(x[m], ox.numpy()[m])
+        assert err < TOL_F16, f"B={B} N={N} R={R} P={P}: latent rel L2 {err:.3e}"
+
+
+def test_default_precision_codec_decode_and_ladder(eng, golden_seed):
+    """The bench's codec workload (8 x 75 frames): two utterances against the CPU oracle at the default precision, plus the
+    ladder of the codec sites on one utterance."""
+    wd = O.to_torch(synth_state_dict(codec_decoder_param_specs(DEFAULT_CODEC), golden_seed))
+    lat = torch.randn(8, 75, 64, generator=torch.Generator().manual_seed(11))
+    got = eng.codec_decode(lat).cpu()
+    with torch.no_grad():
+        refs = {b: CO.decode(wd, lat[b:b + 1], DEFAULT_CODEC).numpy() for b in (0, 5)}
+    for b, r in refs.items():
+        s = snr_db(got[b:b + 1].numpy(), r)
+        assert s > SNR_F16, f"utterance {b}: decode SNR {s:.1f} dB at the default precision"
+    rows = []
+    try:
+        for p in ("f16", "f16,codec_conv=f16", "bf16x3,codec_ffn=f16", "bf16x3", "bf16"):
+            eng.set_precision(p)
+            rows.append((p, snr_db(eng.codec_decode(lat[:1]).cpu().numpy(), refs[0])))
+    finally:
+        eng.set_precision("f16")
+    print("\n[precision ladder] codec decode SNR vs fp32 oracle, 1 x 75 frames")
+    for k, v in rows:
+        print(f"  {k:28s} {v:.1f} dB")
+    # bitwise repeatable and batch-invariant at the default precision too
+    again = eng.codec_decode(lat).cpu()
+    assert torch.equal(again, got)
+
+
+def test_default_precision_codec_encode(eng, golden_seed):
+    we = O.to_torch(synth_state_dict(codec_encoder_param_specs(DEFAULT_CODEC), golden_seed))
+    t = torch.arange(48000) / 24000.0
+    audio = (0.5 * torch.sin(2 * np.pi * 440 * t))[None, None].repeat(2, 1, 1)
+    audio[1] += 0.05 * torch.randn(48000, generator=torch.Generator().manual_seed(3))
+    with torch.no_grad():
+        ref = CO.encode(we, audio, DEFAULT_CODEC).numpy()
+    got = eng.codec_encode(audio).cpu().numpy()
+    assert got.shape == ref.shape == (2, 15, 64)
+    err = rel_l2(got, ref)
+    assert err < 1e-3, f"encode latent rel L2 {err:.3e}"
+
+
+@pytest.mark.parametrize("M,N,K,cfg", [(600, 960, 960, -1), (600, 3840, 960, -1), (257, 130, 192, -1), (75, 64, 2432, 2),
+                                       (4800, 512, 2048, 5)])
+def test_gemm3_fp16_single_pass_vs_torch(eng, M, N, K, cfg):
+    """gemm3 with one fp16 array per operand: against torch on the SAME fp16-rounded operands (fp64 accumulate) the result is
+    exact up to fp32 accumulation order; against the unrounded product the error is the fp16 rounding (2^-11 relative)."""
+    g = torch.Generator().manual_seed(M + N)
+    A = torch.randn(M, K, generator=g)
+    W = torch.randn(N, K, generator=g) / K ** 0.5
+    bias = torch.randn(N, generator=g)
+    got = eng.test_gemm3(A, W, bias, split=2, cfg=cfg).cpu().double()
+    ref16 = A.half().double() @ W.half().double().t() + bias.double()
+    ref = A.double() @ W.double().t() + bias.double()
+    assert rel_l2(got.numpy(), ref16.numpy()) < 2e-6
+    assert rel_l2(got.numpy(), ref.numpy()) < 6e-4
+    # saturating conversion: finite for values beyond the fp16 range, subnormal inputs are not flushed
+    A2 = A.clone(); A2[0, :] = 1e6; A2[1, :] = 3e-7
+    got2 = eng.test_gemm3(A2, W, None, split=2, cfg=cfg).cpu().double()
+    assert torch.isfinite(got2).all()
+    r1 = (A2[1].half().double()[None] @ W.half().double().t())[0]
+    assert rel_l2(got2[1].numpy(), r1.numpy()) < 1e-5 and float(r1.abs().max()) > 0

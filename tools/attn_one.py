@@ -3,7 +3,7 @@
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from smalltts_amd.engine import HipEngine
-eng = HipEngine(0)
+eng = HipEngine(0, "bf16x3")
 B, N, H, dh, R, P = 8, 75, 8, 120, 15, 30
 g = torch.Generator().manual_seed(0)
 qkvg = torch.randn(B, N, 4 * H * dh, generator=g)

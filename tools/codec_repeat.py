@@ -2,7 +2,7 @@ import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from smalltts_amd.engine import HipEngine
 from smalltts_amd.weights import CodecSpec
-eng = HipEngine(0)
+eng = HipEngine(0, "bf16x3")
 eng.load_synthetic(1, parts=("decoder",)); eng.finalize()
 lat = torch.randn(1, 75, 64, generator=torch.Generator().manual_seed(4))
 a = eng.codec_decode(lat).cpu(); b = eng.codec_decode(lat).cpu()

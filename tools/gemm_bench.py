@@ -16,7 +16,7 @@ SHAPES = [  # name, M, N, K, epi
 
 
 def main():
-    eng = HipEngine(0)
+    eng = HipEngine(0, "bf16x3")
     cfgs = [int(c) for c in (sys.argv[1].split(",") if len(sys.argv) > 1 else ["-1"])]
     print(f"{'shape':16s} {'M':>7s} {'N':>5s} {'K':>5s} ver cfg split {'us':>9s} {'TF(alg)':>8s} {'GB/s(alg)':>9s}")
     for name, M, N, K, epi in SHAPES:
