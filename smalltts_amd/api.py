@@ -126,12 +126,26 @@ class SmallTTS:
                  codec_decoder_path: str = "assets/codec/decoder.onnx",
                  providers: Optional[Iterable[str]] = None, *, weights: Optional[str] = None, device: int = 0,
                  precision: str = DEFAULT_PRECISION, num_steps: int = NUM_STEPS, seed: Optional[int] = None,
-                 engine: Optional[HipEngine] = None) -> None:
+                 engine: Optional[HipEngine] = None, device_ids: Optional[Sequence[int]] = None) -> None:
+        """Keyword-only additions to the reference signature (infer/onnx.py:53-59): `weights`, `device`, `precision`,
+        `num_steps`, `seed`, and `device_ids` — the GPUs `synthesize_sharded` spreads a request list over from THIS process
+        (one weight replica, engine and host thread per GPU; under torch.distributed the process group is used instead)."""
+        if device_ids:
+            device = int(device_ids[0])
         self.engine = engine or get_engine(weights, device, precision, parts=("dit", "decoder", "encoder"))
         if not (self.engine.has("dit") and self.engine.has("decoder")):
             raise RuntimeError("SmallTTS needs DiT and codec-decoder weights")
         self.num_steps = int(num_steps)
+        self._seed = seed
         self._rng = np.random.default_rng(seed) if seed is not None else None
+        self._replicas: List["SmallTTS"] = [self]
+        for d in list(device_ids or [])[1:]:
+            # a repeated device id is its own replica (own engine + weights): the threads must not share an engine
+            eng = (HipEngine(int(d), precision) if int(d) in [r.engine.device_index for r in self._replicas]
+                   else get_engine(weights, int(d), precision, parts=("dit", "decoder", "encoder")))
+            if not eng.has("dit"):
+                _load_weights_into(eng, weights or DEFAULT_WEIGHTS, ("dit", "decoder", "encoder"))
+            self._replicas.append(SmallTTS(engine=eng, num_steps=num_steps, seed=seed))
 
     def _next_seed(self) -> int:
         # the reference draws noise from numpy's global RNG (infer/onnx.py:104); seeding numpy (or seed=)
@@ -175,7 +189,7 @@ class SmallTTS:
             return outs, [xl[b, : ns[b]] for b in range(B)]
         return outs
 
-    def synthesize_batches(self, batches: Sequence[tuple], in_flight: int = 3) -> List[list]:
+    def synthesize_batches(self, batches: Sequence[tuple], in_flight: int = 3, release_workspaces: bool = False) -> List[list]:
         """Several independent batches, `in_flight` of them overlapping on the GPU.
 
         batches: [(ref_latents, phoneme_ids, durations), ...] as for synthesize_batch.  Batch i runs whole on HIP stream
@@ -191,7 +205,8 @@ class SmallTTS:
         for st in streams:
             st.wait_stream(cur)
         pending = []
-        eng.set_dual_stream(False)   # the engine's own side stream would serialise the text encoders of all batches in flight
+        # the engine's own side stream would serialise the text encoders of all batches in flight; restore the caller's setting
+        prev_dual = eng.set_dual_stream(False)
         try:
             for i, (refs, toks, durs) in enumerate(batches):
                 with torch.cuda.stream(streams[i % len(streams)]):
@@ -199,14 +214,49 @@ class SmallTTS:
                     pending.append(self.synthesize_batch(refs, toks, durs, _defer=True))
         finally:
             eng.use_workspace(None)
-            eng.set_dual_stream(True)
+            eng.set_dual_stream(prev_dual)
         for st in streams:
             cur.wait_stream(st)
         outs = []
         for audio, _, ns in pending:
             a = audio.cpu().numpy()
             outs.append([a[b, :, : HOP_SIZE * ns[b]] for b in range(len(ns))])
+        if release_workspaces:
+            torch.cuda.synchronize(dev)
+            eng.release_workspaces()
         return outs
+
+    def synthesize_sharded(self, ref_latents: Sequence[np.ndarray], phoneme_ids: Sequence[Sequence[int]],
+                           duration_sec: float, *, max_batch: int = 8) -> np.ndarray:
+        """Data-parallel synthesis of a request list with a common duration -> (n, 1, samples) fp32 on the host.
+
+        * under torch.distributed (one process per GPU, e.g. `python -m torch.distributed.run --nproc-per-node 8`): every rank
+          passes the same list, synthesises its contiguous shard and receives the whole batch after ONE RCCL all-gather
+          (`smalltts_amd.parallel.ShardContext`; the configuration `bench.py --gpus N` measures);
+        * otherwise over `device_ids` from this process (one engine + one host thread per GPU, gathered on the host);
+        * with one GPU: plain batches of `max_batch`."""
+        from . import parallel
+        n = len(ref_latents)
+        S = _frames(duration_sec) * HOP_SIZE
+
+        def run_span(tts: "SmallTTS", lo: int, hi: int) -> list:
+            outs: list = []
+            with torch.cuda.device(tts.engine.device):
+                for s0 in range(lo, hi, max_batch):
+                    s1 = min(hi, s0 + max_batch)
+                    outs.extend(tts.synthesize_batch(list(ref_latents[s0:s1]), list(phoneme_ids[s0:s1]), duration_sec))
+            return outs
+
+        ctx = parallel.ShardContext.current()
+        if ctx.world > 1:
+            full = parallel.synthesize_sharded(lambda r, p, d: run_span(self, *ctx.my_shard(n)), ref_latents, phoneme_ids,
+                                               duration_sec, ctx=ctx)
+            return full.cpu().numpy()
+        if len(self._replicas) > 1:
+            outs = parallel.run_shards_in_threads([lambda lo, hi, t=t: run_span(t, lo, hi) for t in self._replicas], n)
+        else:
+            outs = run_span(self, 0, n)
+        return np.stack(outs) if outs else np.zeros((0, 1, S), np.float32)
 
     def synthesize(self, ref_latents: np.ndarray, phoneme_ids: list, duration_sec: float) -> np.ndarray:
         """ref_latents (T,64) f32, phoneme ids, duration -> audio (1, samples) f32 @ 24 kHz."""

@@ -287,25 +287,31 @@ static inline bool gemm3_ok(const Gemm3Operands& g) {
            (g.amap.bstride % 8) == 0;
 }
 
+// Ring depth per tile shape.  A single-array operand format (PREC_F16 / PREC_BF16) halves the bytes per stage, so the same
+// LDS budget holds twice the k-tiles in flight (G3_DEEP, default on; -DG3_DEEP=0 restores the split-bf16 depths for A/B).
+#ifndef G3_DEEP
+#define G3_DEEP 1
+#endif
 template <int SPLIT, class Epi>
 static inline hipError_t gemm3_launch_split(const Gemm3Operands& g, const Epi& epi, int Z, int cfg, hipStream_t st) {
+    constexpr bool D = G3_DEEP && SPLIT != 3;
     switch (cfg) {
         case G3_128x128:
-            return gemm3_launch_cfg<128, 128, 4, 2, SPLIT, 2, Epi>(g, epi, Z, st);
+            return gemm3_launch_cfg<128, 128, 4, 2, SPLIT, D ? 4 : 2, Epi>(g, epi, Z, st);
         case G3_64x128:
-            if constexpr (!Epi::PAIRED) return gemm3_launch_cfg<64, 128, 2, 4, SPLIT, 3, Epi>(g, epi, Z, st);
+            if constexpr (!Epi::PAIRED) return gemm3_launch_cfg<64, 128, 2, 4, SPLIT, D ? 6 : 3, Epi>(g, epi, Z, st);
             break;
         case G3_64x64:
-            if constexpr (!Epi::PAIRED) return gemm3_launch_cfg<64, 64, 2, 2, SPLIT, 2, Epi>(g, epi, Z, st);
+            if constexpr (!Epi::PAIRED) return gemm3_launch_cfg<64, 64, 2, 2, SPLIT, D ? 4 : 2, Epi>(g, epi, Z, st);
             break;
         case G3_128x64:
-            if constexpr (!Epi::PAIRED) return gemm3_launch_cfg<128, 64, 4, 2, SPLIT, 3, Epi>(g, epi, Z, st);
+            if constexpr (!Epi::PAIRED) return gemm3_launch_cfg<128, 64, 4, 2, SPLIT, D ? 6 : 3, Epi>(g, epi, Z, st);
             break;
         case G3_128x32:
-            if constexpr (!Epi::PAIRED) return gemm3_launch_cfg<128, 32, 4, 1, SPLIT, 2, Epi>(g, epi, Z, st);
+            if constexpr (!Epi::PAIRED) return gemm3_launch_cfg<128, 32, 4, 1, SPLIT, D ? 4 : 2, Epi>(g, epi, Z, st);
             break;
         case G3_160x128:
-            if constexpr (!Epi::PAIRED) return gemm3_launch_cfg<160, 128, 5, 2, SPLIT, 2, Epi>(g, epi, Z, st);
+            if constexpr (!Epi::PAIRED) return gemm3_launch_cfg<160, 128, 5, 2, SPLIT, D ? 4 : 2, Epi>(g, epi, Z, st);
             break;
     }
     return hipErrorInvalidValue;

@@ -229,10 +229,7 @@ __global__ void convpos_pack_kernel(const float* __restrict__ h, const uint8_t* 
     int t = tp - pad;
     float v = 0.f;
     if (t >= 0 && t < T && c < cpg && mask[b * T + t]) v = h[((long)b * T + t) * (G * cpg) + g * cpg + c];
-    bf16_t hh, ll;
-    split1(v, hh, ll);
-    gm_hi[i] = hh;
-    if (gm_lo) gm_lo[i] = ll;
+    store_act1(gm_hi, gm_lo, i, v);
 }
 hipError_t launch_convpos_pack(const float* h, const uint8_t* mask, bf16_t* gm_hi, bf16_t* gm_lo, int B, int T, int G,
                                int cpg, int pad, int gstride, hipStream_t st) {

@@ -84,9 +84,20 @@ class HipEngine:
             t = torch.from_numpy(t)
         return t.to(device=self.device, dtype=dtype).contiguous()
 
-    def set_dual_stream(self, on: bool):
-        """Text encoder of cond_encode on the engine's side stream (default) or inline on the caller's stream."""
+    def set_dual_stream(self, on: bool) -> bool:
+        """Text encoder of cond_encode on the engine's side stream (default unless SMTTS_SINGLE_STREAM=1) or inline on the
+        caller's stream.  Returns the previous setting so that callers can restore it."""
+        prev = getattr(self, "dual_stream", None)
+        if prev is None:
+            import os
+            prev = os.environ.get("SMTTS_SINGLE_STREAM", "") != "1"
         self._ck(self.lib.smtts_set_dual_stream(self.h, int(bool(on))), "set_dual_stream")
+        self.dual_stream = bool(on)
+        return prev
+
+    def release_workspaces(self):
+        """Drop the named per-stream scratch buffers (synthesize_batches / bench keep one per batch in flight)."""
+        self._ws_named.clear()
 
     def set_precision(self, precision: str):
         """Preset ("f16" mixed / "bf16x3" / "bf16"), optionally followed by per-site overrides: "f16,codec_ffn=bf16x3"."""

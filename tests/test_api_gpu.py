@@ -213,7 +213,7 @@ def test_weight_file_and_checkpoint_load_give_the_synthetic_engines_latents(eng,
     p_all = str(tmp_path / "all.smtts")
     save_weight_file(p_all, {**dit, **codec}, SPEC)
     # (2) training checkpoint: wrapped key names, non-tensor entries, DiT only -> converter -> flat DiT file; codec separately
-    ck = {"student_model": {("module._orig_mod." + k): torch.from_numpy(np.ascontiguousarray(v)) for k, v in dit.items()},
+    ck = {"student_model": {("module._orig_mod." + k): torch.tensor(v) for k, v in dit.items()},   # (0-d log_scale stays 0-d)
           "step": 1234, "optimizer": {"lr": 1e-4}}
     p_ck = str(tmp_path / "checkpoint_latest.pt")
     torch.save(ck, p_ck)

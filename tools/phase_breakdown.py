@@ -18,7 +18,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--workload", default="dmd4")
     ap.add_argument("--reps", type=int, default=5)
-    ap.add_argument("--precision", default="bf16x3")
+    ap.add_argument("--precision", default="f16")
     a = ap.parse_args()
     from smalltts_amd.engine import HipEngine
     torch.cuda.set_device(0)
