@@ -56,7 +56,9 @@ WORKLOADS = {
 }
 
 
-def one_step(eng, inp, seed, gather=None, workload="dmd4"):
+def one_step(eng, inp, seed, ctx=None, gather=None, workload="dmd4", pcm16=False):
+    """One pass of the hot path over this rank's batch of 8; with several ranks the waveform shards are reassembled by
+    smalltts_amd.parallel.ShardContext.gather_waveforms (ONE all-gather: RCCL over xGMI) inside the step."""
     if workload == "clone":      # reference bench.rs times the codec encode of the 2 s / 440 Hz sine in every call
         ref = eng.codec_encode(inp["ref_wav"])
         cache = eng.cond_encode(ref, inp["ref_len"], inp["ids"], inp["ph_mask"])
@@ -68,14 +70,24 @@ def one_step(eng, inp, seed, gather=None, workload="dmd4"):
         cache = eng.cond_encode(inp["ref"], inp["ref_len"], inp["ids"], inp["ph_mask"])
         x = eng.sample(cache, inp["mask"], num_steps=DMD_STEPS, seed=seed)
     audio = eng.codec_decode(x)
-    if gather is not None:
-        import torch.distributed as dist
-        if gather.is_cuda:
-            dist.all_gather_into_tensor(gather, audio)   # RCCL over xGMI: 7.68 MB per rank
-        else:                                            # gloo smoke path (CPU tensors)
-            dist.all_gather_into_tensor(gather, audio.cpu())
-        return gather
+    if ctx is not None and ctx.world > 1:
+        if pcm16:                # the CLIs write PCM_16 (tryme.py:29): gathering int16 halves the bytes on the links
+            audio = eng.pcm16(audio)
+        return ctx.gather_waveforms(audio, ctx.world * B, out=gather)
     return audio
+
+
+def kernel_source_hash():
+    """Hash of the kernel sources: profiles/*_latest files record the hash they were measured on, so a stale counter file
+    (kernels changed since the rocprofv3 passes) is detected instead of silently quoted."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "smalltts_amd", "csrc")
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".hip", ".hpp")):
+            with open(os.path.join(d, name), "rb") as f:
+                h.update(name.encode() + b"\0" + f.read())
+    return h.hexdigest()[:16]
 
 
 def cpu_baseline(cores):
@@ -112,11 +124,21 @@ def cpu_baseline(cores):
             "dit_seconds": round(t_dit, 3), "codec_decode_seconds_per_utt": round(t_dec1, 3)}
 
 
+# SURVEY 8(d) / BASELINE.md 4 algorithmic work per 8 x 10 s batch (R = 15, P = 30): flops counted once, bf16 weights read once
+# per use, activations negligible.  Codec: this build's CodecSpec: 13.5 GMAC per audio-second; bytes = weights
+# once (2 B / parameter) + one read and one write of every stage-boundary image.
+ALGO = {
+    "dit_sampler": {"flops": 695e9, "bytes": 1.722e9},
+    "cond_encoders": {"flops": 38e9, "bytes": 0.225e9},
+    "codec_decode": {"flops": 2.16e12, "bytes": None},   # bytes: measured sum of the kernels' algorithmic bytes (profiler)
+}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=300, help="timed steps (default sized so the timed region is >= 3 s)")
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--precision", default="f16",
                     help="f16 (default: one fp16 MFMA per product on the block / encoder / codec-FFN GEMMs, split-bf16 on the "
                          "conditioning and in / out projections), bf16x3 (split-bf16 everywhere), bf16; site overrides as f16,cond=f16")
@@ -126,41 +148,26 @@ def main():
                     help="independent batches in flight on one GPU: batch i runs, whole, on HIP stream i %% IN_FLIGHT with its own "
                          "workspace (default 3; 1 = one batch at a time on one stream)")
     ap.add_argument("--no-pipeline", dest="in_flight", action="store_const", const=1, help="same as --in-flight 1")
+    ap.add_argument("--gather", default="f32", choices=["f32", "pcm16"], help="dtype of the N > 1 waveform all-gather")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    dist = None
-    backend = os.environ.get("SMTTS_DIST_BACKEND", "nccl")   # "gloo": 2-rank smoke test on a 1-GPU box
-    local = local % max(1, torch.cuda.device_count()) if backend != "nccl" else local
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(local)
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-        else:
-            dist.init_process_group(backend)
-    n_gpus = world if world > 1 else 1
-    torch.cuda.set_device(local)
-    device = torch.device("cuda", local)
+    from smalltts_amd.parallel import ShardContext
+    ctx = ShardContext.from_env()          # one process per GPU (torch.distributed.run); single process when WORLD_SIZE <= 1
+    world, rank, device = ctx.world, ctx.rank, ctx.device
+    n_gpus = world
+    torch.cuda.set_device(ctx.device_index)
 
     from smalltts_amd.engine import HipEngine
-    eng = HipEngine(local, args.precision)
+    eng = HipEngine(ctx.device_index, args.precision)
     eng.load_synthetic(SEED, parts=("dit", "decoder", "encoder") if args.workload == "clone" else ("dit", "decoder"))
     eng.finalize()
     inp = make_inputs(device, rank)
-    gather = (torch.empty(world * B, 1, 3200 * N_FRAMES, device=device if backend == "nccl" else "cpu")
-              if world > 1 else None)
-
-    def barrier():
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
+    pcm16 = args.gather == "pcm16"
+    gdtype = torch.int16 if pcm16 else torch.float32
+    samples = 3200 * N_FRAMES
+    barrier = ctx.barrier
 
     def run_steps(n, seed0, in_flight):
         """n full passes of the hot path, each over its own batch of 8.  With in_flight > 1 consecutive batches are issued
@@ -170,48 +177,46 @@ def main():
         if in_flight <= 1:
             out = None
             for i in range(n):
-                out = one_step(eng, inp, seed0 + i, gather, args.workload)
+                out = one_step(eng, inp, seed0 + i, ctx, gathers[0] if gathers else None, args.workload, pcm16)
             return out
         cur = torch.cuda.current_stream(device)
         for s_ in streams[:in_flight]:
             s_.wait_stream(cur)
-        eng.set_dual_stream(False)   # the engine's single side stream would serialise the text encoders of all batches in flight
+        prev = eng.set_tuning("throughput")   # unsplit GEMMs, shallow DMA rings, no engine side stream: fewest CU-us per kernel
         out = None
-        for i in range(n):
-            with torch.cuda.stream(streams[i % in_flight]):
-                eng.use_workspace(f"batch{i % in_flight}")
-                out = one_step(eng, inp, seed0 + i, gathers[i % in_flight] if gather is not None else None, args.workload)
-        eng.use_workspace(None)
-        eng.set_dual_stream(True)
+        try:
+            for i in range(n):
+                with torch.cuda.stream(streams[i % in_flight]):
+                    eng.use_workspace(f"batch{i % in_flight}")
+                    out = one_step(eng, inp, seed0 + i, ctx, gathers[i % in_flight] if gathers else None, args.workload, pcm16)
+        finally:
+            eng.use_workspace(None)
+            eng.set_tuning(prev)
         for s_ in streams[:in_flight]:
             cur.wait_stream(s_)
         return out
 
     in_flight = max(1, args.in_flight)
     streams = [torch.cuda.Stream(device) for _ in range(in_flight)] if in_flight > 1 else []
-    gathers = [gather] + [torch.empty_like(gather) for _ in range(in_flight - 1)] if gather is not None else []  # one per slot
+    gathers = [ctx.gather_buffer(world * B, samples, gdtype) for _ in range(in_flight)] if world > 1 else []  # one per slot
     run_steps(args.warmup, 0, in_flight)
     barrier()
     t0 = time.perf_counter()
     out = run_steps(args.steps, 100, in_flight)
     barrier()
-    dt = time.perf_counter() - t0
-    seq_ms = None
-    if in_flight > 1:   # also report one-batch-at-a-time latency (not the metric)
-        ns = max(3, min(args.steps, 10))
-        run_steps(1, 50, 1)
-        barrier()
-        t1 = time.perf_counter()
-        run_steps(ns, 60, 1)
-        barrier()
-        seq_ms = 1e3 * (time.perf_counter() - t1) / ns
-    if dist is not None:
-        tmax = torch.tensor([dt], device=device if backend == "nccl" else "cpu", dtype=torch.float64)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
-    assert torch.isfinite(out).all()
+    dt = ctx.max_over_ranks(time.perf_counter() - t0)
+    # the same K steps one batch at a time on one stream: the latency of a batch, and the strict reading of "at batch = 8"
+    ns = max(3, min(args.steps, 100))
+    run_steps(2, 50, 1)
+    barrier()
+    t1 = time.perf_counter()
+    run_steps(ns, 60, 1)
+    barrier()
+    dt_seq = ctx.max_over_ranks(time.perf_counter() - t1)
+    assert torch.isfinite(out.float()).all()
 
     audio_s = n_gpus * B * AUDIO_SEC_PER_UTT * args.steps
+    audio_s_seq = n_gpus * B * AUDIO_SEC_PER_UTT * ns
     res = {
         "metric": "audio-seconds/sec (RTF) at batch=8, 10 s utterances; 1->8 GPU scaling",
         "value": round(audio_s / dt, 2), "unit": "audio-seconds/sec", "n_gpus": n_gpus, "steps": args.steps,
@@ -223,71 +228,93 @@ def main():
                   "bf16": "bf16 MFMA single pass, fp32 accumulate/residual"}.get(args.precision, args.precision),
         "data": "synthetic (seeded inputs + seeded random weights; no released weights offline)",
         "rtf": round(dt / audio_s, 7),
+        # one batch of 8 at a time on one stream (no batches in flight): the strict reading of the metric's "at batch = 8"
+        "value_sequential": round(audio_s_seq / dt_seq, 2), "sequential_ms_per_step": round(1e3 * dt_seq / ns, 3),
+        "rtf_sequential": round(dt_seq / audio_s_seq, 7), "timed_seconds": round(dt, 3),
         "config": {"workload": WORKLOADS[args.workload] + ", B=8 x 10 s per GPU "
                                "(N=75 frames, R=15 ref frames, P=30 tokens; reference bench.rs workload)",
                    "global_batch": n_gpus * B, "utterance_seconds": AUDIO_SEC_PER_UTT, "sampler_steps": 128 if args.workload == "teacher128" else DMD_STEPS,
-                   "parallelism": f"dp{n_gpus} (utterance shards, waveform all-gather)" if n_gpus > 1 else "single GPU",
-                   "batches_in_flight": in_flight},
+                   "parallelism": (f"dp{n_gpus}: one process per GPU, 8-utterance shard each, one {args.gather} waveform all-gather "
+                                   f"({ctx.backend})") if n_gpus > 1 else "single GPU",
+                   "batches_in_flight": in_flight, "precision": args.precision},
     }
-    if seq_ms is not None:
-        res["sequential_ms_per_step"] = round(seq_ms, 3)   # one batch at a time on one stream (latency of a batch)
 
     if rank == 0 and not args.no_roofline:
         # per-kernel HIP-event timing on the launch stream, separate (untimed) passes
         eng.profile(True, tagged=True)   # names come back as "<phase>/<kernel>" (enc, mod, dit, dec.s<i>, cenc.s<i>)
         reps = min(args.steps, 5)   # same workload as the timed region, events on the launch stream
         for i in range(reps):
-            one_step(eng, inp, 900 + i, None, args.workload)
+            one_step(eng, inp, 900 + i, None, None, args.workload)
         torch.cuda.synchronize()
         tagged = eng.profile_report()
         eng.profile(False)
         merged, phases = {}, {}
         for r in tagged:
             ph, _, kname = r["name"].partition("/") if "/" in r["name"] else ("-", "", r["name"])
-            k = merged.setdefault(kname, {"name": kname, "ms": 0.0, "launches": 0, "flops": 0.0, "bytes": 0.0})
+            k = merged.setdefault(kname, {"name": kname, "ms": 0.0, "launches": 0, "flops": 0.0, "bytes": 0.0, "bytes8d": 0.0})
             group = "dit_sampler" if ph in ("dit", "mod") else "cond_encoders" if ph == "enc" else \
                     "codec_encode" if ph.startswith("cenc") else "codec_decode"   # untagged: head conv / stem of the decoder
-            g_ = phases.setdefault(group, {"ms": 0.0, "flops": 0.0, "bytes": 0.0})
+            g_ = phases.setdefault(group, {"ms": 0.0, "flops": 0.0, "bytes": 0.0, "bytes8d": 0.0})
             for d_ in (k, g_):
-                d_["ms"] += r["ms"]; d_["flops"] += r["flops"]; d_["bytes"] += r["bytes"]
+                d_["ms"] += r["ms"]; d_["flops"] += r["flops"]; d_["bytes"] += r["bytes"]; d_["bytes8d"] += r.get("bytes8d", r["bytes"])
             k["launches"] += r["launches"]
         rows = list(merged.values())
-        # DiT and codec roofline fractions separately.  Algorithmic flops (counted once, not x3 for the split) and
-        # algorithmic bytes of the phase's kernels / the sum of their HIP-event times per batch.
-        res["phase_roofline"] = {
-            g: {"ms_per_step": round(v["ms"] / reps, 3), "TFLOPs": round(v["flops"] / max(v["ms"], 1e-9) / 1e9, 2),
-                "GBs": round(v["bytes"] / max(v["ms"], 1e-9) / 1e6, 1),
-                "mfma_frac": round(v["flops"] / max(v["ms"], 1e-9) / 1e9 / MFMA_BF16_PEAK_TF, 5),
-                "hbm_frac": round(v["bytes"] / max(v["ms"], 1e-9) / 1e6 / HBM_PEAK_GBS, 5)}
-            for g, v in sorted(phases.items(), key=lambda kv: -kv[1]["ms"])}
+        # DiT and codec roofline fractions separately.  "8d" = the survey's own accounting (ALGO above: flops once,
+        # bf16 weights once, activations negligible) over the sum of the phase's kernel times; "as_run" = the operand bytes the
+        # kernels are given in this precision (fp16 = 2 B, split-bf16 = 4 B per element, split-K partials included).
+        pr = {}
+        for g, v in sorted(phases.items(), key=lambda kv: -kv[1]["ms"]):
+            ms = v["ms"] / reps
+            a = ALGO.get(g, {})
+            fl8 = a.get("flops") if args.workload == "dmd4" and a.get("flops") else v["flops"] / reps
+            by8 = a.get("bytes") if args.workload == "dmd4" and a.get("bytes") else v["bytes8d"] / reps
+            pr[g] = {"ms_per_step": round(ms, 3),
+                     "8d": {"TFLOPs": round(fl8 / ms / 1e9, 2), "GBs": round(by8 / ms / 1e6, 1),
+                            "mfma_frac": round(fl8 / ms / 1e9 / MFMA_BF16_PEAK_TF, 5), "hbm_frac": round(by8 / ms / 1e6 / HBM_PEAK_GBS, 5)},
+                     "as_run": {"TFLOPs": round(v["flops"] / reps / ms / 1e9, 2), "GBs": round(v["bytes"] / reps / ms / 1e6, 1),
+                                "hbm_frac": round(v["bytes"] / reps / ms / 1e6 / HBM_PEAK_GBS, 5)}}
+        res["phase_roofline"] = pr
         rows.sort(key=lambda r: -r["ms"])
         tot = sum(r["ms"] for r in rows)
         top = rows[0]
         per = top["ms"] / top["launches"] * 1e-3
         tf = top["flops"] / top["launches"] / per / 1e12
-        gbs = top["bytes"] / top["launches"] / per / 1e9
-        mfma_frac, hbm_frac = tf / MFMA_BF16_PEAK_TF, gbs / HBM_PEAK_GBS
+        gbs8 = top["bytes8d"] / top["launches"] / per / 1e9
+        gbs_run = top["bytes"] / top["launches"] / per / 1e9
+        mfma_frac, hbm_frac = tf / MFMA_BF16_PEAK_TF, gbs8 / HBM_PEAK_GBS
         bound = "mfma" if mfma_frac >= hbm_frac else "hbm"
         res["roofline"] = {
             "kernel": top["name"], "bound": bound,
-            "achieved": round(tf if bound == "mfma" else gbs, 3),
+            "achieved": round(tf if bound == "mfma" else gbs8, 3),
             "peak": MFMA_BF16_PEAK_TF if bound == "mfma" else HBM_PEAK_GBS,
             "unit": "TFLOP/s" if bound == "mfma" else "GB/s",
             "frac": round(max(mfma_frac, hbm_frac), 5), "traffic": None,
             "avg_launch_us": round(per * 1e6, 3), "launches_per_step": top["launches"] // reps,
             "share_of_kernel_time": round(top["ms"] / tot, 4),
-            "note": "algorithmic flops (2MNK, counted once, not x3 for the split) and bytes per launch / HIP-event time",
+            "flops_per_launch": round(top["flops"] / top["launches"]), "bytes8d_per_launch": round(top["bytes8d"] / top["launches"]),
+            "as_run_bytes_per_launch": round(top["bytes"] / top["launches"]), "as_run_GBs": round(gbs_run, 1),
+            "mfma_frac": round(mfma_frac, 5), "hbm_frac": round(hbm_frac, 5),
+            "note": "SURVEY 8(d) accounting: algorithmic flops (2MNK, counted once) and weight bytes at 2 B / parameter read once, "
+                    "per launch / HIP-event time on the launch stream; as_run_* = the operand + output bytes the launch is given",
         }
-        # HBM bytes per launch of that kernel from the PMC passes of tools/profile_round.sh (committed under profiles/)
+        # HBM bytes per launch of that kernel from the PMC passes of tools/profile_round.sh (committed under profiles/); only
+        # quoted when the file was measured on THESE kernel sources (hash stamp), otherwise null + the reason
+        ksha = kernel_source_hash()
+        res["roofline"]["kernel_src_sha"] = ksha
         tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
         if os.path.exists(tpath):
             with open(tpath) as f:
-                tk = json.load(f).get("by_prof_name", {})
-            if top["name"] in tk:
-                res["roofline"]["traffic"] = tk[top["name"]]
-        # rocprofv3 average of the same kernel class from the committed summary (the HIP-event pair adds ~1.5 us per launch)
+                tj = json.load(f)
+            if tj.get("kernel_src_sha") == ksha:
+                res["roofline"]["traffic"] = tj.get("by_prof_name", {}).get(top["name"])
+                res["roofline"]["traffic_source"] = "profiles/traffic_latest.json (" + str(tj.get("tag", "")) + ")"
+            else:
+                res["roofline"]["traffic_source"] = ("stale: profiles/traffic_latest.json was measured on kernel sources "
+                                                     + str(tj.get("kernel_src_sha")) + ", not quoted")
+        # rocprofv3 average of the same kernel class from the committed summary (the HIP-event pair adds ~1.5-3 us per launch)
         spath = os.path.join(ROOT, "profiles", "kernel_stats_latest.csv")
-        if os.path.exists(spath):
+        mpath = os.path.join(ROOT, "profiles", "kernel_stats_latest.meta.json")
+        if os.path.exists(spath) and os.path.exists(mpath) and json.load(open(mpath)).get("kernel_src_sha") == ksha:
             import csv
             sys.path.insert(0, os.path.join(ROOT, "tools"))
             from prof_names import prof_name
@@ -301,19 +328,30 @@ def main():
                 res["roofline"]["rocprof_avg_us"] = round(us / calls, 3)
         res["kernel_breakdown"] = [
             {"name": r["name"], "launches_per_step": r["launches"] // reps, "ms_per_step": round(r["ms"] / reps, 4),
-             "TFLOPs": round(r["flops"] / max(r["ms"], 1e-9) / 1e9, 2), "GBs": round(r["bytes"] / max(r["ms"], 1e-9) / 1e6, 1)}
-            for r in rows[:12]]
+             "TFLOPs": round(r["flops"] / max(r["ms"], 1e-9) / 1e9, 2), "GBs_8d": round(r["bytes8d"] / max(r["ms"], 1e-9) / 1e6, 1),
+             "GBs_as_run": round(r["bytes"] / max(r["ms"], 1e-9) / 1e6, 1)}
+            for r in rows[:16]]
     if rank == 0 and n_gpus == 1 and not args.no_cpu_baseline and args.workload == "dmd4":
         try:
             avail = len(os.sched_getaffinity(0))
         except Exception:
             avail = os.cpu_count() or 1
-        res["cpu_baseline"] = cpu_baseline(min(avail, 16))  # small-op torch graphs thrash beyond ~16 threads
+        # all host cores, count stated.  Graphs of small torch ops stop scaling (and can regress) well before a
+        # big host's core count, so when more than 16 cores are available the 16-thread figure is timed too and the faster is
+        # `value`; both are reported.
+        full = cpu_baseline(avail)
+        full["cores_available"] = avail
+        if avail > 16:
+            cap = cpu_baseline(16)
+            full["all_cores"] = {"value": full["value"], "cores": avail}
+            full["capped_16"] = {"value": cap["value"], "cores": 16}
+            if cap["value"] > full["value"]:
+                keep = {k: full[k] for k in ("cores_available", "all_cores", "capped_16")}
+                full = dict(cap, **keep)
+        res["cpu_baseline"] = full
     if rank == 0:
         print(json.dumps(res))
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    ctx.close()
 
 
 if __name__ == "__main__":

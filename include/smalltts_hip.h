@@ -123,6 +123,11 @@ int smtts_pcm16(smtts_handle h, void* stream, const float* x, int64_t n, int16_t
  * for one batch at a time).  Callers that keep several batches in flight on their own streams should turn it off: the single
  * side stream would serialise the text encoders of all of them (16.2 -> 15.7 ms per batch at three in flight). */
 int smtts_set_dual_stream(smtts_handle h, int on);
+/* Tuning mode: 0 = latency (default: one batch at a time finishes as early as possible: split-K on the small-M projections, deep
+ * DMA rings, text encoder on the side stream), 1 = throughput (the caller keeps several independent batches in flight on its own
+ * streams: unsplit GEMMs, shallow rings, no side stream, so that kernels cost the fewest CU-microseconds and leave LDS for the
+ * other streams).  Results differ between the modes only by fp32 summation order. */
+int smtts_set_tuning(smtts_handle h, int mode);
 
 /* per-kernel HIP-event timing on the launch stream (bench.py roofline): enable, run, then read a JSON array
  * [{"name","launches","ms","flops","bytes"}] of algorithmic work and measured time per kernel class */

@@ -45,6 +45,7 @@ SIGNATURES: Dict[str, Tuple[object, List[object]]] = {
     "smtts_encode_workspace_bytes": (sz, [vp, i32, i32]),
     "smtts_codec_encode": (i32, [vp, vp, vp, i32, i32, vp, vp, sz]),
     "smtts_set_dual_stream": (i32, [vp, i32]),
+    "smtts_set_tuning": (i32, [vp, i32]),
     "smtts_randn": (i32, [vp, vp, vp, i64, u64, u64]),
     "smtts_resample_poly": (i32, [vp, vp, vp, i32, i64, vp, i32, i32, i32, i32, vp, i64]),
     "smtts_pcm16": (i32, [vp, vp, vp, i64, vp]),

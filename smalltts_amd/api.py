@@ -205,8 +205,9 @@ class SmallTTS:
         for st in streams:
             st.wait_stream(cur)
         pending = []
-        # the engine's own side stream would serialise the text encoders of all batches in flight; restore the caller's setting
-        prev_dual = eng.set_dual_stream(False)
+        # throughput tuning: unsplit GEMMs, shallow rings, no engine side stream (it would serialise the text encoders of all
+        # batches in flight); the caller's mode is restored afterwards
+        prev_tuning = eng.set_tuning("throughput")
         try:
             for i, (refs, toks, durs) in enumerate(batches):
                 with torch.cuda.stream(streams[i % len(streams)]):
@@ -214,7 +215,7 @@ class SmallTTS:
                     pending.append(self.synthesize_batch(refs, toks, durs, _defer=True))
         finally:
             eng.use_workspace(None)
-            eng.set_dual_stream(prev_dual)
+            eng.set_tuning(prev_tuning)
         for st in streams:
             cur.wait_stream(st)
         outs = []

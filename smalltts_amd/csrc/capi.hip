@@ -134,6 +134,11 @@ int smtts_pcm16(smtts_handle h, void* stream, const float* x, int64_t n, int16_t
     return e == hipSuccess ? 0 : E.fail_hip(e, "pcm16");
 }
 int smtts_set_dual_stream(smtts_handle h, int on) { NULLCHK; E.set_dual_stream(on != 0); return 0; }
+int smtts_set_tuning(smtts_handle h, int mode) { NULLCHK;
+    if (mode != 0 && mode != 1) return E.fail("tuning mode must be 0 (latency) or 1 (throughput)");
+    E.set_tuning(mode);
+    return 0;
+}
 int smtts_profile_enable(smtts_handle h, int on) { NULLCHK; E.profile_enable(on); return 0; }
 int smtts_profile_report(smtts_handle h, char* buf, size_t cap) { NULLCHK;
     std::string r = E.profile_report();

@@ -28,18 +28,34 @@ inline std::string sidx(const std::string& a, int i, const std::string& b) { ret
 }  // namespace
 
 int g_gemm3_t160 = 1;   // gemm3 160x128 tiles for M = 600 x wide N (SMTTS_GEMM_T160=0: off)
+int g_gemm3_deep = 1;   // gemm3 ring depth for single-array operand formats: 1 = deep (latency tuning), 0 = shallow (throughput tuning)
 int g_gemm3_nfast = 1;  // gemm3 tile order: N fastest when M > N (SMTTS_GEMM_NFAST=0 restores M fastest everywhere)
 thread_local Profiler* g_prof = nullptr;
 thread_local const char* g_prof_tag = nullptr;
 
 Engine::Engine(int device) : device_(device) {
     if (const char* nf = getenv("SMTTS_GEMM_NFAST")) g_gemm3_nfast = atoi(nf);
+    if (const char* dp = getenv("SMTTS_GEMM_DEEP")) g_gemm3_deep = atoi(dp);
     if (const char* t1 = getenv("SMTTS_GEMM_T160")) g_gemm3_t160 = atoi(t1);
     const char* s = getenv("SMTTS_SINGLE_STREAM");
     if (s && *s == '1') dual_stream_ = false;
     if ((s = getenv("SMTTS_KSPLIT_OUT")) && atoi(s) >= 1 && atoi(s) <= kSplitK) ksplit_out_ = atoi(s);
     if ((s = getenv("SMTTS_KSPLIT_ENC")) && atoi(s) >= 1 && atoi(s) <= kSplitK) ksplit_enc_ = atoi(s);
     if ((s = getenv("SMTTS_KSPLIT_FF2")) && atoi(s) >= 1 && atoi(s) <= kSplitK) ksplit_ff2_ = atoi(s);
+}
+
+void Engine::set_tuning(int mode) {
+    extern int g_gemm3_deep;
+    if (mode == TUNE_THROUGHPUT) {
+        if (tuning_ != TUNE_THROUGHPUT) dual_stream_latency_ = dual_stream_;
+        tuning_ = TUNE_THROUGHPUT;
+        dual_stream_ = false;
+        g_gemm3_deep = 0;
+    } else {
+        if (tuning_ == TUNE_THROUGHPUT) dual_stream_ = dual_stream_latency_;
+        tuning_ = TUNE_LATENCY;
+        g_gemm3_deep = getenv("SMTTS_GEMM_DEEP") ? atoi(getenv("SMTTS_GEMM_DEEP")) : 1;
+    }
 }
 
 void Engine::profile_enable(int mode) {
@@ -58,8 +74,8 @@ std::string Engine::profile_report() {
     bool first = true;
     char buf[512];
     for (auto& kv : agg) {
-        snprintf(buf, sizeof buf, "%s{\"name\": \"%s\", \"launches\": %ld, \"ms\": %.6f, \"flops\": %.6e, \"bytes\": %.6e}",
-                 first ? "" : ", ", kv.first.c_str(), kv.second.launches, kv.second.ms, kv.second.flops, kv.second.bytes);
+        snprintf(buf, sizeof buf, "%s{\"name\": \"%s\", \"launches\": %ld, \"ms\": %.6f, \"flops\": %.6e, \"bytes\": %.6e, \"bytes8d\": %.6e}",
+                 first ? "" : ", ", kv.first.c_str(), kv.second.launches, kv.second.ms, kv.second.flops, kv.second.bytes, kv.second.bytes8d);
         out += buf;
         first = false;
     }
@@ -916,7 +932,10 @@ int Engine::denoise_core(hipStream_t st, const float* x_t, const uint8_t* mask, 
                             mod_row0, mod_rstride, N, st));
     // split-K exists to fill the chip at M = 600 (150 tiles of 64x64 for N = 960); the 3B-row CFG batches of the teacher
     // sampler (M = 1800: 435 tiles) fill it without, and the fused epilogue is cheaper than partials + reduce (495 -> 454 ms)
-    const int ks_out = M > 1024 ? 1 : ksplit_out_, ks_ff2 = M > 1024 ? 1 : ksplit_ff2_;
+    // ... and so do several batches in flight (throughput tuning): there the unsplit GEMM + a separate AdaLN costs 2.3x fewer
+    // workgroup-microseconds than three K slices + reduce, and that is what counts when other streams want the CUs
+    const bool unsplit = M > 1024 || tuning_ == TUNE_THROUGHPUT;
+    const int ks_out = unsplit ? 1 : ksplit_out_, ks_ff2 = unsplit ? 1 : ksplit_ff2_;
     for (int l = 0; l < kBlocks; ++l) {
         const DitBlockW& b = blocks_[l];
         const float* m = mod + (long)l * kModPerBlock;

@@ -112,6 +112,13 @@ class Engine {
         prec_[site] = prec;
         return 0;
     }
+    // Tuning mode.  TUNE_LATENCY (default): one batch at a time should finish as early as possible — split-K on the small-M
+    // projections, deep DMA rings, text encoder on the side stream.  TUNE_THROUGHPUT: several independent batches are in flight
+    // on the caller's streams (SmallTTS.synthesize_batches, bench.py) — kernels should cost the fewest CU-microseconds and hold
+    // the least LDS so that other streams' kernels fit beside them: no split-K, shallow rings, no side stream.
+    enum { TUNE_LATENCY = 0, TUNE_THROUGHPUT = 1 };
+    void set_tuning(int mode);
+    int tuning() const { return tuning_; }
     void set_fused_ffn(bool on) { fused_ffn_ = on; }
     void set_attn_mfma(bool on) { attn_mfma_ = on; }
     void set_dual_stream(bool on) { dual_stream_ = on; }
@@ -194,6 +201,8 @@ class Engine {
     std::vector<void*> allocs_;       // raw fp32 tensors (live as long as the engine)
     std::vector<void*> pack_allocs_;  // everything finalize() builds: freed and rebuilt by the next finalize()
     bool packing_ = false;
+    int tuning_ = TUNE_LATENCY;
+    bool dual_stream_latency_ = true;  // the dual-stream setting that TUNE_LATENCY restores
     int preset_ = PREC_BF16X3;
     int prec_[SITE_COUNT] = {3, 3, 3, 3, 3, 3};
     bool fused_ffn_ = true;  // test hook: smtts_test_set_fused_ffn

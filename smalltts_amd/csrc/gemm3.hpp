@@ -287,31 +287,50 @@ static inline bool gemm3_ok(const Gemm3Operands& g) {
            (g.amap.bstride % 8) == 0;
 }
 
-// Ring depth per tile shape.  A single-array operand format (PREC_F16 / PREC_BF16) halves the bytes per stage, so the same
-// LDS budget holds twice the k-tiles in flight (G3_DEEP, default on; -DG3_DEEP=0 restores the split-bf16 depths for A/B).
-#ifndef G3_DEEP
-#define G3_DEEP 1
-#endif
+// Ring depth per tile shape.  A single-array operand format (PREC_F16 / PREC_BF16) halves the bytes per stage, so the same LDS
+// budget can hold twice the k-tiles in flight.  Measured (profiles/r02b_ab_ring_depth.txt, f16, M = 600): deep rings cut one
+// batch's latency (QKVG 25.4 -> 21.5 us, SwiGLU 22.7 -> 19.4, 64x64 16.0 -> 14.5; 14.8 -> 14.2 ms per batch one at a time)
+// but cost throughput with several batches in flight (10.1 -> 10.4 ms per batch): a workgroup that holds 128 KiB of LDS while
+// it waits on memory keeps the other streams' kernels off its CU.  Hence a run-time choice: g_gemm3_deep (Engine tuning mode).
 template <int SPLIT, class Epi>
 static inline hipError_t gemm3_launch_split(const Gemm3Operands& g, const Epi& epi, int Z, int cfg, hipStream_t st) {
-    constexpr bool D = G3_DEEP && SPLIT != 3;
+    extern int g_gemm3_deep;
+    if constexpr (SPLIT != 3) {
+        if (g_gemm3_deep) {
+            switch (cfg) {
+                case G3_128x128:
+                    return gemm3_launch_cfg<128, 128, 4, 2, SPLIT, 4, Epi>(g, epi, Z, st);
+                case G3_64x128:
+                    if constexpr (!Epi::PAIRED) return gemm3_launch_cfg<64, 128, 2, 4, SPLIT, 6, Epi>(g, epi, Z, st);
+                    break;
+                case G3_64x64:
+                    if constexpr (!Epi::PAIRED) return gemm3_launch_cfg<64, 64, 2, 2, SPLIT, 4, Epi>(g, epi, Z, st);
+                    break;
+                case G3_160x128:
+                    if constexpr (!Epi::PAIRED) return gemm3_launch_cfg<160, 128, 5, 2, SPLIT, 4, Epi>(g, epi, Z, st);
+                    break;
+                default:
+                    break;  // the tall 128x64 / 128x32 shapes (codec, M >= 2048) keep their depth: many rounds, never latency-bound
+            }
+        }
+    }
     switch (cfg) {
         case G3_128x128:
-            return gemm3_launch_cfg<128, 128, 4, 2, SPLIT, D ? 4 : 2, Epi>(g, epi, Z, st);
+            return gemm3_launch_cfg<128, 128, 4, 2, SPLIT, 2, Epi>(g, epi, Z, st);
         case G3_64x128:
-            if constexpr (!Epi::PAIRED) return gemm3_launch_cfg<64, 128, 2, 4, SPLIT, D ? 6 : 3, Epi>(g, epi, Z, st);
+            if constexpr (!Epi::PAIRED) return gemm3_launch_cfg<64, 128, 2, 4, SPLIT, 3, Epi>(g, epi, Z, st);
             break;
         case G3_64x64:
-            if constexpr (!Epi::PAIRED) return gemm3_launch_cfg<64, 64, 2, 2, SPLIT, D ? 4 : 2, Epi>(g, epi, Z, st);
+            if constexpr (!Epi::PAIRED) return gemm3_launch_cfg<64, 64, 2, 2, SPLIT, 2, Epi>(g, epi, Z, st);
             break;
         case G3_128x64:
-            if constexpr (!Epi::PAIRED) return gemm3_launch_cfg<128, 64, 4, 2, SPLIT, D ? 6 : 3, Epi>(g, epi, Z, st);
+            if constexpr (!Epi::PAIRED) return gemm3_launch_cfg<128, 64, 4, 2, SPLIT, 3, Epi>(g, epi, Z, st);
             break;
         case G3_128x32:
-            if constexpr (!Epi::PAIRED) return gemm3_launch_cfg<128, 32, 4, 1, SPLIT, D ? 4 : 2, Epi>(g, epi, Z, st);
+            if constexpr (!Epi::PAIRED) return gemm3_launch_cfg<128, 32, 4, 1, SPLIT, 2, Epi>(g, epi, Z, st);
             break;
         case G3_160x128:
-            if constexpr (!Epi::PAIRED) return gemm3_launch_cfg<160, 128, 5, 2, SPLIT, D ? 4 : 2, Epi>(g, epi, Z, st);
+            if constexpr (!Epi::PAIRED) return gemm3_launch_cfg<160, 128, 5, 2, SPLIT, 2, Epi>(g, epi, Z, st);
             break;
     }
     return hipErrorInvalidValue;

@@ -1,16 +1,16 @@
 #include "gemm_ops.hpp"
 #include "prof.hpp"
 hipError_t gemm3_swiglu(const Gemm3Operands& g, const EpiSwiGLU& p, int split, hipStream_t st) {
-    ProfScope ps(st, gemm3_prof_name(g, true, G3_128x128, split, "swiglu"), gemm3_flops(g, 1), gemm3_bytes(g, 1, split, 2.0));
+    ProfScope ps(st, gemm3_prof_name(g, true, G3_128x128, split, "swiglu"), gemm3_flops(g, 1), gemm3_bytes(g, 1, split, 2.0), gemm_bytes8d(g.N, g.K, (g.ksplit_tiles ? 1 : 1)));
     return gemm3_launch(g, p, 1, split, st, G3_128x128);
 }
 hipError_t gemm3_kv(const Gemm3Operands& g, const EpiKV& p, int split, hipStream_t st) {
-    ProfScope ps(st, gemm3_prof_name(g, false, -1, split, "kv_scatter"), gemm3_flops(g, 1), gemm3_bytes(g, 1, split, 4.0));
+    ProfScope ps(st, gemm3_prof_name(g, false, -1, split, "kv_scatter"), gemm3_flops(g, 1), gemm3_bytes(g, 1, split, 4.0), gemm_bytes8d(g.N, g.K, (g.ksplit_tiles ? 1 : 1)));
     return gemm3_launch(g, p, 1, split, st, -1);
 }
 hipError_t gemm3_convpos(const Gemm3Operands& g, bool final, const EpiConvPos<0>& p, int Z, int split, hipStream_t st) {
     ProfScope ps(st, gemm3_prof_name(g, false, G3_64x64, split, final ? "convpos_final" : "convpos"), gemm3_flops(g, Z),
-                 gemm3_bytes(g, Z, split, 4.0, true));
+                 gemm3_bytes(g, Z, split, 4.0, true), gemm_bytes8d(g.N, g.K, (g.ksplit_tiles ? 1 : Z), true));
     if (final) {
         EpiConvPos<1> q{p.out, p.h, p.bias, p.mask, p.G, p.cpg, p.T, p.pad, p.gstride, nullptr, nullptr};
         return gemm3_launch(g, q, Z, split, st, G3_64x64);

@@ -6,7 +6,7 @@ static EpiResid<G> conv(const EpiResid<0>& p) {
 }
 hipError_t gemm3_resid(const Gemm3Operands& g, int gate_mode, const EpiResid<0>& p, int split, hipStream_t st, int cfg) {
     static const char* names[] = {"resid", "resid_gate", "resid_layerscale"};
-    ProfScope ps(st, gemm3_prof_name(g, false, cfg, split, names[gate_mode % 3]), gemm3_flops(g, 1), gemm3_bytes(g, 1, split, 8.0));
+    ProfScope ps(st, gemm3_prof_name(g, false, cfg, split, names[gate_mode % 3]), gemm3_flops(g, 1), gemm3_bytes(g, 1, split, 8.0), gemm_bytes8d(g.N, g.K, (g.ksplit_tiles ? 1 : 1)));
     switch (gate_mode) {
         case 0: return gemm3_launch(g, p, 1, split, st, cfg);
         case 1: return gemm3_launch(g, conv<1>(p), 1, split, st, cfg);

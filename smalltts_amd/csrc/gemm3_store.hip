@@ -6,7 +6,7 @@ static EpiStore<ACT> conv(const EpiStore<ACT_NONE>& p) {
 }
 hipError_t gemm3_store(const Gemm3Operands& g, int act, const EpiStore<ACT_NONE>& p, int Z, int split, hipStream_t st, int cfg) {
     static const char* names[] = {"store", "store_silu", "store_gelu", "store_mish"};
-    ProfScope ps(st, gemm3_prof_name(g, false, cfg, split, names[act & 3]), gemm3_flops(g, Z), gemm3_bytes(g, Z, split, 4.0));
+    ProfScope ps(st, gemm3_prof_name(g, false, cfg, split, names[act & 3]), gemm3_flops(g, Z), gemm3_bytes(g, Z, split, 4.0), gemm_bytes8d(g.N, g.K, (g.ksplit_tiles ? 1 : Z)));
     switch (act) {
         case ACT_NONE: return gemm3_launch(g, p, Z, split, st, cfg);
         case ACT_SILU: return gemm3_launch(g, conv<ACT_SILU>(p), Z, split, st, cfg);

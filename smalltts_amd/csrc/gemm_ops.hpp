@@ -46,6 +46,8 @@ static inline double gemm3_bytes(const Gemm3Operands& g, int Z, int split, doubl
         return (double)g.M * g.K * e + (double)g.N * g.K * e + Z * (double)g.M * g.N * c_bytes_per_out;
     return Z * ((double)g.M * g.K * e + (double)g.M * g.N * c_bytes_per_out) + (double)g.N * g.K * e * (w_shared ? 1 : Z);
 }
+// SURVEY 8(d) bytes of a GEMM launch: the weights once at 2 B / parameter ("bf16 weights read once per use, activations negligible")
+static inline double gemm_bytes8d(int N, int K, int Z, bool w_shared = false) { return (double)N * K * 2.0 * (w_shared ? 1 : Z); }
 hipError_t gemm3_store(const Gemm3Operands& g, int act, const EpiStore<ACT_NONE>& p, int Z, int split, hipStream_t st, int cfg = -1);
 hipError_t gemm3_swiglu(const Gemm3Operands& g, const EpiSwiGLU& p, int split, hipStream_t st);
 hipError_t gemm3_resid(const Gemm3Operands& g, int gate_mode, const EpiResid<0>& p, int split, hipStream_t st, int cfg = -1);

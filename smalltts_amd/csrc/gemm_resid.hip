@@ -7,7 +7,7 @@ static EpiResid<G> conv(const EpiResid<0>& p) {
 hipError_t gemm_resid(const GemmOperands& g, int gate_mode, const EpiResid<0>& p, int split, hipStream_t st, int cfg) {
     static const char* names[] = {"resid", "resid_tanhgate", "resid_layerscale"};
     ProfScope ps(st, gemm_prof_name(g, false, cfg, split, names[gate_mode % 3]), gemm_flops(g, 1),
-                 gemm_bytes(g, 1, split, 2.0));
+                 gemm_bytes(g, 1, split, 2.0), gemm_bytes8d(g.N, g.K, 1));
     switch (gate_mode) {
         case 0: return gemm_launch(g, p, 1, split, st, cfg);
         case 1: return gemm_launch(g, conv<1>(p), 1, split, st, cfg);

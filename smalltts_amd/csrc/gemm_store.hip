@@ -7,7 +7,7 @@ static EpiStore<ACT> conv(const EpiStore<ACT_NONE>& p) {
 hipError_t gemm_store(const GemmOperands& g, int act, const EpiStore<ACT_NONE>& p, int Z, int split, hipStream_t st, int cfg) {
     static const char* names[] = {"store", "store_silu", "store_gelu", "store_mish"};
     ProfScope ps(st, gemm_prof_name(g, false, cfg, split, names[act & 3]), gemm_flops(g, Z),
-                 gemm_bytes(g, Z, split, 1.0));
+                 gemm_bytes(g, Z, split, 1.0), gemm_bytes8d(g.N, g.K, Z));
     switch (act) {
         case ACT_NONE: return gemm_launch(g, p, Z, split, st, cfg);
         case ACT_SILU: return gemm_launch(g, conv<ACT_SILU>(p), Z, split, st, cfg);

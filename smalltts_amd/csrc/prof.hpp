@@ -12,15 +12,16 @@ extern thread_local const char* g_prof_tag;
 struct ProfAgg {
     long launches = 0;
     double ms = 0, flops = 0, bytes = 0;
+    double bytes8d = 0;  // SURVEY 8(d) accounting: GEMMs = their weights once at 2 B / parameter (activations "negligible"), other kernels = bytes
 };
 
 class Profiler {
   public:
     ~Profiler() { reset(); }
-    void begin(hipStream_t st, const std::string& name, double flops, double bytes) {
+    void begin(hipStream_t st, const std::string& name, double flops, double bytes, double bytes8d) {
         Rec r;
         r.name = (g_prof_tag && *g_prof_tag) ? std::string(g_prof_tag) + "/" + name : name;
-        r.flops = flops; r.bytes = bytes;
+        r.flops = flops; r.bytes = bytes; r.bytes8d = bytes8d < 0 ? bytes : bytes8d;
         (void)hipEventCreate(&r.a);
         (void)hipEventCreate(&r.b);
         (void)hipEventRecord(r.a, st);
@@ -36,7 +37,7 @@ class Profiler {
             float ms = 0.f;
             if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) {
                 ProfAgg& a = out[r.name];
-                a.launches++; a.ms += ms; a.flops += r.flops; a.bytes += r.bytes;
+                a.launches++; a.ms += ms; a.flops += r.flops; a.bytes += r.bytes; a.bytes8d += r.bytes8d;
             }
         }
         return out;
@@ -47,7 +48,7 @@ class Profiler {
     }
 
   private:
-    struct Rec { std::string name; double flops, bytes; hipEvent_t a, b; };
+    struct Rec { std::string name; double flops, bytes, bytes8d; hipEvent_t a, b; };
     std::vector<Rec> recs_;
 };
 
@@ -62,11 +63,11 @@ struct ProfTag {  // scoped phase label ("enc", "dit", "dec.s3" ...); no effect 
 struct ProfScope {
     hipStream_t st;
     bool on;
-    ProfScope(hipStream_t s, const char* name, double flops, double bytes) : st(s), on(g_prof != nullptr) {
-        if (on) g_prof->begin(st, name, flops, bytes);
+    ProfScope(hipStream_t s, const char* name, double flops, double bytes, double bytes8d = -1.0) : st(s), on(g_prof != nullptr) {
+        if (on) g_prof->begin(st, name, flops, bytes, bytes8d);
     }
-    ProfScope(hipStream_t s, const std::string& name, double flops, double bytes) : st(s), on(g_prof != nullptr) {
-        if (on) g_prof->begin(st, name, flops, bytes);
+    ProfScope(hipStream_t s, const std::string& name, double flops, double bytes, double bytes8d = -1.0) : st(s), on(g_prof != nullptr) {
+        if (on) g_prof->begin(st, name, flops, bytes, bytes8d);
     }
     ~ProfScope() { if (on) g_prof->end(st); }
 };

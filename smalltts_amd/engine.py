@@ -95,6 +95,13 @@ class HipEngine:
         self.dual_stream = bool(on)
         return prev
 
+    def set_tuning(self, mode: str) -> str:
+        """"latency" (default) or "throughput" (several batches in flight on the caller's streams); returns the previous mode."""
+        prev = getattr(self, "tuning", "latency")
+        self._ck(self.lib.smtts_set_tuning(self.h, {"latency": 0, "throughput": 1}[mode]), "set_tuning")
+        self.tuning = mode
+        return prev
+
     def release_workspaces(self):
         """Drop the named per-stream scratch buffers (synthesize_batches / bench keep one per batch in flight)."""
         self._ws_named.clear()
@@ -122,7 +129,7 @@ class HipEngine:
             on_dev = t.is_cuda
             ptr, shape = t.data_ptr(), tuple(t.shape)
         else:
-            t = np.ascontiguousarray(arr, dtype=np.float32)
+            t = np.asarray(arr, dtype=np.float32, order="C")   # (ascontiguousarray would turn a 0-d scalar into shape (1,))
             on_dev, ptr, shape = False, t.ctypes.data, t.shape
         sh = (C.c_int64 * max(1, len(shape)))(*shape)
         self._ck(self.lib.smtts_set_tensor(self.h, name.encode(), C.c_void_p(ptr), sh, len(shape), int(on_dev)),
