@@ -32,6 +32,11 @@ def shard_sizes(n_items: int, world: int) -> List[int]:
     return [shard_range(n_items, world, r)[1] - shard_range(n_items, world, r)[0] for r in range(world)]
 
 
+def _wire(t: torch.Tensor) -> torch.Tensor:
+    """int16 PCM travels as bytes: neither RCCL / NCCL nor gloo has a 16-bit integer type."""
+    return t.view(torch.uint8) if t.dtype == torch.int16 else t
+
+
 def all_gather_waveforms(local: torch.Tensor, n_total: int, group=None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """local: (n_local, 1, S) on this rank (fp32 audio or int16 PCM) -> (n_total, 1, S) on every rank, rows in global
     utterance order.  Equal shards: one all_gather_into_tensor straight into `out` (pre-allocated by steady-state callers);
@@ -48,12 +53,12 @@ def all_gather_waveforms(local: torch.Tensor, n_total: int, group=None, out: Opt
         if out is None:
             out = local.new_empty((world * mx, 1, S))
         assert out.shape == (world * mx, 1, S) and out.dtype == local.dtype and out.device == local.device
-        dist.all_gather_into_tensor(out, local.contiguous(), group=group)
+        dist.all_gather_into_tensor(_wire(out), _wire(local.contiguous()), group=group)
         return out
     pad = local.new_zeros((mx, 1, S))
     pad[: local.shape[0]] = local
     buf = local.new_empty((world * mx, 1, S))
-    dist.all_gather_into_tensor(buf, pad, group=group)
+    dist.all_gather_into_tensor(_wire(buf), _wire(pad), group=group)
     return torch.cat([buf[r * mx: r * mx + sizes[r]] for r in range(world)], 0)
 
 

@@ -1,0 +1,56 @@
+"""GPU: bench.py itself — the JSON contract of the driver's command lines, at N = 1 and at N = 2 (two ranks share the box's
+single GPU over gloo, SMTTS_DIST_BACKEND=gloo: same ShardContext code path as the 8-GPU RCCL job, host-side collective)."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+KEYS = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+        "dtype", "data", "config", "value_sequential"}
+
+
+def _last_json(out):
+    return json.loads([l for l in out.splitlines() if l.startswith("{")][-1])
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def test_bench_single_gpu_line_has_the_contract_fields_and_rooflines():
+    p = subprocess.run([sys.executable, "bench.py", "--steps", "6", "--warmup", "2"], capture_output=True, text=True, timeout=900,
+                       cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-2000:]
+    r = _last_json(p.stdout)
+    assert KEYS <= set(r) and r["n_gpus"] == 1 and r["steps"] == 6 and r["warmup"] == 2 and r["scaling"] == "weak"
+    assert r["unit"] == "audio-seconds/sec" and r["value"] > 100 and r["value_sequential"] > 100 and r["vs_baseline"] is None
+    assert abs(r["value"] - 80.0 / (r["ms_per_step"] * 1e-3)) / r["value"] < 1e-3        # 8 x 10 s per step
+    assert r["config"]["workload"].startswith("cond-encode + 4-step DMD sampler + codec decode") and "model" not in r["config"]
+    rf = r["roofline"]
+    assert rf["bound"] in ("hbm", "mfma") and 0 < rf["frac"] < 1 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-4
+    assert rf["unit"] in ("GB/s", "TFLOP/s") and "traffic" in rf and len(rf["kernel_src_sha"]) == 16
+    for ph in ("dit_sampler", "cond_encoders", "codec_decode"):
+        assert r["phase_roofline"][ph]["ms_per_step"] > 0 and 0 < r["phase_roofline"][ph]["8d"]["mfma_frac"] < 1
+    cb = r["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["value"] > 0 and cb["cores"] >= 1 and cb["cores_available"] >= cb["cores"] and cb["sample"]
+
+
+@pytest.mark.parametrize("gather", ["f32", "pcm16"])
+def test_bench_two_ranks_over_gloo_on_one_gpu(gather):
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), "bench.py", "--gpus", "2", "--steps", "4", "--warmup", "1", "--gather", gather]
+    env = dict(os.environ, SMTTS_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=1200, cwd=ROOT, env=env)
+    assert p.returncode == 0, p.stderr[-3000:]
+    r = _last_json(p.stdout)
+    assert KEYS <= set(r) and r["n_gpus"] == 2 and r["config"]["global_batch"] == 16 and r["scaling"] == "weak"
+    assert abs(r["value"] - 160.0 / (r["ms_per_step"] * 1e-3)) / r["value"] < 1e-3       # both ranks' 8 x 10 s count
+    assert "gloo" in r["config"]["parallelism"] and gather in r["config"]["parallelism"]
+    assert "cpu_baseline" not in r                                                       # rank 0 at N = 1 only

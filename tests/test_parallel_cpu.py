@@ -69,3 +69,24 @@ def test_two_ranks_reassemble_single_process_result(n):
     want = np.stack(_fake_synth(refs, ids, 0.4))
     for r in range(2):
         assert got[r].shape == want.shape and np.array_equal(got[r], want)
+
+
+@pytest.mark.parametrize("mode", ["f32", "pcm16"])
+def test_torchrun_two_ranks_walk_the_bench_protocol(mode):
+    """The driver's N > 1 command line (python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
+    --master-port P <script>) with world 2 over gloo: rendezvous from the environment, barriers, the steady-state gather into a
+    pre-allocated buffer (fp32 and int16 PCM), MAX-over-ranks timing and the ragged library path — ShardContext is the single
+    implementation bench.py and SmallTTS.synthesize_sharded use."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(root, "tests", "helpers", "shard_worker.py"), mode]
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env, cwd=root)
+    assert p.returncode == 0, p.stderr[-2000:]
+    line = [l for l in p.stdout.splitlines() if l.startswith("{")][-1]
+    res = json.loads(line)
+    assert res["ok"] and res["world"] == 2 and res["backend"] == "gloo"
+    assert res["max_s"] >= 0.01   # rank 1 reported 10 ms more than rank 0: the MAX over ranks was taken

@@ -28,7 +28,7 @@ def load(path, counter):
     return agg
 
 
-def main(fetch_csv, write_csv, out):
+def main(fetch_csv, write_csv, out, sha=None, tag=None):
     fe, wr = load(fetch_csv, "FETCH_SIZE"), load(write_csv, "WRITE_SIZE")
     res = {}
     for k in sorted(set(fe) | set(wr)):
@@ -51,12 +51,12 @@ def main(fetch_csv, write_csv, out):
             by[n][1] += v["launches"]
     by_prof = {n: round(b / c) for n, (b, c) in by.items() if c}
     with open(out, "w") as fo:
-        json.dump({"note": "per launch; read side doubled per the gfx950 FETCH_SIZE correction", "kernels": res,
-                   "by_prof_name": by_prof}, fo, indent=1)
+        json.dump({"note": "per launch; read side doubled per the gfx950 FETCH_SIZE correction", "kernel_src_sha": sha, "tag": tag,
+                   "kernels": res, "by_prof_name": by_prof}, fo, indent=1)
     top = sorted(res.items(), key=lambda kv: -kv[1]["hbm_bytes_per_launch"] * kv[1]["launches"])[:8]
     for k, v in top:
         print(f"{v['hbm_bytes_per_launch'] / 1e6:10.1f} MB/launch x{v['launches']:4d}  {k[:110]}")
 
 
 if __name__ == "__main__":
-    main(*sys.argv[1:4])
+    main(*sys.argv[1:6])
