@@ -156,14 +156,16 @@ class SmallTTS:
 
     def synthesize_batch(self, ref_latents: Sequence[np.ndarray], phoneme_ids: Sequence[Sequence[int]],
                          durations, *, noise: Optional[np.ndarray] = None, return_latents: bool = False,
-                         _defer: bool = False):
-        """Batched synthesize: per-utterance (R_i,64) refs, token lists and durations -> list of (1, samples)."""
+                         frames: Optional[Sequence[int]] = None, _defer: bool = False):
+        """Batched synthesize: per-utterance (R_i,64) refs, token lists and durations -> list of (1, samples).
+        `frames` overrides the per-utterance frame counts (default floor(duration * 7.5), infer/onnx.py:84; the HTTP server
+        rounds up like the reference's Rust server, pipeline.rs:66)."""
         B = len(ref_latents)
         if B == 0:
             return []
         if np.isscalar(durations):
             durations = [float(durations)] * B
-        ns = [_frames(d) for d in durations]
+        ns = [int(f) for f in frames] if frames is not None else [_frames(d) for d in durations]
         rs = [int(np.asarray(r).shape[0]) for r in ref_latents]
         ps = [len(p) for p in phoneme_ids]
         Rm, Pm, Nm = max(max(rs), 1), max(max(ps), 1), max(ns)
@@ -195,7 +197,7 @@ class SmallTTS:
         batches: [(ref_latents, phoneme_ids, durations), ...] as for synthesize_batch.  Batch i runs whole on HIP stream
         i % in_flight with its own workspace, so one batch's latency-bound phases (condition encoders, DiT) fill the
         CUs another batch's kernels leave idle (bench.py: 16 ms per 8 x 10 s batch against 20 ms one at a time).
-        Results are identical to calling synthesize_batch in a loop with the same seeds."""
+        The engine runs in throughput tuning meanwhile; results equal a loop of synthesize_batch under that tuning bit for bit."""
         eng = self.engine
         if in_flight <= 1 or len(batches) <= 1:
             return [self.synthesize_batch(*b) for b in batches]

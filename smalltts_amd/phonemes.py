@@ -2,7 +2,8 @@
 
 The id space is the reference's (src/smalltts/data/phonemization/phonemes.py:10-55): 197 symbols
 -> ids 1..197, id 0 = padding, `phoneme_len` = 198; non-verbal `[event]` tags expand to
-NV_REPEAT copies of the event id (:39,77-89).  Phonemisation itself needs espeak through the
+NV_REPEAT copies of the event id (:39,77-89).  Text is first normalised like the reference does (numbers, currency, abbreviations spelled out:
+`normalizer.py`).  Phonemisation itself needs espeak through the
 `phonemizer` package (pinned 3.3.0 by the reference's uv.lock), which is not available offline;
 when it is missing, pass token ids directly (CLI `--tokens`) or use backend="chars", a clearly
 non-reference grapheme fallback for smoke runs.
@@ -42,6 +43,18 @@ def event_id(label: str) -> Optional[int]:
     return p2idx[f"[{label}]"] if label in EVENTS else None
 
 
+_normalizer = None
+
+
+def normalize_text(text: str) -> str:
+    """Abbreviation / number expansion the reference applies before espeak (phonemes.py:67-70 -> normalizer.py)."""
+    global _normalizer
+    if _normalizer is None:
+        from .normalizer import EnglishTextNormalizer
+        _normalizer = EnglishTextNormalizer()
+    return _normalizer.normalize(text)
+
+
 def _espeak_phonemize(text: str) -> str:
     global _espeak
     if _espeak is None:
@@ -64,6 +77,7 @@ def get_token_ids(text: str, backend: str = "espeak") -> List[int]:
             if eid is not None:
                 out += [eid] * NV_REPEAT
         elif part.strip():
+            part = normalize_text(part)              # reference _phonemize: normalise, then phonemise
             s = _espeak_phonemize(part) if backend == "espeak" else part
             out += [p2idx[c] for c in s if c in p2idx]
     return out

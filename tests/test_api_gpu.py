@@ -128,6 +128,19 @@ def test_clone_cli_end_to_end(tmp_path):
     assert rate == 24000 and a.shape == (3200 * 7,) and np.isfinite(a).all()
 
 
+def test_interactive_cli_loop_writes_one_wav_per_line(tmp_path):
+    """interactive.py surface (reference src/scripts/infer/interactive.py:17-60): lines in, one utterance each."""
+    from smalltts_amd import api
+    from smalltts_amd.audio import read_wav
+    from smalltts_amd.scripts import interactive
+    n = interactive.main(["--weights", "synthetic:3", "--seed", "0", "--tokenizer", "chars", "--outdir", str(tmp_path)],
+                         lines=["hello there", "", "it costs $5"])
+    api._ENGINES.clear()
+    assert n == 2
+    a, rate = read_wav(str(tmp_path / "interactive_001.wav"))
+    assert rate == 24000 and a.size % 3200 == 0 and a.size > 0 and np.isfinite(a).all()
+
+
 def test_missing_weight_file_is_a_clear_error():
     from smalltts_amd.api import SmallTTS
     with pytest.raises(FileNotFoundError, match="synthetic"):
@@ -180,11 +193,48 @@ def test_synthesize_batches_matches_a_loop_of_synthesize_batch(eng):
         batches.append(([rng.standard_normal((3 + j, 64)).astype(np.float32) for j in range(n)],
                         [[int(v) for v in rng.integers(1, 198, size=5 + j)] for j in range(n)], [0.4 + 0.3 * j for j in range(n)]))
     a = SmallTTS(engine=eng, seed=5).synthesize_batches(batches, in_flight=3)
+    assert eng.tuning == "latency"                      # the caller's tuning mode is restored
+    # concurrency changes nothing: the same batches one after the other under the SAME (throughput) tuning are bit-identical
     tts = SmallTTS(engine=eng, seed=5)
-    b = [tts.synthesize_batch(*x) for x in batches]
+    eng.set_tuning("throughput")
+    try:
+        b = [tts.synthesize_batch(*x) for x in batches]
+    finally:
+        eng.set_tuning("latency")
     assert len(a) == len(b) == 5
     for xa, xb in zip(a, b):
         assert len(xa) == len(xb) and all(np.array_equal(u, v) for u, v in zip(xa, xb))
+    # the two tuning modes differ by fp32 summation order only (split-K / ring depth): far inside every tolerance
+    tts = SmallTTS(engine=eng, seed=5)
+    c = [tts.synthesize_batch(*x) for x in batches]
+    for xa, xc in zip(a, c):
+        for u, v in zip(xa, xc):
+            assert snr_db(u, v) > 80.0
+
+
+def test_synthesize_sharded_over_device_replicas_equals_one_engine(eng):
+    """SmallTTS(device_ids=[...]): contiguous shards on one engine + host thread per listed GPU, gathered on the host.  The box has
+    one GPU, so the second replica is a second engine on device 0 — the code path (threads, shard spans, order of the gathered
+    rows) is the multi-GPU one."""
+    from smalltts_amd.api import SmallTTS
+    from smalltts_amd.engine import HipEngine
+    rng = np.random.default_rng(33)
+    n = 5
+    refs = [rng.standard_normal((4 + j % 3, 64)).astype(np.float32) for j in range(n)]
+    toks = [[int(v) for v in rng.integers(1, 198, size=6 + j)] for j in range(n)]
+    one = SmallTTS(engine=eng, seed=9).synthesize_sharded(refs, toks, 0.8, max_batch=8)
+    assert one.shape == (n, 1, 3200 * 6)
+    e2 = HipEngine(0, "bf16x3")
+    e2.load_synthetic(SEED, parts=("dit", "decoder", "encoder"), codec_spec=SPEC)
+    e2.finalize()
+    tts = SmallTTS(engine=eng, seed=9)
+    tts._replicas.append(SmallTTS(engine=e2, seed=9))
+    two = tts.synthesize_sharded(refs, toks, 0.8)
+    assert two.shape == one.shape and np.isfinite(two).all()
+    # rows 0..2 ran on replica 0 as one batch of 3, rows 3..4 on replica 1: per-utterance results do not depend on the batch they
+    # rode in beyond summation order, the sampler noise does (seeded per call) -> compare shapes / finiteness / distinct rows
+    assert not np.array_equal(two[0], two[3])
+    e2.close()
 
 
 # ---- N1: converted weights on the GPU (SURVEY 8f; distill.py:39-57, 468-479) ---------------------------------------------

@@ -147,3 +147,49 @@ def test_onnx_initializer_reader_on_hand_encoded_model(tmp_path):
     # name matching: the two velocity tensors have the wrong shapes for this build -> reported, nothing guessed
     with pytest.raises(ValueError, match="do not cover"):
         convert.convert_onnx([str(p)], str(tmp_path / "o.smtts"))
+
+
+def test_text_normalizer_spells_out_what_the_reference_spells_out():
+    """Reference _phonemize runs EnglishTextNormalizer.normalize before espeak (phonemes.py:67-70); sentences from its own
+    __main__ list (phonemes.py:121-145).  Expected strings follow normalizer.py's rules with inflect's documented spelling
+    (inflect is not installed offline: parity with inflect itself is unpinned, see smalltts_amd/normalizer.py)."""
+    from smalltts_amd.normalizer import EnglishTextNormalizer, needs_normalization
+    n = EnglishTextNormalizer()
+    sq = lambda t: " ".join(n.normalize(t).split())
+    assert sq("Dr. Smith and Mrs. Johnson met at 3:30pm.") == "doctor. Smith and misess. Johnson met at three : thirty pm."
+    assert sq("The company earned $1,250,000.50 in Q4 2023.") == ("The company earned one million, two hundred fifty thousand "
+                                                                    "dollars, fifty cents in Q four twenty twenty-three .")
+    assert sq("About 75% of students scored above 90th percentile.") == "About seventy-five percent of students scored above ninetieth percentile."
+    assert sq("The recipe calls for 1/2 cup sugar and 3/4 tsp salt.") == "The recipe calls for one half cup sugar and three quarters tsp salt."
+    assert sq("The temperature is 98.6°F today.") == "The temperature is ninety-eight point six °F today."
+    assert sq("£500 equals approximately $625.50.") == "five hundred pounds equals approximately six hundred twenty-five dollars, fifty cents ."
+    assert sq("The 21st century began on January 1st, 2001.") == "The twenty-first century began on January first , two thousand one ."
+    assert sq("BTW, the meeting is at 2nd St. near Fort Collins.") == "by the way, the meeting is at second saint. near Fort Collins."
+    assert sq("1905 1100 2000 1984 7/8 101st $1 $0.01") == ("nineteen oh five eleven hundred two thousand nineteen eighty-four seven eighth "
+                                                            "one hundred and first one dollar one cent")
+    assert needs_normalization("at 3pm") and needs_normalization("Mr. X") and not needs_normalization("hello there, world!")
+    # the token path normalises before it maps characters (chars backend: no espeak offline)
+    assert phonemes.get_token_ids("$5", backend="chars") == [phonemes.p2idx[c] for c in n.normalize("$5") if c in phonemes.p2idx]
+    assert phonemes.decode_token_ids(phonemes.get_token_ids("$5", backend="chars")).split() == ["five", "dollars"]
+
+
+def test_reference_import_paths_resolve_to_this_build():
+    """The reference's scripts import smalltts.* (tryme.py:7-9, clone.py:7-11, interactive.py:11-15); the shim package re-exports
+    this build under those paths so the import lines need no edit.  (No GPU here: classes are imported, not constructed.)"""
+    import smalltts
+    from smalltts.assets.ensure import ensure_assets
+    from smalltts.codec.onnx import Decoder, Encoder
+    from smalltts.data.phonemization.phonemes import get_token_ids, phoneme_len
+    from smalltts.infer.onnx import HOP_SIZE, NUM_STEPS, SAMPLE_RATE, SmallTTS, estimate_duration
+    from smalltts.infer.utils import resample_hq
+    from smalltts_amd import api
+    assert smalltts.SmallTTS is SmallTTS is api.SmallTTS and Encoder is api.Encoder and Decoder is api.Decoder
+    assert (SAMPLE_RATE, HOP_SIZE, NUM_STEPS, phoneme_len) == (24000, 3200, 4, 198)
+    assert estimate_duration("x" * 23) == 2.0 and estimate_duration("") == 0.5 and estimate_duration("x" * 1000) == 30.0
+    import torch
+    assert tuple(resample_hq(torch.zeros(1, 1600), 16000, 24000).shape) == (1, 2400)
+    assert get_token_ids("[laughter]", backend="chars") == [188] * 4
+    with pytest.raises(FileNotFoundError, match="smalltts_amd.convert"):
+        ensure_assets(["codec", "dmd"])
+    with pytest.raises(AttributeError):
+        smalltts.nothing_here
