@@ -15,6 +15,10 @@ Two sources, both optional at run time because neither exists offline:
 
 CLI:  python -m smalltts_amd.convert --checkpoint ckpt.pt --out weights.smtts
       python -m smalltts_amd.convert --onnx condition_encoder.onnx denoiser.onnx --out weights.smtts [--allow-partial]
+      python -m smalltts_amd.convert --onnx decoder.onnx encoder.onnx --codec [--codec-spec spec.json] [--map-by-position]
+                                     --out codec.smtts --report codec_report.json
+The last form is the one-command path to pinning the codec the day the files are available: the report lists, per shape
+signature, what the exported graph holds against this build's CodecSpec inventory (missing biases, extra norms, other depths).
 """
 from __future__ import annotations
 
@@ -26,7 +30,8 @@ from typing import Dict, Iterable, List, Optional, Sequence, Tuple
 
 import numpy as np
 
-from .weights import (CodecSpec, all_param_specs, clean_state_dict_keys, dit_param_specs, save_weight_file)
+from .weights import (CodecSpec, clean_state_dict_keys, codec_decoder_param_specs, codec_encoder_param_specs, dit_param_specs,
+                      save_weight_file)
 
 
 # ----------------------------------------------------------------------------------------------
@@ -197,26 +202,112 @@ def read_onnx_initializers(path: str) -> Dict[str, np.ndarray]:
     return out
 
 
-def convert_onnx(paths: Sequence[str], out: str, codec: Optional[CodecSpec] = None, allow_partial: bool = False):
-    """Merge the initialisers of the given files; keep those whose names are parameters of this build."""
+def _signature(shape: Sequence[int]) -> Tuple[int, ...]:
+    """Layout-insensitive shape signature: size-1 axes dropped (a depthwise conv weight is (C, 1, K) in torch and (C, K) here),
+    2-D shapes order-insensitive (exporters store Linear weights as MatMul operands [in, out] = W^T)."""
+    sq = tuple(int(d) for d in shape if int(d) != 1)
+    return tuple(sorted(sq)) if len(sq) == 2 else sq
+
+
+def _fit(arr: np.ndarray, want: Tuple[int, ...], name: str) -> Optional[np.ndarray]:
+    """Bring an initialiser with the right signature into the inventory's layout (reshape size-1 axes, transpose MatMul
+    operands).  Square 2-D tensors are ambiguous: transposed iff the initialiser is a MatMul operand by name."""
+    if tuple(arr.shape) == tuple(want):
+        if len(want) == 2 and want[0] == want[1] and "matmul" in name.lower():
+            return np.ascontiguousarray(arr.T)
+        return arr
+    sq = arr.reshape([d for d in arr.shape if d != 1] or [1]) if arr.ndim else arr
+    wsq = tuple(d for d in want if d != 1)
+    if tuple(sq.shape) == wsq:
+        return np.ascontiguousarray(sq).reshape(want)
+    if sq.ndim == 2 and tuple(sq.shape[::-1]) == wsq:
+        return np.ascontiguousarray(sq.T).reshape(want)
+    return None
+
+
+def shape_signature_report(inits: Dict[str, np.ndarray], specs: Iterable[Tuple[str, Tuple[int, ...]]]) -> dict:
+    """Match ONNX initialisers to the parameter inventory: by (cleaned) name first, then BY POSITION inside each shape
+    signature — the k-th still-unmatched initialiser of a signature (file order = graph order of the exporter) against the
+    k-th still-unmatched parameter of that signature (inventory order = module registration order).  Position matches are
+    unverified by construction and reported as such; signatures whose counts differ are listed with both sides so that the
+    delta between the exported graph and this build's spec (a missing bias, an extra norm, another depth) can be read off."""
+    specs = list(specs)
+    want = dict(specs)
+    rep = {"by_name": {}, "by_position": {}, "count_mismatch": [], "expected_only": [], "onnx_only": []}
+    left_onnx = []
+    for name, arr in inits.items():
+        if arr.dtype.kind != "f":
+            continue
+        if name in want and _signature(arr.shape) == _signature(want[name]):
+            rep["by_name"][name] = name
+        else:
+            left_onnx.append(name)
+    left_exp = [n for n, _ in specs if n not in rep["by_name"]]
+    groups: Dict[Tuple[int, ...], List[List[str]]] = {}
+    for n in left_exp:
+        groups.setdefault(_signature(want[n]), [[], []])[0].append(n)
+    for n in left_onnx:
+        groups.setdefault(_signature(inits[n].shape), [[], []])[1].append(n)
+    for sig, (exp, got) in sorted(groups.items(), key=lambda kv: (len(kv[0]), kv[0])):
+        if exp and got and len(exp) == len(got):
+            for e_, g_ in zip(exp, got):
+                rep["by_position"][g_] = e_
+        elif exp and got:
+            rep["count_mismatch"].append({"signature": list(sig), "expected": len(exp), "onnx": len(got),
+                                          "expected_names": exp[:6], "onnx_names": got[:6]})
+        elif exp:
+            rep["expected_only"].append({"signature": list(sig), "count": len(exp), "names": exp[:6]})
+        else:
+            rep["onnx_only"].append({"signature": list(sig), "count": len(got), "names": got[:6]})
+    rep["summary"] = (f"{len(rep['by_name'])} by name, {len(rep['by_position'])} by position (unverified), "
+                      f"{len(rep['count_mismatch'])} signatures with differing counts, "
+                      f"{sum(e['count'] for e in rep['expected_only'])} parameters without a candidate, "
+                      f"{sum(e['count'] for e in rep['onnx_only'])} initialisers without a parameter")
+    return rep
+
+
+def convert_onnx(paths: Sequence[str], out: str, codec: Optional[CodecSpec] = None, allow_partial: bool = False,
+                 map_by_position: bool = False, parts: Optional[Sequence[str]] = None):
+    """Merge the float initialisers of the given files and keep those that are parameters of this build: by name (exact or
+    transposed 2-D shape) and, with map_by_position, by position inside each shape signature (shape_signature_report).
+    `parts` names the inventories the files are matched against — "dit" (condition_encoder.onnx + denoiser.onnx; default
+    without `codec`), "decoder" / "encoder" (codec/decoder.onnx, codec/encoder.onnx; default both with `codec`): matching a file
+    against an inventory it does not hold would only add signature collisions.  The report's `signature` entry lists every delta."""
     merged: Dict[str, np.ndarray] = {}
     for p in paths:
         for name, arr in read_onnx_initializers(p).items():
             if arr.dtype.kind == "f":
                 merged[name] = np.ascontiguousarray(arr, dtype=np.float32)
     merged = {k: v for k, v in clean_state_dict_keys(merged).items()}
-    specs = list(dit_param_specs()) + ([s for s in all_param_specs(codec) if s[0] not in dict(dit_param_specs())] if codec else [])
-    rep = check_against_specs(merged, specs)
-    # exporters fold Linear weights into MatMul initialisers stored as [in, out]: accept an exact transposed shape match by name
-    for name, got, want in list(rep["shape_mismatch"]):
-        if len(want) == 2 and tuple(reversed(got)) == tuple(want):
-            merged[name] = np.ascontiguousarray(merged[name].T)
-            rep["shape_mismatch"].remove((name, got, want))
-            rep["matched"] += 1
+    parts = tuple(parts) if parts else (("decoder", "encoder") if codec else ("dit",))
+    if ("decoder" in parts or "encoder" in parts) and codec is None:
+        codec = CodecSpec()
+    specs = []
+    if "dit" in parts:
+        specs += list(dit_param_specs())
+    if "decoder" in parts:
+        specs += codec_decoder_param_specs(codec)
+    if "encoder" in parts:
+        specs += codec_encoder_param_specs(codec)
+    want = dict(specs)
+    sig = shape_signature_report(merged, specs)
+    tensors: Dict[str, np.ndarray] = {}
+    for name in sig["by_name"]:
+        fit = _fit(merged[name], want[name], name)
+        if fit is not None:
+            tensors[name] = fit
+    if map_by_position:
+        for src, dst in sig["by_position"].items():
+            fit = _fit(merged[src], want[dst], src)
+            if fit is not None:
+                tensors[dst] = fit
+    rep = check_against_specs(tensors, specs)
+    rep["unexpected"] = sorted(k for k in merged if k not in tensors and k not in sig["by_position"])
+    rep["signature"] = sig
     if not rep.ok and not allow_partial:
-        raise ValueError(f"ONNX initialisers do not cover the parameter inventory by name — {rep.summary()}; "
-                         f"unmatched initialisers (first 5): {rep['unexpected'][:5]}")
-    keep = {n: merged[n] for n, s in specs if n in merged and tuple(merged[n].shape) == tuple(s)}
+        raise ValueError(f"ONNX initialisers do not cover the parameter inventory — {rep.summary()}; signature match: "
+                         f"{sig['summary']}" + ("" if map_by_position else " (re-run with --map-by-position to apply the position matches)"))
+    keep = {n: tensors[n] for n, s_ in specs if n in tensors}
     save_weight_file(out, keep, codec)
     return rep
 
@@ -230,10 +321,29 @@ def main(argv: Optional[Sequence[str]] = None) -> int:
     ap.add_argument("--out", required=True)
     ap.add_argument("--allow-partial", action="store_true", help="write what matched instead of failing")
     ap.add_argument("--report", default=None, help="write the match report as JSON")
+    ap.add_argument("--codec", action="store_true", help="--onnx: include the codec inventory (decoder.onnx / encoder.onnx)")
+    ap.add_argument("--codec-spec", default=None, help="JSON file with CodecSpec fields (default: the built-in VibeVoice-shaped spec)")
+    ap.add_argument("--parts", default=None, help="--onnx: inventories to match, comma separated: dit | decoder | encoder "
+                                                  "(default: dit, or decoder,encoder with --codec)")
+    ap.add_argument("--map-by-position", action="store_true",
+                    help="--onnx: also take initialisers matched by position inside their shape signature (unverified; see the report)")
     a = ap.parse_args(argv)
+    codec = None
+    if a.codec or a.codec_spec:
+        codec = CodecSpec(**json.load(open(a.codec_spec))) if a.codec_spec else CodecSpec()
     rep = (convert_checkpoint(a.checkpoint, a.out, a.key, a.allow_partial) if a.checkpoint
-           else convert_onnx(a.onnx, a.out, None, a.allow_partial))
+           else convert_onnx(a.onnx, a.out, codec, a.allow_partial, a.map_by_position, a.parts.split(",") if a.parts else None))
     print(rep.summary())
+    if "signature" in rep:
+        sg = rep["signature"]
+        print("signature match:", sg["summary"])
+        for row in sg["count_mismatch"]:
+            print(f"  shape {tuple(row['signature'])}: this build expects {row['expected']} ({', '.join(row['expected_names'][:3])} ...), "
+                  f"the file has {row['onnx']} ({', '.join(row['onnx_names'][:3])} ...)")
+        for row in sg["expected_only"]:
+            print(f"  shape {tuple(row['signature'])}: {row['count']} parameter(s) with no initialiser of that shape, e.g. {row['names'][0]}")
+        for row in sg["onnx_only"]:
+            print(f"  shape {tuple(row['signature'])}: {row['count']} initialiser(s) this build has no parameter for, e.g. {row['names'][0]}")
     if a.report:
         with open(a.report, "w") as f:
             json.dump(rep, f, indent=1)

@@ -450,6 +450,20 @@ int Engine::finalize_codec(bool decoder) {
     const int S = s.n_ratios + 1, Kc = s.kernel;
     if (Kc - 1 > kCodecPad) return fail("codec kernel too large for the frame padding");
     h = CodecHalfW();
+    // Optional tensors (CodecSpec flags conv_bias / ffn_bias / layer_scale, smalltts_amd/weights.py): an exported codec may come
+    // without biases or layer scales — absent means the identity value, present means the inventory's shape.
+    auto opt_vec = [&](const std::string& name, long n, float fill, const float** out) -> int {
+        if (raw(name)) {
+            if (check_shape(name, {n})) return 1;
+            *out = rawp(name);
+            return 0;
+        }
+        float* d = static_cast<float*>(dalloc((size_t)n * 4));
+        if (!d) return fail("codec: out of memory for the default of " + name);
+        HIPC(launch_fill(d, fill, n, 0));
+        *out = d;
+        return 0;
+    };
     auto gather_to_pw = [&](const float* src, int N, int K, GatherSpec g, PW& out, float** f32_out) -> int {
         float* tmp = nullptr;
         if (f32_out) {
@@ -479,8 +493,8 @@ int Engine::finalize_codec(bool decoder) {
                 if (!w || w->numel != (long)Cin * C * 2 * r) return fail("missing/mis-shaped " + sidx(P + ".up.", i, ".weight"));
                 GatherSpec g{r, 1, 2L * r, -(long)r, (long)C * 2 * r, C, Cin, Cin};
                 if (gather_to_pw(w->d, r * C, 2 * Cin, g, st.resample, nullptr)) return 1;
-                const float* b = rawp(sidx(P + ".up.", i, ".bias"));
-                if (!b) return fail("missing up bias");
+                const float* b = nullptr;
+                if (opt_vec(sidx(P + ".up.", i, ".bias"), C, 0.f, &b)) return 1;
                 GatherSpec gb{0, 0, 0, 0, 1, 1, C, C};
                 PW dummy;
                 if (gather_to_pw(b, 1, r * C, gb, dummy, &st.resample_bias)) return 1;
@@ -490,28 +504,29 @@ int Engine::finalize_codec(bool decoder) {
                 if (!w || w->numel != (long)C * Cin * 2 * r) return fail("missing/mis-shaped " + sidx(P + ".down.", i, ".weight"));
                 GatherSpec g{0, 0, (long)Cin * 2 * r, 1, 2L * r, C, Cin, Cin};
                 if (gather_to_pw(w->d, C, 2 * r * Cin, g, st.resample, nullptr)) return 1;
-                st.resample_bias = const_cast<float*>(rawp(sidx(P + ".down.", i, ".bias")));
-                if (!st.resample_bias) return fail("missing down bias");
+                const float* b = nullptr;
+                if (opt_vec(sidx(P + ".down.", i, ".bias"), C, 0.f, &b)) return 1;
+                st.resample_bias = const_cast<float*>(b);
             }
         }
         const int depth = decoder ? s.depths[i] : s.depths[S - 1 - i];
         for (int j = 0; j < depth; ++j) {
             std::string p = P + ".stages." + std::to_string(i) + "." + std::to_string(j);
             CodecBlockW b;
-            b.norm_w = rawp(p + ".norm.weight"); b.dw_b = rawp(p + ".mixer.bias"); b.gamma = rawp(p + ".gamma");
-            b.ffn_norm_w = rawp(p + ".ffn_norm.weight"); b.b1 = rawp(p + ".ffn.w1.bias");
-            b.b2 = rawp(p + ".ffn.w2.bias"); b.ffn_gamma = rawp(p + ".ffn_gamma");
+            b.norm_w = rawp(p + ".norm.weight");
+            b.ffn_norm_w = rawp(p + ".ffn_norm.weight");
             const float* mw = rawp(p + ".mixer.weight");
             {
                 const long Fh = (long)s.ffn_mult * C;
-                if (check_shape(p + ".norm.weight", {C}) || check_shape(p + ".mixer.weight", {C, Kc}) || check_shape(p + ".mixer.bias", {C}) ||
-                    check_shape(p + ".gamma", {C}) || check_shape(p + ".ffn_norm.weight", {C}) || check_shape(p + ".ffn.w1.weight", {Fh, C}) ||
-                    check_shape(p + ".ffn.w1.bias", {Fh}) || check_shape(p + ".ffn.w2.weight", {C, Fh}) || check_shape(p + ".ffn.w2.bias", {C}) ||
-                    check_shape(p + ".ffn_gamma", {C}))
+                if (check_shape(p + ".norm.weight", {C}) || check_shape(p + ".mixer.weight", {C, Kc}) ||
+                    check_shape(p + ".ffn_norm.weight", {C}) || check_shape(p + ".ffn.w1.weight", {Fh, C}) ||
+                    check_shape(p + ".ffn.w2.weight", {C, Fh}))
+                    return 1;
+                if (opt_vec(p + ".mixer.bias", C, 0.f, &b.dw_b) || opt_vec(p + ".gamma", C, 1.f, &b.gamma) ||
+                    opt_vec(p + ".ffn.w1.bias", Fh, 0.f, &b.b1) || opt_vec(p + ".ffn.w2.bias", C, 0.f, &b.b2) ||
+                    opt_vec(p + ".ffn_gamma", C, 1.f, &b.ffn_gamma))
                     return 1;
             }
-            if (!b.norm_w || !b.dw_b || !b.gamma || !b.ffn_norm_w || !b.b1 || !b.b2 || !b.ffn_gamma || !mw)
-                return fail("codec block incomplete: " + p);
             GatherSpec g{0, 0, 1, 0, Kc, Kc, C, C};
             PW dummy;
             if (gather_to_pw(mw, Kc, C, g, dummy, &b.dw_w)) return 1;
@@ -540,22 +555,30 @@ int Engine::finalize_codec(bool decoder) {
         if (!w || w->numel != (long)C0 * s.latent_dim * Kc) return fail("missing decoder stem");
         GatherSpec g{0, 0, (long)s.latent_dim * Kc, 1, Kc, C0, s.latent_dim, s.latent_dim};
         if (gather_to_pw(w->d, C0, Kc * s.latent_dim, g, h.stem, nullptr)) return 1;
-        h.stem_b = rawp(P + ".stem.bias");
+        if (opt_vec(P + ".stem.bias", C0, 0.f, &h.stem_b)) return 1;
         const float* hw = rawp(P + ".head.weight");
-        const float* hb = rawp(P + ".head.bias");
-        if (!h.stem_b || !hw || !hb) return fail("missing decoder stem bias / head");
+        const float* hb = nullptr;
+        if (opt_vec(P + ".head.bias", 1, 0.f, &hb)) return 1;
+        if (!hw) return fail("missing decoder head");
+        if (check_shape(P + ".head.weight", {1, Cl, Kc})) return 1;
         GatherSpec gh{0, 0, 1, 0, Kc, Kc, Cl, Cl};
         PW dummy;
         if (gather_to_pw(hw, Kc, Cl, gh, dummy, &h.head_w)) return 1;
         HIPC(hipMemcpy(&h.head_b_host, hb, 4, hipMemcpyDeviceToHost));
     } else {
         h.stem_w_raw = rawp(P + ".stem.weight");
-        h.stem_b = rawp(P + ".stem.bias");
         const RawTensor* w = raw(P + ".head.weight");
-        h.head_b = rawp(P + ".head.bias");
-        if (!h.stem_w_raw || !h.stem_b || !w || !h.head_b) return fail("missing encoder stem/head");
+        if (opt_vec(P + ".stem.bias", C0, 0.f, &h.stem_b) || opt_vec(P + ".head.bias", s.latent_dim, 0.f, &h.head_b)) return 1;
+        if (!h.stem_w_raw || !w) return fail("missing encoder stem/head");
+        if (check_shape(P + ".stem.weight", {C0, 1, Kc}) || check_shape(P + ".head.weight", {s.latent_dim, Cl, Kc})) return 1;
         GatherSpec g{0, 0, (long)Cl * Kc, 1, Kc, s.latent_dim, Cl, Cl};
         if (gather_to_pw(w->d, s.latent_dim, Kc * Cl, g, h.head, nullptr)) return 1;
+    }
+    // optional RMSNorm in front of the head conv (CodecSpec.final_norm)
+    h.final_norm_w = nullptr;
+    if (raw(P + ".final_norm.weight")) {
+        if (check_shape(P + ".final_norm.weight", {Cl})) return 1;
+        h.final_norm_w = rawp(P + ".final_norm.weight");
     }
     h.ready = true;
     return 0;
@@ -1324,6 +1347,11 @@ int Engine::codec_decode(hipStream_t st, const float* latents, int B, int T, flo
         for (const CodecBlockW& b : sg.blocks)
             if (codec_block(st, b, &x, &xn, w.nb, w.n2hi, w.n2lo, w.hhi, w.hlo, B, Ti, C, max_img)) return 1;
     }
+    if (dec_.final_norm_w) {   // out of place into the (zero-padded) scratch image: the head conv reads K - 1 pad frames
+        const RowMap img = rowmap_batched(C, Ti, (long)(pad + Ti) * C, (long)pad * C);
+        HIPC(launch_rmsnorm(x, img, w.nb, nullptr, nullptr, img, B * Ti, C, cspec_.eps, dec_.final_norm_w, st));
+        x = w.nb;
+    }
     HIPC(launch_head_conv(x, dec_.head_w, dec_.head_b_host, audio, B, Ti, C, Kc, pad, st));
     return 0;
 }
@@ -1396,6 +1424,11 @@ int Engine::codec_encode(hipStream_t st, const float* audio, int B, int S_, floa
         }
         for (const CodecBlockW& b : sg.blocks)
             if (codec_block(st, b, &x, &xn, w.nb, w.n2hi, w.n2lo, w.hhi, w.hlo, B, Ti, C, max_img)) return 1;
+    }
+    if (enc_.final_norm_w) {
+        const RowMap img = rowmap_batched(C, Ti, (long)(pad + Ti) * C, (long)pad * C);
+        HIPC(launch_rmsnorm(x, img, w.nb, nullptr, nullptr, img, B * Ti, C, cspec_.eps, enc_.final_norm_w, st));
+        x = w.nb;
     }
     RowMap am = rowmap_batched(C, Ti, (long)(pad + Ti) * C, (long)(pad - (Kc - 1)) * C);
     HIPC(gemm_store(ops(x, am, enc_.head, B * Ti), ACT_NONE, store_to(latents, rowmap_plain(s.latent_dim), enc_.head_b), 1,

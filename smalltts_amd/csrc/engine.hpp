@@ -65,6 +65,7 @@ struct CodecHalfW {
     float* head_w = nullptr; // decoder: [K][Clast] fp32
     float head_b_host = 0.f;
     const float* head_b = nullptr;
+    const float* final_norm_w = nullptr;  // optional RMSNorm in front of the head conv
 };
 
 struct CodecSpecC {

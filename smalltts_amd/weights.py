@@ -146,7 +146,8 @@ class CodecSpec:
     hop = prod(ratios) must equal the reference HOP_SIZE (infer/onnx.py:12)."""
 
     def __init__(self, latent_dim=64, n_filters=32, ratios=(8, 5, 5, 4, 2, 2),
-                 dec_depths=(8, 3, 3, 3, 3, 3, 3), kernel=7, ffn_mult=4, eps=1e-5):
+                 dec_depths=(8, 3, 3, 3, 3, 3, 3), kernel=7, ffn_mult=4, eps=1e-5,
+                 conv_bias=True, ffn_bias=True, layer_scale=True, final_norm=False):
         self.latent_dim = latent_dim
         self.n_filters = n_filters
         self.ratios = tuple(ratios)          # decoder order (coarse -> fine)
@@ -154,6 +155,14 @@ class CodecSpec:
         self.kernel = kernel
         self.ffn_mult = ffn_mult
         self.eps = eps
+        # Which OPTIONAL tensors the parameter inventory contains.  The engine and the oracle treat them as optional at run
+        # time (absent bias = 0, absent layer scale = 1, absent final norm = identity), so an exported codec that differs from
+        # the default in these respects loads without code changes; the flags only steer the inventory (synthetic weights,
+        # converter report).
+        self.conv_bias = bool(conv_bias)      # bias of stem / head / resampling / depthwise convs
+        self.ffn_bias = bool(ffn_bias)        # bias of the two FFN linears
+        self.layer_scale = bool(layer_scale)  # per-channel gamma / ffn_gamma on the two residual branches
+        self.final_norm = bool(final_norm)    # RMSNorm in front of the head conv
         assert len(self.dec_depths) == len(self.ratios) + 1
 
     @property
@@ -170,7 +179,8 @@ class CodecSpec:
     def to_dict(self):
         return dict(latent_dim=self.latent_dim, n_filters=self.n_filters, ratios=list(self.ratios),
                     dec_depths=list(self.dec_depths), kernel=self.kernel, ffn_mult=self.ffn_mult,
-                    eps=self.eps)
+                    eps=self.eps, conv_bias=self.conv_bias, ffn_bias=self.ffn_bias, layer_scale=self.layer_scale,
+                    final_norm=self.final_norm)
 
     # encoder mirrors the decoder: stage order fine -> coarse
     @property
@@ -188,9 +198,21 @@ class CodecSpec:
 DEFAULT_CODEC = CodecSpec()
 
 
+def _optional(spec: CodecSpec, name: str) -> bool:
+    """Is this tensor of the full inventory present under the spec's flags?"""
+    leaf = name.rsplit(".", 1)[-1]
+    if leaf in ("gamma", "ffn_gamma"):
+        return spec.layer_scale
+    if leaf == "bias":
+        return spec.ffn_bias if ".ffn." in name else spec.conv_bias
+    if ".final_norm." in name:
+        return spec.final_norm
+    return True
+
+
 def _block_specs(prefix: str, c: int, spec: CodecSpec):
     k, f = spec.kernel, spec.ffn_mult
-    return [(f"{prefix}.norm.weight", (c,)),
+    full = [(f"{prefix}.norm.weight", (c,)),
             (f"{prefix}.mixer.weight", (c, k)),      # depthwise causal conv
             (f"{prefix}.mixer.bias", (c,)),
             (f"{prefix}.gamma", (c,)),
@@ -200,6 +222,7 @@ def _block_specs(prefix: str, c: int, spec: CodecSpec):
             (f"{prefix}.ffn.w2.weight", (c, f * c)),
             (f"{prefix}.ffn.w2.bias", (c,)),
             (f"{prefix}.ffn_gamma", (c,))]
+    return [t for t in full if _optional(spec, t[0])]
 
 
 def codec_decoder_param_specs(spec: CodecSpec = DEFAULT_CODEC):
@@ -217,8 +240,9 @@ def codec_decoder_param_specs(spec: CodecSpec = DEFAULT_CODEC):
         for j in range(spec.dec_depths[i]):
             s += _block_specs(f"codec.decoder.stages.{i}.{j}", c, spec)
     cl = spec.dec_channels(spec.n_stages - 1)
-    s += [("codec.decoder.head.weight", (1, cl, spec.kernel)), ("codec.decoder.head.bias", (1,))]
-    return s
+    s += [("codec.decoder.final_norm.weight", (cl,)),
+          ("codec.decoder.head.weight", (1, cl, spec.kernel)), ("codec.decoder.head.bias", (1,))]
+    return [t for t in s if _optional(spec, t[0])]
 
 
 def codec_encoder_param_specs(spec: CodecSpec = DEFAULT_CODEC):
@@ -234,9 +258,10 @@ def codec_encoder_param_specs(spec: CodecSpec = DEFAULT_CODEC):
         for j in range(spec.enc_depths[i]):
             s += _block_specs(f"codec.encoder.stages.{i}.{j}", c, spec)
     cl = spec.enc_channels(spec.n_stages - 1)
-    s += [("codec.encoder.head.weight", (spec.latent_dim, cl, spec.kernel)),
+    s += [("codec.encoder.final_norm.weight", (cl,)),
+          ("codec.encoder.head.weight", (spec.latent_dim, cl, spec.kernel)),
           ("codec.encoder.head.bias", (spec.latent_dim,))]
-    return s
+    return [t for t in s if _optional(spec, t[0])]
 
 
 def all_param_specs(spec: CodecSpec = DEFAULT_CODEC):

@@ -23,6 +23,11 @@ SPECS = {
     "tiny": CodecSpec(n_filters=8, ratios=(4, 2, 2), dec_depths=(2, 1, 1, 2)),
     "odd": CodecSpec(n_filters=16, ratios=(5, 3, 2), dec_depths=(1, 2, 1, 1)),
     "narrow6": CodecSpec(n_filters=32, ratios=(8, 5, 5, 4, 2, 2), dec_depths=(1, 1, 1, 1, 1, 1, 1)),
+    # the plausible deltas of an exported VibeVoice codec: no conv / FFN biases, no layer scale, a final
+    # norm in front of the head, a different depth order — absent tensors take their identity value in the engine and the oracle
+    "no_bias_no_scale_final_norm": CodecSpec(n_filters=32, ratios=(8, 5, 5, 4, 2, 2), dec_depths=(1, 2, 1, 1, 1, 1, 2), conv_bias=False,
+                                             ffn_bias=False, layer_scale=False, final_norm=True),
+    "ffn_bias_only": CodecSpec(n_filters=16, ratios=(5, 3, 2), dec_depths=(1, 2, 1, 1), conv_bias=False, layer_scale=True, final_norm=True),
 }
 
 

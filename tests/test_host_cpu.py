@@ -193,3 +193,81 @@ def test_reference_import_paths_resolve_to_this_build():
         ensure_assets(["codec", "dmd"])
     with pytest.raises(AttributeError):
         smalltts.nothing_here
+
+
+def _onnx_bytes(named):
+    """Hand-encoded ModelProto whose graph holds the given float32 initialisers (name, array) in order."""
+    graph = b""
+    for name, arr in named:
+        dims = b"".join(_pb_varint(int(d)) for d in arr.shape)
+        t = (_pb_field(1, 2, dims) if arr.ndim else b"") + _pb_field(2, 0, _pb_varint(1)) + _pb_field(8, 2, name.encode()) + \
+            _pb_field(9, 2, np.ascontiguousarray(arr, "<f4").tobytes())
+        graph += _pb_field(5, 2, t)
+    return _pb_field(1, 0, _pb_varint(8)) + _pb_field(7, 2, graph)
+
+
+def test_codec_onnx_with_renamed_and_permuted_initialisers_gets_a_precise_report(tmp_path):
+    """the day decoder.onnx exists, pinning the codec must be one command.  A hand-built ONNX file holds a
+    small codec decoder the way an exporter would leave it — Linear weights as anonymous transposed MatMul operands, conv
+    weights under graph names, depthwise weights as (C, 1, K), one bias family missing, one extra tensor — and the converter
+    (a) reports the deltas per shape signature, (b) maps the rest by position, (c) writes a weight file the loader accepts."""
+    from smalltts_amd import convert
+    from smalltts_amd.weights import CodecSpec, codec_decoder_param_specs, load_weight_file, synth_state_dict
+    spec = CodecSpec(n_filters=8, ratios=(4, 2), dec_depths=(1, 2, 1))
+    sd = synth_state_dict(codec_decoder_param_specs(spec), 5)
+    named, k = [], 0
+    for name, arr in sd.items():
+        if name.endswith(".ffn.w1.bias"):
+            continue                                            # the exporter's graph has no FFN-1 bias
+        if name.endswith(".ffn.w1.weight") or name.endswith(".ffn.w2.weight"):
+            named.append((f"onnx::MatMul_{1000 + k}", arr.T)); k += 1          # anonymous, stored [in, out]
+        elif name.endswith(".mixer.weight"):
+            named.append((f"/decoder/stages/{k}/mixer/conv.weight", arr[:, None, :])); k += 1   # torch depthwise layout (C, 1, K)
+        elif name.endswith((".up.1.weight", ".up.2.weight", ".stem.weight", ".head.weight")):
+            named.append((name, arr))                           # kept their names
+        else:
+            named.append((f"decoder.renamed.{k}", arr)); k += 1
+    named.append(("decoder.extra_buffer", np.zeros((3, 5, 7), np.float32)))
+    p = tmp_path / "decoder.onnx"
+    p.write_bytes(_onnx_bytes(named))
+    out = tmp_path / "codec.smtts"
+    with pytest.raises(ValueError, match="--map-by-position"):
+        convert.convert_onnx([str(p)], str(out), codec=spec, parts=["decoder"])
+    rep = convert.convert_onnx([str(p)], str(out), codec=spec, allow_partial=True, map_by_position=True, parts=["decoder"])
+    sg = rep["signature"]
+    assert set(sg["by_name"]) == {n for n in sd if n.endswith((".up.1.weight", ".up.2.weight", ".stem.weight", ".head.weight"))}
+    # every FFN weight came back under its own name, un-transposed, purely from graph order within its shape signature
+    got, cdict = load_weight_file(str(out))
+    for n, a in sd.items():
+        if n.endswith((".ffn.w1.weight", ".ffn.w2.weight", ".mixer.weight")):
+            assert np.array_equal(got[n], a), n
+    # ... and the report names exactly what differs: the missing bias family and the extra tensor
+    missing = [n for n in sd if n.endswith(".ffn.w1.bias")]
+    assert set(missing) <= set(rep["missing"])
+    deltas = sg["count_mismatch"] + sg["expected_only"]
+    assert any(set(row.get("expected_names", row.get("names"))) & set(missing) for row in deltas), sg
+    assert any(row["names"] == ["decoder.extra_buffer"] for row in sg["onnx_only"])
+    assert cdict["ratios"] == [4, 2] and cdict["ffn_bias"] is True
+    # the CLI prints the same report and exits non-zero without --allow-partial
+    assert convert.main(["--onnx", str(p), "--codec-spec", _write_json(tmp_path, spec.to_dict()), "--map-by-position", "--parts", "decoder", "--out", str(out),
+                         "--allow-partial", "--report", str(tmp_path / "r.json")]) == 0
+    import json
+    assert json.load(open(tmp_path / "r.json"))["signature"]["summary"].startswith(f"{len(sg['by_name'])} by name")
+
+
+def _write_json(tmp_path, obj):
+    import json
+    p = tmp_path / "spec.json"
+    p.write_text(json.dumps(obj))
+    return str(p)
+
+
+def test_codec_spec_flags_steer_the_inventory():
+    from smalltts_amd.weights import CodecSpec, codec_decoder_param_specs, codec_encoder_param_specs
+    full = CodecSpec(n_filters=8, ratios=(4, 2), dec_depths=(1, 1, 1), final_norm=True)
+    lean = CodecSpec(n_filters=8, ratios=(4, 2), dec_depths=(1, 1, 1), conv_bias=False, ffn_bias=False, layer_scale=False)
+    nf = {n for n, _ in codec_decoder_param_specs(full) + codec_encoder_param_specs(full)}
+    nl = {n for n, _ in codec_decoder_param_specs(lean) + codec_encoder_param_specs(lean)}
+    assert "codec.decoder.final_norm.weight" in nf and "codec.encoder.final_norm.weight" in nf
+    assert not any(n.endswith((".bias", "gamma")) or "final_norm" in n for n in nl)
+    assert nl < nf and CodecSpec(**lean.to_dict()).to_dict() == lean.to_dict()

@@ -54,7 +54,8 @@ def test_sixteen_concurrent_requests_get_their_own_audio():
         sr = (16000, 24000, 44100)[i % 3]
         t = np.arange(int((0.5 + 0.1 * (i % 4)) * sr)) / sr
         voice = 0.4 * np.sin(2 * np.pi * (220 + 40 * (i % 5)) * t) + 0.02 * rng.standard_normal(t.size)   # 5 distinct voices x 3 rates
-        reqs.append((S.encode_wav(voice, sr), [int(v) for v in rng.integers(1, 198, size=4 + i % 7)], round(0.3 + 0.17 * (i % 6), 2), 1000 + i))
+        wav = S.encode_wav(voice, sr) if i < 8 else reqs[i - 8][0]      # the second half re-uses the first half's voices (cache)
+        reqs.append((wav, [int(v) for v in rng.integers(1, 198, size=4 + i % 7)], round(0.3 + 0.17 * (i % 6), 2), 1000 + i))
     try:
         with ThreadPoolExecutor(16) as pool:
             outs = list(pool.map(lambda r: _post(port, *r), reqs))
