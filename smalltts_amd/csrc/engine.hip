@@ -29,6 +29,7 @@ inline std::string sidx(const std::string& a, int i, const std::string& b) { ret
 
 int g_gemm3_t160 = 1;   // gemm3 160x128 tiles for M = 600 x wide N (SMTTS_GEMM_T160=0: off)
 int g_gemm3_deep = 1;   // gemm3 ring depth for single-array operand formats: 1 = deep (latency tuning), 0 = shallow (throughput tuning)
+int g_gemm3_stage16 = 1;  // gemm3: 16-bit outputs through the LDS-staged epilogue (SMTTS_GEMM_STAGE16=0: scalar stores)
 int g_gemm3_nfast = 1;  // gemm3 tile order: N fastest when M > N (SMTTS_GEMM_NFAST=0 restores M fastest everywhere)
 thread_local Profiler* g_prof = nullptr;
 thread_local const char* g_prof_tag = nullptr;
@@ -36,6 +37,7 @@ thread_local const char* g_prof_tag = nullptr;
 Engine::Engine(int device) : device_(device) {
     if (const char* nf = getenv("SMTTS_GEMM_NFAST")) g_gemm3_nfast = atoi(nf);
     if (const char* dp = getenv("SMTTS_GEMM_DEEP")) g_gemm3_deep = atoi(dp);
+    if (const char* s16 = getenv("SMTTS_GEMM_STAGE16")) g_gemm3_stage16 = atoi(s16);
     if (const char* t1 = getenv("SMTTS_GEMM_T160")) g_gemm3_t160 = atoi(t1);
     const char* s = getenv("SMTTS_SINGLE_STREAM");
     if (s && *s == '1') dual_stream_ = false;
@@ -430,9 +432,6 @@ int Engine::finalize_dit() {
     HIPC(hipMemcpy(&ls, rawp("style_encoder.log_scale"), 4, hipMemcpyDeviceToHost));
     style_scale_ = expf(ls);
     if (make_rope(64, &rope_dit_cos_, &rope_dit_sin_)) return 1;
-    rope_tmp_cos_ = static_cast<float*>(dalloc((size_t)kMaxPos * 64 * 4));
-    rope_tmp_sin_ = static_cast<float*>(dalloc((size_t)kMaxPos * 64 * 4));
-    if (!rope_tmp_cos_ || !rope_tmp_sin_) return fail("rope alloc failed");
     for (const char* n : {"time_embedding.mlp.0.bias", "time_embedding.mlp.2.bias", "dit.emb_proj.0.bias",
                           "dit.emb_proj.2.bias", "dit.input_embed.proj.bias", "velocity.bias", "dit.phoneme_proj.bias",
                           "style_encoder.in_proj.bias", "style_encoder.out_proj.bias",
@@ -873,6 +872,7 @@ struct ModWs {
 };
 struct CoreWs {
     float *h, *x, *qkvg, *part;
+    float *rope_c, *rope_s;  // cos / sin of a caller-supplied angle table: per call (several calls may be in flight on different streams)
     SplitBuf gm1, gm2, y, o, ffh;
     size_t gm_elems;
     void plan(Bump& b, int B, int N) {
@@ -882,6 +882,8 @@ struct CoreWs {
         x = b.take<float>(M * kHidden);
         qkvg = b.take<float>(M * 4 * kHidden);
         part = b.take<float>(M * kHidden * kSplitK);
+        rope_c = b.take<float>((size_t)N * 64);
+        rope_s = b.take<float>((size_t)N * 64);
         gm1 = take_split(b, gm_elems);
         gm2 = take_split(b, gm_elems);
         y = take_split(b, M * kHidden);
@@ -945,9 +947,9 @@ int Engine::denoise_core(hipStream_t st, const float* x_t, const uint8_t* mask, 
     const float* rc = rope_dit_cos_;
     const float* rs = rope_dit_sin_;
     if (rope) {  // caller-supplied angle table (reference operator input, infer/onnx.py:42-47,122)
-        HIPC(launch_rope_cossin(rope, rope_tmp_cos_, rope_tmp_sin_, N * 64, st));
-        rc = rope_tmp_cos_;
-        rs = rope_tmp_sin_;
+        HIPC(launch_rope_cossin(rope, w.rope_c, w.rope_s, N * 64, st));
+        rc = w.rope_c;
+        rs = w.rope_s;
     }
     // The AdaLN in front of each GEMM is fused into the kernel that produced the residual stream it normalises
     // (split-K reduction + gated residual + LayerNorm-modulate in one pass); only the very first one runs alone.

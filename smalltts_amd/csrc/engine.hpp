@@ -1,8 +1,11 @@
 // smalltts gfx950 engine: owns the weights (fp32 originals + bf16 hi/lo GEMM packs) for one GPU and
 // sequences the kernels of the three boundary operators the reference runs through onnxruntime
 // (condition_encoder / denoiser / codec, reference infer/onnx.py:91-128) plus the fused sampler.
-// Single-stream, not thread-safe: one Engine per GPU (mirrors the reference's one-Session-per-
-// pipeline model, src/server/src/main.rs:24).
+// Not thread-safe: one Engine per GPU, driven by one host thread (mirrors the reference's one-Session-per-pipeline model,
+// src/server/src/main.rs:24).  That thread may keep several operator calls in flight on DIFFERENT streams as long as each
+// call has its own workspace and outputs: all per-call scratch (incl. the rope cos / sin of a caller-supplied table) lives
+// in the workspace, weights are read-only after finalize().  Exceptions: the dual-stream condition encoder shares one side
+// stream + event pair (switch to throughput tuning first), and per-kernel profiling assumes one call at a time.
 #pragma once
 #include <initializer_list>
 #include <map>
@@ -227,7 +230,6 @@ class Engine {
     EncoderW style_, text_;
     float style_scale_ = 1.f;
     float *rope_dit_cos_ = nullptr, *rope_dit_sin_ = nullptr;  // [MAXPOS][64]
-    float *rope_tmp_cos_ = nullptr, *rope_tmp_sin_ = nullptr;  // cos/sin of a caller-supplied angle table
 
     CodecSpecC cspec_;
     CodecHalfW dec_, enc_;

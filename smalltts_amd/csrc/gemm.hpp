@@ -202,6 +202,7 @@ __device__ __forceinline__ int epi_row(int mb, int r) { return mb + (r & 3) + 8 
 template <int ACT>
 struct EpiStore {
     static constexpr bool PAIRED = false;
+    static constexpr bool STAGE16 = true;
     float* out;
     RowMap omap;
     long o_z;
@@ -238,11 +239,39 @@ struct EpiStore {
         }
     }
     __device__ __forceinline__ void colpair(int, int, const RowCtx&, const floatx16&, const floatx16&) const {}
+    // ---- LDS-staged 16-bit output (gemm3 only, see gemm_epilogue_staged16) ----
+    __device__ __forceinline__ bool stage16_ok() const {   // one 16-bit array, 16-byte aligned rows
+        return ohi != nullptr && !sm_is_split(olo) && (omap.ld % 8) == 0 && (omap.off % 8) == 0 && (omap.bstride % 8) == 0 && (o_z % 8) == 0;
+    }
+    __device__ __forceinline__ bf16_t* out16() const { return ohi; }
+    __device__ __forceinline__ long row_off(int z, int m) const { return (long)z * o_z + omap.at(m); }
+    __device__ __forceinline__ void col16(int z, int n, const RowCtx& rc, const floatx16& acc, unsigned short (&o)[16]) const {
+        const float b = bias ? bias[(long)z * bias_z + n] : 0.f;
+        const bool f16 = sm_is_f16(olo);
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) {
+            float v0 = apply_act<ACT>((acc[r] + b) * scale), v1 = apply_act<ACT>((acc[r + 1] + b) * scale);
+            v0 = rc.aux[r] ? v0 : 0.f;
+            v1 = rc.aux[r + 1] ? v1 : 0.f;
+            unsigned p;
+            if (f16) {
+                p = cvt_pk_f16_sat(v0, v1);
+            } else {
+                bf16x4 t;
+                t[0] = (bf16_t)v0; t[1] = (bf16_t)v1; t[2] = t[0]; t[3] = t[1];
+                p = (*reinterpret_cast<uint2*>(&t)).x;
+            }
+            o[r] = (unsigned short)(p & 0xffffu);
+            o[r + 1] = (unsigned short)(p >> 16);
+        }
+    }
+    __device__ __forceinline__ void colpair16(int, int, const RowCtx&, const floatx16&, const floatx16&, unsigned short (&)[16]) const {}
 };
 
 // SwiGLU on interleaved [w1 | w3] 32-column groups: out[m][nh] = silu(a + b1[nh]) * (b + b3[nh])
 struct EpiSwiGLU {
     static constexpr bool PAIRED = true;
+    static constexpr bool STAGE16 = true;
     float* out;
     long ldo;
     const float* b1;  // may be null
@@ -274,6 +303,30 @@ struct EpiSwiGLU {
             }
         }
     }
+    // ---- LDS-staged 16-bit output ----
+    __device__ __forceinline__ bool stage16_ok() const { return ohi != nullptr && !sm_is_split(olo) && (ldo % 8) == 0; }
+    __device__ __forceinline__ bf16_t* out16() const { return ohi; }
+    __device__ __forceinline__ long row_off(int, int m) const { return (long)m * ldo; }
+    __device__ __forceinline__ void col16(int, int, const RowCtx&, const floatx16&, unsigned short (&)[16]) const {}
+    __device__ __forceinline__ void colpair16(int, int nh, const RowCtx&, const floatx16& a, const floatx16& b, unsigned short (&o)[16]) const {
+        const float v1 = b1 ? b1[nh] : 0.f, v3 = b1 ? b3[nh] : 0.f;
+        const bool f16 = sm_is_f16(olo);
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) {
+            const float x0 = a[r] + v1, x1 = a[r + 1] + v1;
+            const float w0 = silu_f(x0) * (b[r] + v3), w1 = silu_f(x1) * (b[r + 1] + v3);
+            unsigned p;
+            if (f16) {
+                p = cvt_pk_f16_sat(w0, w1);
+            } else {
+                bf16x4 t;
+                t[0] = (bf16_t)w0; t[1] = (bf16_t)w1; t[2] = t[0]; t[3] = t[1];
+                p = (*reinterpret_cast<uint2*>(&t)).x;
+            }
+            o[r] = (unsigned short)(p & 0xffffu);
+            o[r + 1] = (unsigned short)(p >> 16);
+        }
+    }
 };
 
 // x[xmap(m) + n] += mask(m) * g(batch(m), n) * (acc + bias[n])
@@ -282,6 +335,7 @@ struct EpiSwiGLU {
 template <int GATE>
 struct EpiResid {
     static constexpr bool PAIRED = false;
+    static constexpr bool STAGE16 = false;
     float* x;
     RowMap xmap;
     const float* bias;       // may be null
@@ -326,6 +380,7 @@ struct EpiResid {
 // -> dst_kv[layer][b][h][j][d]  (+bias).  K is RMS-normalised afterwards by headnorm_kernel.
 struct EpiKV {
     static constexpr bool PAIRED = false;
+    static constexpr bool STAGE16 = false;
     float* kdst;
     float* vdst;
     const float* bias;  // [n]
@@ -363,6 +418,7 @@ struct EpiKV {
 template <int FINAL>
 struct EpiConvPos {
     static constexpr bool PAIRED = false;
+    static constexpr bool STAGE16 = false;
     float* out;
     const float* h;       // FINAL only
     const float* bias;    // [G*cpg]
@@ -427,6 +483,62 @@ __device__ __forceinline__ void gemm_epilogue(const Epi& epi, floatx16 (&acc)[TM
                 if (n < N) epi.col(z, n, rc, acc[i][j]);
             }
         }
+    }
+}
+
+// 16-bit outputs (the fp16 / bf16 operand of the NEXT GEMM: GELU hidden, SwiGLU hidden) through a wave-private LDS tile.
+// In the MFMA C layout a lane owns ONE column and 16 rows, so writing a [rows][cols] 16-bit array straight from the accumulators
+// takes 16 two-byte stores per 32x32 tile and lane, each touching 64 B of a row: the store issue, not bandwidth, bounded the
+// epilogue of the K = 512 .. 1024 products (profiles/r02*: FF1 of a codec stage 1.9x the time of its FF2 at equal flops and
+// bytes).  Staged: every lane drops its converted values into the wave's [32][W] tile in LDS (W = the wave tile's output
+// width), then the wave reads the tile back row-major in 16-byte pieces and stores those — W / 8 stores per row, 128-byte rows
+// for a 64-wide wave tile.  `stage` = this wave's private region (32 rows x (2 W + 16) bytes; LDS ring of the finished k-loop).
+template <int TM, int TN, class Epi>
+__device__ __forceinline__ void gemm_epilogue_staged16(const Epi& epi, floatx16 (&acc)[TM][TN], int M, int N, int mw0, int nw0,
+                                                       int z, int lane, char* stage) {
+    constexpr int W = Epi::PAIRED ? 32 : TN * 32;   // output columns of one wave tile
+    constexpr int RS = 2 * W + 16;                  // staged row stride in bytes (16-byte pad staggers the banks)
+    constexpr int CH = W / 8;                       // 16-byte pieces per row
+    const int cn = lane & 31, rm = 4 * (lane >> 5);
+    const int ncol0 = Epi::PAIRED ? nw0 / 2 : nw0;  // first output column of the wave tile
+    const int Nout = Epi::PAIRED ? N / 2 : N;
+    bf16_t* const out = epi.out16();
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int mt = mw0 + i * 32;                // first row of this 32-row tile
+        if (mt >= M) continue;
+        RowCtx rc;
+        epi.rows(z, mt + rm, M, rc);
+        if (Epi::PAIRED) {
+            unsigned short o[16];
+            epi.colpair16(z, ncol0 + cn, rc, acc[i][0], acc[i][TN - 1], o);
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                *reinterpret_cast<unsigned short*>(stage + (rm + (r & 3) + 8 * (r >> 2)) * RS + 2 * cn) = o[r];
+        } else {
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                unsigned short o[16];
+                const int n = nw0 + j * 32 + cn;
+                epi.col16(z, n < N ? n : N - 1, rc, acc[i][j], o);
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    *reinterpret_cast<unsigned short*>(stage + (rm + (r & 3) + 8 * (r >> 2)) * RS + 2 * (j * 32 + cn)) = o[r];
+            }
+        }
+        // same wave wrote and reads: LDS operations of one wave complete in order, the wait makes the data visible to the loads
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int c = 0; c < (32 * CH + 63) / 64; ++c) {
+            const int id = c * 64 + lane;
+            const int row = id / CH, ch = id % CH;
+            const int m = mt + row, n0 = ncol0 + ch * 8;
+            if (id < 32 * CH && m < M && n0 < Nout) {   // Nout % 8 == 0 is part of stage16_ok's contract (checked by the caller)
+                const uint4 v = *reinterpret_cast<const uint4*>(stage + row * RS + ch * 16);
+                *reinterpret_cast<uint4*>(out + epi.row_off(z, m) + n0) = v;
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the tile is reused by the next row tile
     }
 }
 

@@ -24,6 +24,7 @@ struct Gemm3Operands {
     long a_z, w_z;
     int w_zmod;
     int nfast = 0;     // tile order inside an XCD's run: 0 = M fastest, 1 = N fastest (set by gemm3_launch)
+    int stage16 = 1;   // 16-bit outputs through the LDS-staged epilogue (set by gemm3_launch from g_gemm3_stage16; A/B switch)
     int ksplit_tiles;  // > 0: blockIdx.z is a split-K index; this launch slice covers k-tiles [z*ksplit_tiles, +ksplit_tiles)
 };
 
@@ -227,6 +228,16 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm3_kernel(Gemm3Operands g, Epi
                 }
         }
     }
+    if constexpr (Epi::STAGE16) {
+        constexpr int W = Epi::PAIRED ? 32 : TN * 32;
+        constexpr int STG = 32 * (2 * W + 16);   // bytes of one wave's staging tile
+        static_assert(NW * STG <= S * STAGE_LD, "staging tiles must fit the finished ring");
+        if (g.stage16 && epi.stage16_ok() && ((Epi::PAIRED ? g.N / 2 : g.N) % 8) == 0) {   // wave-uniform: kernel arguments only
+            __syncthreads();   // every wave has read its last fragments: the ring is free
+            gemm_epilogue_staged16<TM, TN, Epi>(epi, acc, g.M, g.N, m0 + wm * TM * 32, n0 + wn * TN * 32, z, lane, smem + wave * STG);
+            return;
+        }
+    }
     gemm_epilogue<TM, TN, Epi>(epi, acc, g.M, g.N, m0 + wm * TM * 32, n0 + wn * TN * 32, z, lane);
 }
 
@@ -345,6 +356,8 @@ static inline hipError_t gemm3_launch(const Gemm3Operands& g_in, const Epi& epi,
     if (cfg < 0) cfg = gemm3_pick_cfg(g0.M, g0.N, Epi::PAIRED);
     extern int g_gemm3_nfast;
     Gemm3Operands g = g_in;
+    extern int g_gemm3_stage16;
+    g.stage16 = g_gemm3_stage16;
     g.nfast = g_gemm3_nfast && (long)g.M > (long)g.N;  // the bigger operand streams, the smaller stays in L2
     if (split == PREC_BF16X3) return gemm3_launch_split<3, Epi>(g, epi, Z, cfg, st);
     if (split == PREC_F16) return gemm3_launch_split<2, Epi>(g, epi, Z, cfg, st);

@@ -98,6 +98,8 @@ class HipEngine:
     def set_tuning(self, mode: str) -> str:
         """"latency" (default) or "throughput" (several batches in flight on the caller's streams); returns the previous mode."""
         prev = getattr(self, "tuning", "latency")
+        if mode == "throughput" and getattr(self, "_profiling", False):
+            raise RuntimeError("per-kernel profiling is on: it assumes one call at a time (see HipEngine.profile)")
         self._ck(self.lib.smtts_set_tuning(self.h, {"latency": 0, "throughput": 1}[mode]), "set_tuning")
         self.tuning = mode
         return prev
@@ -314,6 +316,10 @@ class HipEngine:
 
     def profile(self, on, tagged: bool = False):
         """on: False/True; tagged=True prefixes kernel names with the pipeline phase (enc, mod, dit, dec.s<i> ...)."""
+        if on and getattr(self, "tuning", "latency") == "throughput":
+            raise RuntimeError("per-kernel profiling pairs HIP events around every launch and assumes ONE call at a time: "
+                               "leave throughput tuning / batches in flight first")
+        self._profiling = bool(on)
         self._ck(self.lib.smtts_profile_enable(self.h, (2 if tagged else 1) if on else 0), "profile_enable")
 
     def profile_report(self):

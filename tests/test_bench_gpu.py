@@ -40,6 +40,7 @@ def test_bench_single_gpu_line_has_the_contract_fields_and_rooflines():
         assert r["phase_roofline"][ph]["ms_per_step"] > 0 and 0 < r["phase_roofline"][ph]["8d"]["mfma_frac"] < 1
     cb = r["cpu_baseline"]
     assert cb["kind"] == "port" and cb["value"] > 0 and cb["cores"] >= 1 and cb["cores_available"] >= cb["cores"] and cb["sample"]
+    assert str(cb["cores"]) in cb["thread_probe_ms"]          # the thread count was chosen by the bounded probe
 
 
 @pytest.mark.parametrize("gather", ["f32", "pcm16"])
