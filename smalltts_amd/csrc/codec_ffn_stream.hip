@@ -61,6 +61,10 @@ __global__ __launch_bounds__(NW * 64) void codec_ffn_stream_kernel(FfnStreamArgs
     constexpr int NOT = C / 32;             // output (channel) tiles
     constexpr int NARR = SPLIT == 3 ? 2 : 1;
     constexpr int NPASS = SPLIT == 3 ? 3 : 1;
+#ifndef FFN_GELU3
+#define FFN_GELU3 1
+#endif
+    constexpr bool G3 = FFN_GELU3 && SPLIT != 3;  // three-term erfc (A&S 7.1.25) where the hidden is rounded to 16 bits anyway
     constexpr int RB1 = 2 * C;              // bytes per W1 row (256 / 512)
     constexpr int CPR1 = RB1 / 16;          // 16-B chunks per W1 row (16 / 32)
     constexpr int W1T = 32 * RB1;           // bytes of one W1 tile image per array (= 64 C)
@@ -217,7 +221,10 @@ __global__ __launch_bounds__(NW * 64) void codec_ffn_stream_kernel(FfnStreamArgs
 
             constexpr int NG1 = P1 ? KK1 : 0, NG2 = P2 ? 2 * NOT : 0, NG = NG1 + NG2, NCH = NG * NPASS;
             // weight fragment of MFMA group g: first product k16 step g, or second product (s, ot) = ((g - NG1) / NOT, (g - NG1) % NOT)
-            constexpr int PFD = C >= 256 ? 3 : 1;  // fragment reads run PFD MFMA groups ahead (PFD + 1 register buffers)
+#ifndef FS_PFD128
+#define FS_PFD128 1
+#endif
+            constexpr int PFD = C >= 256 ? 3 : (SPLIT != 3 ? FS_PFD128 : 1);  // fragment reads run PFD MFMA groups ahead (PFD + 1 register buffers)
             constexpr int NB = PFD + 1;
             bf16x8 wf[NB][2];
             auto read_frag = [&](int g) {
@@ -250,12 +257,13 @@ __global__ __launch_bounds__(NW * 64) void codec_ffn_stream_kernel(FfnStreamArgs
                     const int v = k >> 1;
                     const float x = hr[8 * s2 + v];
                     if (k & 1) ee[v] = __builtin_amdgcn_exp2f((x * x) * (-0.5f * 1.4426950408889634f));
-                    else tt[v] = fast_rcp(fmaf(fabsf(x), 0.3275911f * 0.70710678118654752f, 1.0f));
+                    else tt[v] = fast_rcp(fmaf(fabsf(x), G3 ? Gelu3::P : 0.3275911f * 0.70710678118654752f, 1.0f));
                 } else if (k < 32) {          // S2: erfc polynomial (Horner, 4 fma) | erf and the result (4)
                     const int v = (k - 16) >> 1;
                     if (!(k & 1)) {
                         const float t = tt[v];
-                        tt[v] = t * fmaf(t, fmaf(t, fmaf(t, fmaf(t, 1.061405429f, -1.453152027f), 1.421413741f), -0.284496736f), 0.254829592f);
+                        if (G3) tt[v] = t * fmaf(t, fmaf(t, Gelu3::A3, Gelu3::A2), Gelu3::A1);
+                        else tt[v] = t * fmaf(t, fmaf(t, fmaf(t, fmaf(t, 1.061405429f, -1.453152027f), 1.421413741f), -0.284496736f), 0.254829592f);
                     } else {
                         const float u = fmaf(-tt[v], ee[v], 1.0f);
                         const float hx = 0.5f * hr[8 * s2 + v];
@@ -382,7 +390,10 @@ hipError_t launch_codec_ffn_stream(float* x, RowMap img, const float* norm_w, co
     if (M <= 0) return hipSuccess;
     FfnStreamArgs a{x, img, norm_w, w1hi, w1lo, b1, w2thi, w2tlo, b2, gamma, M, eps};
     ProfScope ps(st, C == 128 ? "codec_ffn_stream<128>" : "codec_ffn_stream<256>", 4.0 * M * (double)C * F, 8.0 * M * C + 8.0 * (double)C * F);
-    if (C == 128) return split == 3 ? ffn_stream_go<128, 3, 8, 4>(a, st) : split == PREC_F16 ? ffn_stream_go<128, 2, 8, 4>(a, st) : ffn_stream_go<128, 1, 8, 4>(a, st);
+#ifndef FS_S128
+#define FS_S128 4
+#endif
+    if (C == 128) return split == 3 ? ffn_stream_go<128, 3, 8, 4>(a, st) : split == PREC_F16 ? ffn_stream_go<128, 2, 8, FS_S128>(a, st) : ffn_stream_go<128, 1, 8, 4>(a, st);
     return split == 3 ? ffn_stream_go<256, 3, 4, 2>(a, st) : split == PREC_F16 ? ffn_stream_go<256, 2, 4, 4>(a, st) : ffn_stream_go<256, 1, 4, 4>(a, st);
 }
 

@@ -57,6 +57,10 @@ __global__ __launch_bounds__(512) void codec_ffn_wave_kernel(FfnWaveArgs a) {
     constexpr int RB1 = 2 * C;             // bytes per W1 row image (64 or 128)
     constexpr int RB2 = 2 * F;             // bytes per W2 row image (256 or 512)
     constexpr int NARR = SPLIT == 3 ? 2 : 1;
+#ifndef FFN_GELU3
+#define FFN_GELU3 1
+#endif
+    constexpr bool G3 = FFN_GELU3 && SPLIT != 3;  // three-term erfc (A&S 7.1.25) where the hidden is rounded to 16 bits anyway
     constexpr int W_ARR = F * RB1;         // = C * RB2 = 8 C^2
     constexpr int OFF_W1 = 0, OFF_W2 = NARR * W_ARR, OFF_V = 2 * NARR * W_ARR;  // then b1[F] b2[C] gamma[C] norm_w[C] (fp32)
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -201,7 +205,7 @@ __global__ __launch_bounds__(512) void codec_ffn_wave_kernel(FfnWaveArgs a) {
             auto trans = [&](int v) {
                 const float xv = (v & 1) ? u[v >> 1].y : u[v >> 1].x;
                 const float av = (v & 1) ? ea[v >> 1].y : ea[v >> 1].x;
-                const float tv = fast_rcp(fmaf(fabsf(xv), 0.3275911f * 0.70710678118654752f, 1.0f));
+                const float tv = fast_rcp(fmaf(fabsf(xv), G3 ? Gelu3::P : 0.3275911f * 0.70710678118654752f, 1.0f));
                 const float ev = __builtin_amdgcn_exp2f(av);
                 if (v & 1) { tt[v >> 1].y = tv; ee[v >> 1].y = ev; } else { tt[v >> 1].x = tv; ee[v >> 1].x = ev; }
             };
@@ -239,7 +243,8 @@ __global__ __launch_bounds__(512) void codec_ffn_wave_kernel(FfnWaveArgs a) {
 #pragma unroll
             for (int pr = 0; pr < 8; ++pr) {
                 const f32x2 t2 = tt[pr];
-                const f32x2 poly = t2 * (0.254829592f + t2 * (-0.284496736f + t2 * (1.421413741f + t2 * (-1.453152027f + t2 * 1.061405429f))));
+                const f32x2 poly = G3 ? t2 * (Gelu3::A1 + t2 * (Gelu3::A2 + t2 * Gelu3::A3))
+                                      : t2 * (0.254829592f + t2 * (-0.284496736f + t2 * (1.421413741f + t2 * (-1.453152027f + t2 * 1.061405429f))));
                 uu[pr] = 1.0f - poly * ee[pr];  // erf(z)
                 hx[pr] = 0.5f * u[pr];
             }

@@ -250,7 +250,12 @@ struct EpiStore {
         const bool f16 = sm_is_f16(olo);
 #pragma unroll
         for (int r = 0; r < 16; r += 2) {
-            float v0 = apply_act<ACT>((acc[r] + b) * scale), v1 = apply_act<ACT>((acc[r + 1] + b) * scale);
+            float v0, v1;
+            if (ACT == ACT_GELU) {   // rounded to 16 bits right below: the three-term erfc is 40x inside that rounding
+                v0 = gelu3_f((acc[r] + b) * scale); v1 = gelu3_f((acc[r + 1] + b) * scale);
+            } else {
+                v0 = apply_act<ACT>((acc[r] + b) * scale); v1 = apply_act<ACT>((acc[r + 1] + b) * scale);
+            }
             v0 = rc.aux[r] ? v0 : 0.f;
             v1 = rc.aux[r + 1] ? v1 : 0.f;
             unsigned p;
