@@ -48,8 +48,18 @@ struct FfnWaveArgs {
     float eps;
 };
 
-template <int C, int SPLIT>
-__global__ __launch_bounds__(512) void codec_ffn_wave_kernel(FfnWaveArgs a) {
+// NWV = waves per workgroup.  The waves never synchronise after the weights are in LDS, so the workgroup size only sets how many
+// waves share one LDS copy of the weights — and how the register file divides: at C = 32 the single-array formats need 140
+// registers (3 waves per SIMD), which 8-wave workgroups cannot use (one fits, 2 per SIMD); 4-wave workgroups pack three per CU.
+#ifndef FW_NWV64
+#define FW_NWV64 8
+#endif
+#ifndef FW_MINW64
+#define FW_MINW64 2
+#endif
+template <int C, int SPLIT, int NWV>
+__global__ __launch_bounds__(NWV * 64, (C == 64 && SPLIT != 3 && NWV == 4) ? FW_MINW64 : 1) void codec_ffn_wave_kernel(FfnWaveArgs a) {
+    constexpr int NT = NWV * 64;
     constexpr int F = 4 * C;
     constexpr int KK1 = C / 16;            // k16 steps of the first product
     constexpr int NT1 = F / 32;            // 32-row hidden tiles
@@ -70,14 +80,14 @@ __global__ __launch_bounds__(512) void codec_ffn_wave_kernel(FfnWaveArgs a) {
 
     auto swz1 = [](int r) { return RB1 == 128 ? ((r >> 1) & 7) : ((r >> 2) & 3); };
     // ---- one-time: weight images into LDS (16-B chunks XOR-swizzled so every fragment read is conflict free) ----
-    for (int i = tid; i < F * (C / 8); i += 512) {
+    for (int i = tid; i < F * (C / 8); i += NT) {
         const int r = i / (C / 8), ch = i % (C / 8);
         const int dst = r * RB1 + ((ch ^ swz1(r)) << 4);
         *reinterpret_cast<uint4*>(smem + OFF_W1 + dst) = *reinterpret_cast<const uint4*>(a.w1hi + (long)r * a.ld1 + ch * 8);
         if (SPLIT == 3)
             *reinterpret_cast<uint4*>(smem + OFF_W1 + W_ARR + dst) = *reinterpret_cast<const uint4*>(a.w1lo + (long)r * a.ld1 + ch * 8);
     }
-    for (int i = tid; i < C * (F / 8); i += 512) {
+    for (int i = tid; i < C * (F / 8); i += NT) {
         const int r = i / (F / 8), ch = i % (F / 8);
         const int dst = r * RB2 + (((ch & ~15) | ((ch ^ r) & 15)) << 4);
         *reinterpret_cast<uint4*>(smem + OFF_W2 + dst) = *reinterpret_cast<const uint4*>(a.w2hi + (long)r * F + ch * 8);
@@ -88,8 +98,8 @@ __global__ __launch_bounds__(512) void codec_ffn_wave_kernel(FfnWaveArgs a) {
     float* vb2 = vb1 + F;
     float* vga = vb2 + C;
     float* vnw = vga + C;
-    for (int i = tid; i < F; i += 512) vb1[i] = a.b1[i];
-    for (int i = tid; i < C; i += 512) { vb2[i] = a.b2[i]; vga[i] = a.gamma[i]; vnw[i] = a.norm_w[i]; }
+    for (int i = tid; i < F; i += NT) vb1[i] = a.b1[i];
+    for (int i = tid; i < C; i += NT) { vb2[i] = a.b2[i]; vga[i] = a.gamma[i]; vnw[i] = a.norm_w[i]; }
     __syncthreads();
 
     // fragment byte offsets (constant for the kernel)
@@ -107,7 +117,7 @@ __global__ __launch_bounds__(512) void codec_ffn_wave_kernel(FfnWaveArgs a) {
     constexpr int NPASS = SPLIT == 3 ? 3 : 1;
 
     const int ntiles = (a.M + 31) / 32;
-    const int wg = blockIdx.x * 8 + wave, nwg = gridDim.x * 8;
+    const int wg = blockIdx.x * NWV + wave, nwg = gridDim.x * NWV;
 
     // channel of element e (0..7) of k16 step kk in this lane's B fragment: 16 kk + 8 fh + e
     float4 xa[KK1][2];  // raw x of the tile being prefetched / computed
@@ -383,11 +393,15 @@ __global__ __launch_bounds__(512) void codec_ffn_wave_kernel(FfnWaveArgs a) {
     }
 }
 
+#ifndef FW_NWV32
+#define FW_NWV32 4
+#endif
 template <int C, int SPLIT>
 static hipError_t ffn_wave_go(const FfnWaveArgs& a, hipStream_t st) {
+    constexpr int NWV = (C == 32 && SPLIT != 3) ? FW_NWV32 : (C == 64 && SPLIT != 3) ? FW_NWV64 : 8;
     constexpr size_t lds = (size_t)(SPLIT == 3 ? 2 : 1) * 2 * (8 * C * C) + (size_t)(4 * C + 3 * C) * 4;
     static_assert(lds <= 160 * 1024, "weights must fit LDS");
-    auto kern = codec_ffn_wave_kernel<C, SPLIT>;
+    auto kern = codec_ffn_wave_kernel<C, SPLIT, NWV>;
     static DevOnce once;
     int cus = 256;
     hipError_t e = once.ensure([&] {
@@ -395,10 +409,13 @@ static hipError_t ffn_wave_go(const FfnWaveArgs& a, hipStream_t st) {
     }, &cus);
     if (e != hipSuccess) return e;
     const int ntiles = (a.M + 31) / 32;
-    const int per_cu = lds * 2 <= 160 * 1024 ? 2 : 1;  // persistent: as many workgroups as fit, each wave walks tiles
-    int grid = (ntiles + 7) / 8;
+    // persistent: as many workgroups as fit (LDS, and 32 waves per CU), each wave walks tiles
+    int per_cu = (int)((160 * 1024) / lds);
+    per_cu = per_cu > 32 / NWV ? 32 / NWV : per_cu;
+    per_cu = per_cu > (NWV == 8 ? 2 : 4) ? (NWV == 8 ? 2 : 4) : per_cu;
+    int grid = (ntiles + NWV - 1) / NWV;
     grid = grid < cus * per_cu ? grid : cus * per_cu;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, a);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(NWV * 64), lds, st, a);
     return hipGetLastError();
 }
 
