@@ -49,8 +49,10 @@ struct FfnWaveArgs {
 };
 
 // NWV = waves per workgroup.  The waves never synchronise after the weights are in LDS, so the workgroup size only sets how many
-// waves share one LDS copy of the weights — and how the register file divides: at C = 32 the single-array formats need 140
-// registers (3 waves per SIMD), which 8-wave workgroups cannot use (one fits, 2 per SIMD); 4-wave workgroups pack three per CU.
+// waves share one LDS copy of the weights and how the register file divides.  Measured (profiles/r02f_ab_wave_occupancy.txt):
+// more waves per SIMD do NOT help these kernels — C = 32 with 4-wave workgroups (116 registers, 16 waves per CU) 175 us against
+// 157 us with 8-wave workgroups (8 waves per CU); C = 64 forced to 168 registers (3 waves per SIMD, 208 B of scratch) 294 us
+// against 184 us — so both keep one 8-wave workgroup per CU (the macros stay for A/B builds).
 #ifndef FW_NWV64
 #define FW_NWV64 8
 #endif
@@ -394,7 +396,7 @@ __global__ __launch_bounds__(NWV * 64, (C == 64 && SPLIT != 3 && NWV == 4) ? FW_
 }
 
 #ifndef FW_NWV32
-#define FW_NWV32 4
+#define FW_NWV32 8
 #endif
 template <int C, int SPLIT>
 static hipError_t ffn_wave_go(const FfnWaveArgs& a, hipStream_t st) {
