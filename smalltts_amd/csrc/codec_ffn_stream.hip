@@ -214,7 +214,9 @@ __global__ __launch_bounds__(NW * 64) void codec_ffn_stream_kernel(FfnStreamArgs
                 wait_vmcnt<(S - 2) * PW>();
             else
                 wait_vmcnt<0>();
+#ifndef FS_NOBARRIER   // (timing experiment only: without the barrier the ring hand-over is a data race)
             __builtin_amdgcn_s_barrier();  // everybody's pieces of slot `it` landed; everybody left slot it-1 -> it is free
+#endif
             if (it + S - 1 < total) issue(it + S - 1);
             const char* sl = smem + (it % S) * SLOT;
             ++it;
@@ -377,7 +379,10 @@ static hipError_t ffn_stream_go(const FfnStreamArgs& a, hipStream_t st) {
     }, &cus);
     if (e != hipSuccess) return e;
     const int npass = (a.M + NW * 32 - 1) / (NW * 32);
-    const int grid = npass < cus ? npass : cus;
+    // NW = 4 (one wave per SIMD per workgroup): two workgroups share a CU when the ring is small enough — their steps drift
+    // freely against each other, only the four waves of one ring meet at its barrier
+    const int per_cu = (NW == 4 && 2 * lds <= 160 * 1024 && C == 128) ? 2 : 1;
+    const int grid = npass < cus * per_cu ? npass : cus * per_cu;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), lds, st, a);
     return hipGetLastError();
 }
@@ -393,7 +398,10 @@ hipError_t launch_codec_ffn_stream(float* x, RowMap img, const float* norm_w, co
 #ifndef FS_S128
 #define FS_S128 4
 #endif
-    if (C == 128) return split == 3 ? ffn_stream_go<128, 3, 8, 4>(a, st) : split == PREC_F16 ? ffn_stream_go<128, 2, 8, FS_S128>(a, st) : ffn_stream_go<128, 1, 8, 4>(a, st);
+#ifndef FS_NW128
+#define FS_NW128 8
+#endif
+    if (C == 128) return split == 3 ? ffn_stream_go<128, 3, 8, 4>(a, st) : split == PREC_F16 ? ffn_stream_go<128, 2, FS_NW128, FS_S128>(a, st) : ffn_stream_go<128, 1, 8, 4>(a, st);
     return split == 3 ? ffn_stream_go<256, 3, 4, 2>(a, st) : split == PREC_F16 ? ffn_stream_go<256, 2, 4, 4>(a, st) : ffn_stream_go<256, 1, 4, 4>(a, st);
 }
 

@@ -41,6 +41,7 @@ Engine::Engine(int device) : device_(device) {
     if (const char* t1 = getenv("SMTTS_GEMM_T160")) g_gemm3_t160 = atoi(t1);
     const char* s = getenv("SMTTS_SINGLE_STREAM");
     if (s && *s == '1') dual_stream_ = false;
+    if ((s = getenv("SMTTS_UP_G3_MINK")) && atoi(s) >= 64) up_g3_mink_ = atoi(s);
     if ((s = getenv("SMTTS_KSPLIT_OUT")) && atoi(s) >= 1 && atoi(s) <= kSplitK) ksplit_out_ = atoi(s);
     if ((s = getenv("SMTTS_KSPLIT_ENC")) && atoi(s) >= 1 && atoi(s) <= kSplitK) ksplit_enc_ = atoi(s);
     if ((s = getenv("SMTTS_KSPLIT_FF2")) && atoi(s) >= 1 && atoi(s) <= kSplitK) ksplit_ff2_ = atoi(s);
@@ -1333,7 +1334,7 @@ int Engine::codec_decode(hipStream_t st, const float* latents, int B, int T, flo
             if (fused_ffn_ && codec_upsample_wave_ok(sg.resample.K, sg.resample.N) && sg.resample.K == 2 * C && sg.resample.N == r * Cn)
                 HIPC(launch_codec_upsample_wave(x, am, sg.resample.hi, sg.resample.lo, sg.resample.K, sg.resample_bias, xn, om,
                                                 B * Ti, sg.resample.K, sg.resample.N, pcv3, st));
-            else if (fused_ffn_ && sg.resample.K % 64 == 0 && sg.resample.K >= 2048 && C % 8 == 0 && (size_t)B * (pad + Ti) * C <= max_img) {
+            else if (fused_ffn_ && sg.resample.K % 64 == 0 && sg.resample.K >= up_g3_mink_ && C % 8 == 0 && (size_t)B * (pad + Ti) * C <= max_img) {
                 // widest stages (K >= 2048; measured: 215 -> 148 us and 216 -> 193 us, no gain at K <= 1024): split the image once (pads included: they are the causal zeros) and run the DMA-ring GEMM on
                 // the overlapping rows of the split pair (n2 is free between blocks)
                 SplitBuf xs{w.n2hi, w.n2lo};
