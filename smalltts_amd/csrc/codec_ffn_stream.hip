@@ -297,7 +297,55 @@ __global__ __launch_bounds__(NW * 64) void codec_ffn_stream_kernel(FfnStreamArgs
                     }
                 }
             };
-            constexpr int NTASK = 84;
+            // ---- the same GELU for the single-array formats (FFN_PKGELU): with a third of the MFMAs the kernel is bound by the NUMBER of
+            // vector instructions it issues (SQ counters: profiles/r02d_pmc_codec_ffn_f16.txt), so value PAIRS go through v_pk_mul / v_pk_fma
+            // wherever no |.| modifier is needed — 70 instructions per 8 values instead of 110 — accepting that a packed fp32
+            // instruction does not run in an MFMA's shadow (the matrix pipe is busy 22 % of the time here, 48 % at split-bf16).
+            // 25 tasks per half: S1a x8 (t = rcp(1 + p|x|)), S1b x4 pairs (e = exp2(-x^2 c)), S2a x4 pairs (packed erfc polynomial, u, x/2),
+            // S2b x4 pairs (result = x/2 + |x/2| u), S3 x4 pairs (convert + saturate), lane swap.
+            f32x2s tp[4], ep[4], up[4], hp[4];
+            auto task_pk = [&](int k0) {
+                const int s2 = k0 / 25, k = k0 % 25;
+                if (k < 8) {
+                    const float x = hr[8 * s2 + k];
+                    const float t = fast_rcp(fmaf(fabsf(x), Gelu3::P, 1.0f));
+                    if (k & 1) tp[k >> 1].y = t; else tp[k >> 1].x = t;
+                } else if (k < 12) {
+                    const int j = k - 8;
+                    f32x2s xx;
+                    xx.x = hr[8 * s2 + 2 * j]; xx.y = hr[8 * s2 + 2 * j + 1];
+                    const f32x2s a = (xx * xx) * (-0.5f * 1.4426950408889634f);
+                    ep[j].x = __builtin_amdgcn_exp2f(a.x); ep[j].y = __builtin_amdgcn_exp2f(a.y);
+                } else if (k < 16) {
+                    const int j = k - 12;
+                    f32x2s xx;
+                    xx.x = hr[8 * s2 + 2 * j]; xx.y = hr[8 * s2 + 2 * j + 1];
+                    const f32x2s t = tp[j];
+                    const f32x2s poly = t * (Gelu3::A1 + t * (Gelu3::A2 + t * Gelu3::A3));
+                    up[j] = 1.0f - poly * ep[j];
+                    hp[j] = 0.5f * xx;
+                } else if (k < 20) {
+                    const int j = k - 16;
+                    tt[2 * j] = fmaf(fabsf(hp[j].x), up[j].x, hp[j].x);
+                    tt[2 * j + 1] = fmaf(fabsf(hp[j].y), up[j].y, hp[j].y);
+                } else if (k < 24) {
+                    const int j = k - 20;
+                    hiP[j] = SPLIT == PREC_F16 ? cvt_pk_f16_satpos(tt[2 * j], tt[2 * j + 1]) : cvt_pk_bf16s(tt[2 * j], tt[2 * j + 1]);
+                } else {
+                    unsigned fhh[4];
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        auto rh = __builtin_amdgcn_permlane32_swap(hiP[e], hiP[2 + e], false, false);
+                        fhh[e] = rh[0]; fhh[2 + e] = rh[1];
+                    }
+                    fw.h[s2] = __builtin_bit_cast(bf16x8, *reinterpret_cast<uint4*>(fhh));
+                }
+            };
+#ifndef FFN_PKGELU
+#define FFN_PKGELU 1
+#endif
+            constexpr bool PK = FFN_PKGELU && G3;
+            constexpr int NTASK = PK ? 50 : 84;
             if (NG == 0) {
                 // (no such step: the first step has P1, the last has P2)
             }
@@ -321,7 +369,9 @@ __global__ __launch_bounds__(NW * 64) void codec_ffn_stream_kernel(FfnStreamArgs
                     }
                     if (G)
 #pragma unroll
-                        for (int k = NTASK * c / NCH; k < NTASK * (c + 1) / NCH; ++k) task(k);
+                        for (int k = NTASK * c / NCH; k < NTASK * (c + 1) / NCH; ++k) {
+                            if constexpr (PK) task_pk(k); else task(k);
+                        }
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
