@@ -297,39 +297,24 @@ __global__ __launch_bounds__(NW * 64) void codec_ffn_stream_kernel(FfnStreamArgs
                     }
                 }
             };
-            // ---- the same GELU for the single-array formats (FFN_PKGELU): with a third of the MFMAs the kernel is bound by the NUMBER of
-            // vector instructions it issues (SQ counters: profiles/r02d_pmc_codec_ffn_f16.txt), so value PAIRS go through v_pk_mul / v_pk_fma
-            // wherever no |.| modifier is needed — 70 instructions per 8 values instead of 110 — accepting that a packed fp32
-            // instruction does not run in an MFMA's shadow (the matrix pipe is busy 22 % of the time here, 48 % at split-bf16).
-            // 25 tasks per half: S1a x8 (t = rcp(1 + p|x|)), S1b x4 pairs (e = exp2(-x^2 c)), S2a x4 pairs (packed erfc polynomial, u, x/2),
-            // S2b x4 pairs (result = x/2 + |x/2| u), S3 x4 pairs (convert + saturate), lane swap.
-            f32x2s tp[4], ep[4], up[4], hp[4];
-            auto task_pk = [&](int k0) {
-                const int s2 = k0 / 25, k = k0 % 25;
-                if (k < 8) {
-                    const float x = hr[8 * s2 + k];
-                    const float t = fast_rcp(fmaf(fabsf(x), Gelu3::P, 1.0f));
-                    if (k & 1) tp[k >> 1].y = t; else tp[k >> 1].x = t;
-                } else if (k < 12) {
-                    const int j = k - 8;
-                    f32x2s xx;
-                    xx.x = hr[8 * s2 + 2 * j]; xx.y = hr[8 * s2 + 2 * j + 1];
-                    const f32x2s a = (xx * xx) * (-0.5f * 1.4426950408889634f);
-                    ep[j].x = __builtin_amdgcn_exp2f(a.x); ep[j].y = __builtin_amdgcn_exp2f(a.y);
-                } else if (k < 16) {
-                    const int j = k - 12;
-                    f32x2s xx;
-                    xx.x = hr[8 * s2 + 2 * j]; xx.y = hr[8 * s2 + 2 * j + 1];
-                    const f32x2s t = tp[j];
-                    const f32x2s poly = t * (Gelu3::A1 + t * (Gelu3::A2 + t * Gelu3::A3));
-                    up[j] = 1.0f - poly * ep[j];
-                    hp[j] = 0.5f * xx;
-                } else if (k < 20) {
-                    const int j = k - 16;
-                    tt[2 * j] = fmaf(fabsf(hp[j].x), up[j].x, hp[j].x);
-                    tt[2 * j + 1] = fmaf(fabsf(hp[j].y), up[j].y, hp[j].y);
+            // ---- GELU for the single-array formats: GeluQ5 (common.hpp) — max(x, 0) - |x| 2^q(|x|), q of degree 5: 8 plain VALU
+            // instructions and ONE transcendental per value (A&S: 13 / 11 and two).  With a third of the MFMAs these kernels are bound
+            // by what their waves issue between MFMAs (SQ counters: profiles/r02d_pmc_codec_ffn_f16.txt), and packing value pairs
+            // into v_pk_* did not help (profiles/r02i_ab_packed_gelu.txt: a packed fp32 instruction costs two plain ones here).
+            // 29 tasks per half: Horner in two parts x8, exp2 + result x8 ... convert + saturate x4 pairs, lane swap.
+            auto task_q5 = [&](int k0) {
+                const int s2 = k0 / 29, k = k0 % 29;
+                if (k < 16) {
+                    const int v = k >> 1;
+                    const float ax = fabsf(hr[8 * s2 + v]);
+                    if (!(k & 1)) tt[v] = fmaf(fmaf(fmaf(GeluQ5::Q5, ax, GeluQ5::Q4), ax, GeluQ5::Q3), ax, GeluQ5::Q2);
+                    else ee[v] = __builtin_amdgcn_exp2f(fmaf(fmaf(tt[v], ax, GeluQ5::Q1), ax, GeluQ5::Q0));
                 } else if (k < 24) {
-                    const int j = k - 20;
+                    const int v = k - 16;
+                    const float x = hr[8 * s2 + v];
+                    tt[v] = fmaf(-fabsf(x), ee[v], relu_f(x));
+                } else if (k < 28) {
+                    const int j = k - 24;
                     hiP[j] = SPLIT == PREC_F16 ? cvt_pk_f16_satpos(tt[2 * j], tt[2 * j + 1]) : cvt_pk_bf16s(tt[2 * j], tt[2 * j + 1]);
                 } else {
                     unsigned fhh[4];
@@ -341,11 +326,11 @@ __global__ __launch_bounds__(NW * 64) void codec_ffn_stream_kernel(FfnStreamArgs
                     fw.h[s2] = __builtin_bit_cast(bf16x8, *reinterpret_cast<uint4*>(fhh));
                 }
             };
-#ifndef FFN_PKGELU
-#define FFN_PKGELU 1
+#ifndef FFN_GELUQ5
+#define FFN_GELUQ5 1
 #endif
-            constexpr bool PK = FFN_PKGELU && G3;
-            constexpr int NTASK = PK ? 50 : 84;
+            constexpr bool PK = FFN_GELUQ5 && G3;
+            constexpr int NTASK = PK ? 58 : 84;
             if (NG == 0) {
                 // (no such step: the first step has P1, the last has P2)
             }
@@ -370,7 +355,7 @@ __global__ __launch_bounds__(NW * 64) void codec_ffn_stream_kernel(FfnStreamArgs
                     if (G)
 #pragma unroll
                         for (int k = NTASK * c / NCH; k < NTASK * (c + 1) / NCH; ++k) {
-                            if constexpr (PK) task_pk(k); else task(k);
+                            if constexpr (PK) task_q5(k); else task(k);
                         }
                 }
             }

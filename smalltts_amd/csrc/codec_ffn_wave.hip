@@ -73,6 +73,12 @@ __global__ __launch_bounds__(NWV * 64, (C == 64 && SPLIT != 3 && NWV == 4) ? FW_
 #define FFN_GELU3 1
 #endif
     constexpr bool G3 = FFN_GELU3 && SPLIT != 3;  // three-term erfc (A&S 7.1.25) where the hidden is rounded to 16 bits anyway
+#ifndef FFN_GELUQ5
+#define FFN_GELUQ5 1
+#endif
+    // GeluQ5 (common.hpp): max(x, 0) - |x| 2^q(|x|) — 8 plain instructions, one transcendental, no packed phases: replaces the
+    // A / B / C / D split below for the single-array formats (B = Horner + exp2 under the first product, D = result + convert)
+    constexpr bool Q5 = FFN_GELUQ5 && SPLIT != 3;
     constexpr int W_ARR = F * RB1;         // = C * RB2 = 8 C^2
     constexpr int OFF_W1 = 0, OFF_W2 = NARR * W_ARR, OFF_V = 2 * NARR * W_ARR;  // then b1[F] b2[C] gamma[C] norm_w[C] (fp32)
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -209,17 +215,28 @@ __global__ __launch_bounds__(NWV * 64, (C == 64 && SPLIT != 3 && NWV == 4) ? FW_
 #pragma unroll
             for (int pr = 0; pr < 8; ++pr) {
                 u[pr].x = h[2 * pr]; u[pr].y = h[2 * pr + 1];
-                ea[pr] = (u[pr] * u[pr]) * (-0.5f * 1.4426950408889634f);  // exp(-z^2) = exp2(-x^2/2 log2 e)
+                if constexpr (!Q5) ea[pr] = (u[pr] * u[pr]) * (-0.5f * 1.4426950408889634f);  // exp(-z^2) = exp2(-x^2/2 log2 e)
             }
             __builtin_amdgcn_sched_barrier(0);
             // ---- B: first product of tile t+1 || t = 1 / (1 + p z), e = exp2(.) of the 16 values ----
             f32x2 tt[8], ee[8];
             auto trans = [&](int v) {
                 const float xv = (v & 1) ? u[v >> 1].y : u[v >> 1].x;
-                const float av = (v & 1) ? ea[v >> 1].y : ea[v >> 1].x;
-                const float tv = fast_rcp(fmaf(fabsf(xv), G3 ? Gelu3::P : 0.3275911f * 0.70710678118654752f, 1.0f));
-                const float ev = __builtin_amdgcn_exp2f(av);
-                if (v & 1) { tt[v >> 1].y = tv; ee[v >> 1].y = ev; } else { tt[v >> 1].x = tv; ee[v >> 1].x = ev; }
+                if constexpr (Q5) {
+                    const float ax = fabsf(xv);
+                    float q = fmaf(GeluQ5::Q5, ax, GeluQ5::Q4);
+                    q = fmaf(q, ax, GeluQ5::Q3);
+                    q = fmaf(q, ax, GeluQ5::Q2);
+                    q = fmaf(q, ax, GeluQ5::Q1);
+                    q = fmaf(q, ax, GeluQ5::Q0);
+                    const float ev = __builtin_amdgcn_exp2f(q);
+                    if (v & 1) ee[v >> 1].y = ev; else ee[v >> 1].x = ev;
+                } else {
+                    const float av = (v & 1) ? ea[v >> 1].y : ea[v >> 1].x;
+                    const float tv = fast_rcp(fmaf(fabsf(xv), G3 ? Gelu3::P : 0.3275911f * 0.70710678118654752f, 1.0f));
+                    const float ev = __builtin_amdgcn_exp2f(av);
+                    if (v & 1) { tt[v >> 1].y = tv; ee[v >> 1].y = ev; } else { tt[v >> 1].x = tv; ee[v >> 1].x = ev; }
+                }
             };
             if (P1) {
                 constexpr int NB = KK1 * NPASS;
@@ -252,6 +269,7 @@ __global__ __launch_bounds__(NWV * 64, (C == 64 && SPLIT != 3 && NWV == 4) ? FW_
             __builtin_amdgcn_sched_barrier(0);
             // ---- C (packed): erfc polynomial, erf, x / 2 ----
             f32x2 uu[8], hx[8];
+            if constexpr (!Q5)
 #pragma unroll
             for (int pr = 0; pr < 8; ++pr) {
                 const f32x2 t2 = tt[pr];
@@ -264,8 +282,14 @@ __global__ __launch_bounds__(NWV * 64, (C == 64 && SPLIT != 3 && NWV == 4) ? FW_
             // ---- D: second product of tile t-1 || gelu = x/2 + |x/2| erf, bf16 split, lane swap -> fragments of tile t ----
             unsigned hiP[8], loP[8];
             auto finish = [&](int pr) {
-                const float rx = fmaf(fabsf(hx[pr].x), uu[pr].x, hx[pr].x);
-                const float ry = fmaf(fabsf(hx[pr].y), uu[pr].y, hx[pr].y);
+                float rx, ry;
+                if constexpr (Q5) {
+                    rx = fmaf(-fabsf(u[pr].x), ee[pr].x, relu_f(u[pr].x));
+                    ry = fmaf(-fabsf(u[pr].y), ee[pr].y, relu_f(u[pr].y));
+                } else {
+                    rx = fmaf(fabsf(hx[pr].x), uu[pr].x, hx[pr].x);
+                    ry = fmaf(fabsf(hx[pr].y), uu[pr].y, hx[pr].y);
+                }
                 hiP[pr] = SPLIT == PREC_F16 ? cvt_pk_f16_satpos(rx, ry) : cvt_pk_bf16(rx, ry);
                 if (SPLIT == 3) {
                     f32x2 rr, hf;

@@ -85,8 +85,12 @@ __device__ __forceinline__ float gelu_f(float x) {
     const float hx = 0.5f * x;
     return fmaf(fabsf(hx), 1.0f - poly * e, hx);
 }
-// The same with the three-term form A&S 7.1.25 (|erf error| <= 2.5e-5, i.e. |gelu error| <= 1.25e-5 |x|): two fma fewer per
-// value.  Used where the result is rounded to a 16-bit GEMM operand anyway (fp16: 4.9e-4 relative) — 40x below that rounding.
+// GELU for values that are rounded to a 16-bit GEMM operand right afterwards (fp16: 4.9e-4 relative).  Two cheaper forms:
+// * Gelu3: the three-term A&S 7.1.25 erfc (|gelu error| <= 1.25e-5 |x|): two fma fewer than gelu_f, still rcp + exp2;
+// * GeluQ5: gelu(x) = max(x, 0) - |x| g(|x|) with g(a) = Phi(-a) = erfc(a / sqrt 2) / 2 = 2^q(a), q a degree-5 polynomial fitted
+//   for the absolute error of a g(a) (tests/studies/gelu_q5_fit.py): |gelu error| <= 2.1e-6 for ALL x (fp32 evaluation, the
+//   leading coefficient is negative so large |x| extrapolates to exactly max(x, 0)); 5 fma + exp2 + max + fma = 8
+//   instructions with ONE transcendental and no reciprocal — against 13 (two transcendentals) for gelu_f.
 struct Gelu3 {   // constants shared by the fused FFN kernels' hand-scheduled copies of this formula
     static constexpr float P = 0.47047f * 0.70710678118654752f, A1 = 0.3480242f, A2 = -0.0958798f, A3 = 0.7478556f;
 };
@@ -96,6 +100,26 @@ __device__ __forceinline__ float gelu3_f(float x) {
     const float e = __builtin_amdgcn_exp2f((x * x) * (-0.5f * 1.4426950408889634f));
     const float hx = 0.5f * x;
     return fmaf(fabsf(hx), 1.0f - poly * e, hx);
+}
+struct GeluQ5 {
+    static constexpr float Q0 = -1.000138521194458f, Q1 = -1.1501970291137695f, Q2 = -0.46113213896751404f,
+                           Q3 = -0.050880067050457f, Q4 = 0.006735440343618393f, Q5 = -0.00042676751036196947f;
+};
+// max(x, 0) in ONE instruction: fmaxf() makes hipcc canonicalise an operand it cannot prove quiet (an MFMA accumulator) with an
+// extra v_max x, x
+__device__ __forceinline__ float relu_f(float x) {
+    float r;
+    asm("v_max_f32 %0, 0, %1" : "=v"(r) : "v"(x));
+    return r;
+}
+__device__ __forceinline__ float gelu_q5_f(float x) {
+    const float a = fabsf(x);
+    float q = fmaf(GeluQ5::Q5, a, GeluQ5::Q4);
+    q = fmaf(q, a, GeluQ5::Q3);
+    q = fmaf(q, a, GeluQ5::Q2);
+    q = fmaf(q, a, GeluQ5::Q1);
+    q = fmaf(q, a, GeluQ5::Q0);
+    return fmaf(-a, __builtin_amdgcn_exp2f(q), relu_f(x));
 }
 __device__ __forceinline__ float mish_f(float x) {
     // x * tanh(softplus(x)); softplus with torch's threshold (20) for parity

@@ -251,8 +251,8 @@ struct EpiStore {
 #pragma unroll
         for (int r = 0; r < 16; r += 2) {
             float v0, v1;
-            if (ACT == ACT_GELU) {   // rounded to 16 bits right below: the three-term erfc is 40x inside that rounding
-                v0 = gelu3_f((acc[r] + b) * scale); v1 = gelu3_f((acc[r + 1] + b) * scale);
+            if (ACT == ACT_GELU) {   // rounded to 16 bits right below: GeluQ5's 2e-6 absolute error is far inside that rounding
+                v0 = gelu_q5_f((acc[r] + b) * scale); v1 = gelu_q5_f((acc[r + 1] + b) * scale);
             } else {
                 v0 = apply_act<ACT>((acc[r] + b) * scale); v1 = apply_act<ACT>((acc[r + 1] + b) * scale);
             }
