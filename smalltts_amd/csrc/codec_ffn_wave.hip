@@ -169,6 +169,20 @@ __global__ __launch_bounds__(NWV * 64, (C == 64 && SPLIT != 3 && NWV == 4) ? FW_
             nl[kk] = __builtin_bit_cast(bf16x8, *reinterpret_cast<uint4*>(nlp));
         }
         const int m_cur = wt * 32 + fr;
+#ifndef FW_KEEPX
+#define FW_KEEPX 1
+#endif
+        // The residual add needs this tile's x again.  Re-reading it in the epilogue made the C = 32 / 64 kernels move 3 |x| per
+        // launch (read, re-read, write) at 4.0-4.6 TB/s — they were HBM-bound, which is why neither fewer VALU instructions nor more
+        // waves moved them (profiles/r02j_*, r02f_*).  The tile stays in registers instead (C / 2 per lane) and is brought from the
+        // B-fragment layout (8 consecutive channels per lane half) into the accumulator layout (4-channel groups) by one
+        // v_permlane32_swap per register in the epilogue.
+        constexpr bool KEEPX = FW_KEEPX && (SPLIT != 3 || C == 32);   // (C = 64 at split-bf16 is out of registers: it re-reads)
+        float4 xk[KK1][2];
+        if (KEEPX) {
+#pragma unroll
+            for (int kk = 0; kk < KK1; ++kk) { xk[kk][0] = xa[kk][0]; xk[kk][1] = xa[kk][1]; }
+        }
         if (wt + nwg < ntiles) load_tile(wt + nwg);  // next tile's x arrives under this tile's MFMA / GELU work
 
         floatx16 acc2[NOT];
@@ -397,10 +411,30 @@ __global__ __launch_bounds__(NWV * 64, (C == 64 && SPLIT != 3 && NWV == 4) ? FW_
         if (m_cur < a.M) {
             float* xr = a.x + a.img.at(m_cur);
             float4 xo[NOT][4];
+            if (KEEPX) {
+                // xk[kk][h2] holds channels 16 kk + 8 fh + 4 h2 + (0..3); the accumulator rows 4 q .. 4 q + 3 of channel tile ot are
+                // channels 32 ot + 8 q + 4 fh + (0..3) = 16 kk' + 8 (q & 1) + 4 fh + (0..3), kk' = 2 ot + q / 2.  Swapping the upper lane
+                // half of xk[kk'][0] with the lower lane half of xk[kk'][1] leaves {fh 0: +0..3, fh 1: +4..7} in the first and
+                // {fh 0: +8..11, fh 1: +12..15} in the second: exactly q even / q odd for both lane halves.
 #pragma unroll
-            for (int ot = 0; ot < NOT; ++ot)
+                for (int kk = 0; kk < KK1; ++kk) {
+                    float xe[4], xo2[4];
+                    const float a0[4] = {xk[kk][0].x, xk[kk][0].y, xk[kk][0].z, xk[kk][0].w};
+                    const float a1[4] = {xk[kk][1].x, xk[kk][1].y, xk[kk][1].z, xk[kk][1].w};
 #pragma unroll
-                for (int q = 0; q < 4; ++q) xo[ot][q] = *reinterpret_cast<const float4*>(xr + 32 * ot + 8 * q + 4 * fh);
+                    for (int e = 0; e < 4; ++e) {
+                        auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a0[e]), __float_as_uint(a1[e]), false, false);
+                        xe[e] = __uint_as_float(r[0]); xo2[e] = __uint_as_float(r[1]);
+                    }
+                    xo[kk / 2][2 * (kk % 2)] = make_float4(xe[0], xe[1], xe[2], xe[3]);
+                    xo[kk / 2][2 * (kk % 2) + 1] = make_float4(xo2[0], xo2[1], xo2[2], xo2[3]);
+                }
+            } else {
+#pragma unroll
+                for (int ot = 0; ot < NOT; ++ot)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) xo[ot][q] = *reinterpret_cast<const float4*>(xr + 32 * ot + 8 * q + 4 * fh);
+            }
 #pragma unroll
             for (int ot = 0; ot < NOT; ++ot)
 #pragma unroll

@@ -29,6 +29,7 @@ inline std::string sidx(const std::string& a, int i, const std::string& b) { ret
 
 int g_gemm3_t160 = 1;   // gemm3 160x128 tiles for M = 600 x wide N (SMTTS_GEMM_T160=0: off)
 int g_gemm3_deep = 1;   // gemm3 ring depth for single-array operand formats: 1 = deep (latency tuning), 0 = shallow (throughput tuning)
+int g_gemm3_w4_minm = 0;  // gemm3: 4-wave 128x128 tiles (wave 64x64) for single-array products with M >= this (SMTTS_GEMM_W4_MINM; 0 = off)
 int g_gemm3_stage16 = 1;  // gemm3: 16-bit outputs through the LDS-staged epilogue (SMTTS_GEMM_STAGE16=0: scalar stores)
 int g_gemm3_nfast = 1;  // gemm3 tile order: N fastest when M > N (SMTTS_GEMM_NFAST=0 restores M fastest everywhere)
 thread_local Profiler* g_prof = nullptr;
@@ -38,6 +39,7 @@ Engine::Engine(int device) : device_(device) {
     if (const char* nf = getenv("SMTTS_GEMM_NFAST")) g_gemm3_nfast = atoi(nf);
     if (const char* dp = getenv("SMTTS_GEMM_DEEP")) g_gemm3_deep = atoi(dp);
     if (const char* s16 = getenv("SMTTS_GEMM_STAGE16")) g_gemm3_stage16 = atoi(s16);
+    if (const char* w4 = getenv("SMTTS_GEMM_W4_MINM")) g_gemm3_w4_minm = atoi(w4);
     if (const char* t1 = getenv("SMTTS_GEMM_T160")) g_gemm3_t160 = atoi(t1);
     const char* s = getenv("SMTTS_SINGLE_STREAM");
     if (s && *s == '1') dual_stream_ = false;

@@ -265,9 +265,13 @@ enum Gemm3Cfg {
     G3_128x64 = 3,   // 8 waves 4x2, wave 32x32, 3 stages (144 KiB): tall, N <= 64
     G3_128x32 = 4,   // 4 waves 4x1, wave 32x32, 2 stages (80 KiB) -> 2 workgroups / CU: tall, N <= 32
     G3_160x128 = 5,  // 10 waves 5x2, wave 32x64, 2 stages (146 KiB): M = 600 (4 row tiles, 6 % padding) x wide N in ONE round
+    G3_128x128_W4 = 6,  // 4 waves 2x2, wave 64x64: 4 fragment reads per 4 MFMAs instead of 3 per 2 — for the single-array formats,
+                        // where one MFMA per fragment pair leaves the k-loop bound by ds_read_b128 traffic; 2 workgroups per CU
 };
 
 static inline int gemm3_pick_cfg(int M, int N, bool paired) {
+    extern int g_gemm3_w4_minm;   // single-array formats: 128x128 with four 64x64 waves from this M up (0 = never); split-bf16 falls back
+    if (g_gemm3_w4_minm > 0 && M >= g_gemm3_w4_minm && N >= 128) return G3_128x128_W4;
     if (paired) return G3_128x128;
     if (N <= 32) return G3_128x32;
     if (N <= 64) return M >= 2048 ? G3_128x64 : G3_64x64;
@@ -343,6 +347,9 @@ static inline hipError_t gemm3_launch_split(const Gemm3Operands& g, const Epi& e
         case G3_160x128:
             if constexpr (!Epi::PAIRED) return gemm3_launch_cfg<160, 128, 5, 2, SPLIT, 2, Epi>(g, epi, Z, st);
             break;
+        case G3_128x128_W4:
+            if constexpr (SPLIT != 3) return gemm3_launch_cfg<128, 128, 2, 2, SPLIT, 2, Epi>(g, epi, Z, st);
+            break;
     }
     return hipErrorInvalidValue;
 }
@@ -359,7 +366,7 @@ static inline hipError_t gemm3_launch(const Gemm3Operands& g_in, const Epi& epi,
     extern int g_gemm3_stage16;
     g.stage16 = g_gemm3_stage16;
     g.nfast = g_gemm3_nfast && (long)g.M > (long)g.N;  // the bigger operand streams, the smaller stays in L2
-    if (split == PREC_BF16X3) return gemm3_launch_split<3, Epi>(g, epi, Z, cfg, st);
+    if (split == PREC_BF16X3) return gemm3_launch_split<3, Epi>(g, epi, Z, cfg == G3_128x128_W4 ? G3_128x128 : cfg, st);
     if (split == PREC_F16) return gemm3_launch_split<2, Epi>(g, epi, Z, cfg, st);
     return gemm3_launch_split<1, Epi>(g, epi, Z, cfg, st);
 }

@@ -271,3 +271,16 @@ def test_codec_spec_flags_steer_the_inventory():
     assert "codec.decoder.final_norm.weight" in nf and "codec.encoder.final_norm.weight" in nf
     assert not any(n.endswith((".bias", "gamma")) or "final_norm" in n for n in nl)
     assert nl < nf and CodecSpec(**lean.to_dict()).to_dict() == lean.to_dict()
+
+
+def test_gelu_q5_constants_in_the_kernel_header_meet_their_error_bound():
+    """GeluQ5 (csrc/common.hpp): gelu(x) = max(x, 0) - |x| 2^q(|x|).  The constants compiled into the kernels are parsed from the
+    header and evaluated in fp32 exactly as the device does; the bound is the one the header states (2.1e-6 absolute, all x)."""
+    import os
+    import re
+    from tests.studies.gelu_q5_fit import fp32_error
+    src = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "smalltts_amd", "csrc", "common.hpp")).read()
+    body = re.search(r"struct GeluQ5 \{(.*?)\};", src, re.S).group(1)
+    c = np.array([float(v) for v in re.findall(r"Q\d = (-?[0-9.e-]+)f", body)], np.float32)
+    assert c.size == 6 and c[-1] < 0            # negative leading coefficient: |x| -> inf extrapolates to max(x, 0)
+    assert fp32_error(c) < 2.2e-6
