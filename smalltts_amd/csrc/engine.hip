@@ -29,7 +29,7 @@ inline std::string sidx(const std::string& a, int i, const std::string& b) { ret
 
 int g_gemm3_t160 = 1;   // gemm3 160x128 tiles for M = 600 x wide N (SMTTS_GEMM_T160=0: off)
 int g_gemm3_deep = 1;   // gemm3 ring depth for single-array operand formats: 1 = deep (latency tuning), 0 = shallow (throughput tuning)
-int g_gemm3_w4_minm = 0;  // gemm3: 4-wave 128x128 tiles (wave 64x64) for single-array products with M >= this (SMTTS_GEMM_W4_MINM; 0 = off)
+int g_gemm3_w4_minm = 2048;  // gemm3: 4-wave 128x128 tiles (wave 64x64) for single-array products with M >= this and N >= 2048 (SMTTS_GEMM_W4_MINM; 0 = off)
 int g_gemm3_stage16 = 1;  // gemm3: 16-bit outputs through the LDS-staged epilogue (SMTTS_GEMM_STAGE16=0: scalar stores)
 int g_gemm3_nfast = 1;  // gemm3 tile order: N fastest when M > N (SMTTS_GEMM_NFAST=0 restores M fastest everywhere)
 thread_local Profiler* g_prof = nullptr;

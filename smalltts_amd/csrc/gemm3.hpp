@@ -271,7 +271,9 @@ enum Gemm3Cfg {
 
 static inline int gemm3_pick_cfg(int M, int N, bool paired) {
     extern int g_gemm3_w4_minm;   // single-array formats: 128x128 with four 64x64 waves from this M up (0 = never); split-bf16 falls back
-    if (g_gemm3_w4_minm > 0 && M >= g_gemm3_w4_minm && N >= 128) return G3_128x128_W4;
+    // measured (profiles/r02k_ab_keepx_w4.txt): the wide, short-K first FFN product of the codec's GEMM stages gains (24000 x 2048 x 512:
+    // 122 -> 98 us, 4800 x 4096 x 1024: 86 -> 72 us), the narrow long-K second product loses (94 -> 102, 64 -> 81 us) -> wide N only
+    if (g_gemm3_w4_minm > 0 && M >= g_gemm3_w4_minm && N >= 2048) return G3_128x128_W4;
     if (paired) return G3_128x128;
     if (N <= 32) return G3_128x32;
     if (N <= 64) return M >= 2048 ? G3_128x64 : G3_64x64;
