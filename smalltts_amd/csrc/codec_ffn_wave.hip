@@ -46,6 +46,13 @@ struct FfnWaveArgs {
     const float* gamma;    // [C]
     int M;
     float eps;
+    // fused mixer (MIX kernels only): x_mid = xin + mgamma (mnorm_w * conv7(RMSNorm_noaffine(xin)) + dw_b), then the FFN on x_mid,
+    // result written to x (a DIFFERENT image: tiles read 6 halo frames their neighbours overwrite)
+    const float* xin;
+    const float* mnorm_w;  // [C]
+    const float* dw_w;     // [7][C]
+    const float* dw_b;     // [C]
+    const float* mgamma;   // [C]
 };
 
 // NWV = waves per workgroup.  The waves never synchronise after the weights are in LDS, so the workgroup size only sets how many
@@ -59,7 +66,14 @@ struct FfnWaveArgs {
 #ifndef FW_MINW64
 #define FW_MINW64 2
 #endif
-template <int C, int SPLIT, int NWV>
+// MIX: the whole codec block in one pass over the image — the mixer (RMSNorm -> causal depthwise conv k = 7 -> LayerScale residual)
+// is computed for the wave's 32 frames in front of the FFN, so a block reads the image once and writes it once instead of
+// twice each (mixer_fused + this kernel): at C = 32 / 64 both were HBM-bound.  The conv runs over TIME, i.e. across lanes
+// (lane = frame): every lane drops its normalised frame into a wave-private [38][C + 4] fp32 tile in LDS (rows 0..5 = the six
+// halo frames in front of the tile, loaded and normalised by the first 6 C / 8 lanes), then accumulates its own channels over
+// the seven rows fr .. fr + 6.  Requires a tile to lie inside one batch item (T % 32 == 0) and K = 7; the engine falls back
+// to the two-kernel path otherwise.
+template <int C, int SPLIT, int NWV, bool MIX = false>
 __global__ __launch_bounds__(NWV * 64, (C == 64 && SPLIT != 3 && NWV == 4) ? FW_MINW64 : 1) void codec_ffn_wave_kernel(FfnWaveArgs a) {
     constexpr int NT = NWV * 64;
     constexpr int F = 4 * C;
@@ -106,8 +120,19 @@ __global__ __launch_bounds__(NWV * 64, (C == 64 && SPLIT != 3 && NWV == 4) ? FW_
     float* vb2 = vb1 + F;
     float* vga = vb2 + C;
     float* vnw = vga + C;
+    // MIX: mixer vectors behind them, then one n-tile per wave
+    float* vmn = vnw + C;        // mixer norm weight [C]
+    float* vdb = vmn + C;        // conv bias [C]
+    float* vmg = vdb + C;        // mixer layer scale [C]
+    float* vdw = vmg + C;        // conv taps [7][C]
+    constexpr int RSN = C + 4;   // n-tile row stride in floats: 16 B of padding -> the 32 frames of a ds_read_b128 hit 32 different bank quads
+    float* ntile = vdw + 7 * C + (size_t)wave * (38 * RSN);
     for (int i = tid; i < F; i += NT) vb1[i] = a.b1[i];
     for (int i = tid; i < C; i += NT) { vb2[i] = a.b2[i]; vga[i] = a.gamma[i]; vnw[i] = a.norm_w[i]; }
+    if (MIX) {
+        for (int i = tid; i < C; i += NT) { vmn[i] = a.mnorm_w[i]; vdb[i] = a.dw_b[i]; vmg[i] = a.mgamma[i]; }
+        for (int i = tid; i < 7 * C; i += NT) vdw[i] = a.dw_w[i];
+    }
     __syncthreads();
 
     // fragment byte offsets (constant for the kernel)
@@ -129,20 +154,78 @@ __global__ __launch_bounds__(NWV * 64, (C == 64 && SPLIT != 3 && NWV == 4) ? FW_
 
     // channel of element e (0..7) of k16 step kk in this lane's B fragment: 16 kk + 8 fh + e
     float4 xa[KK1][2];  // raw x of the tile being prefetched / computed
+    float4 hv[2];       // MIX: 8 channels of one halo frame (lanes < 6 C / 8)
+    constexpr int LPF = C / 8;   // halo: lanes per frame
+    const float* const xsrc = MIX ? a.xin : a.x;
     auto load_tile = [&](int wt) {
         int m = wt * 32 + fr;
         m = m < a.M ? m : a.M - 1;
-        const float* xr = a.x + a.img.at(m);
+        const float* xr = xsrc + a.img.at(m);
 #pragma unroll
         for (int kk = 0; kk < KK1; ++kk) {
             xa[kk][0] = *reinterpret_cast<const float4*>(xr + 16 * kk + 8 * fh);
             xa[kk][1] = *reinterpret_cast<const float4*>(xr + 16 * kk + 8 * fh + 4);
+        }
+        if (MIX) {   // halo frame f = lane / LPF (0..5) of the tile = 6 - f rows in front of its first frame (zero pad rows at t = 0)
+            const int l = lane < 6 * LPF ? lane : 0;
+            const float* hr_ = xsrc + a.img.at(wt * 32) - (long)(6 - l / LPF) * a.img.ld + 8 * (l % LPF);
+            hv[0] = *reinterpret_cast<const float4*>(hr_);
+            hv[1] = *reinterpret_cast<const float4*>(hr_ + 4);
         }
     };
     if (wg < ntiles) load_tile(wg);
 
 #pragma unroll 1
     for (int wt = wg; wt < ntiles; wt += nwg) {
+        if (MIX) {
+            // ---- mixer: u = x * rstd (no affine) of the 32 + 6 frames -> LDS, conv over the seven rows, LayerScale residual ----
+            float ms = 0.f;
+#pragma unroll
+            for (int kk = 0; kk < KK1; ++kk)
+#pragma unroll
+                for (int h2 = 0; h2 < 2; ++h2)
+                    ms += xa[kk][h2].x * xa[kk][h2].x + xa[kk][h2].y * xa[kk][h2].y + xa[kk][h2].z * xa[kk][h2].z + xa[kk][h2].w * xa[kk][h2].w;
+            ms += __shfl_xor(ms, 32, 64);
+            const float mr = 1.0f / sqrtf(ms / (float)C + a.eps);
+            float hs = hv[0].x * hv[0].x + hv[0].y * hv[0].y + hv[0].z * hv[0].z + hv[0].w * hv[0].w +
+                       hv[1].x * hv[1].x + hv[1].y * hv[1].y + hv[1].z * hv[1].z + hv[1].w * hv[1].w;
+#pragma unroll
+            for (int o = LPF >> 1; o > 0; o >>= 1) hs += __shfl_xor(hs, o, 64);
+            const float hrs = 1.0f / sqrtf(hs / (float)C + a.eps);
+            float* own = ntile + (6 + fr) * RSN + 8 * fh;
+#pragma unroll
+            for (int kk = 0; kk < KK1; ++kk) {
+                *reinterpret_cast<float4*>(own + 16 * kk) = make_float4(xa[kk][0].x * mr, xa[kk][0].y * mr, xa[kk][0].z * mr, xa[kk][0].w * mr);
+                *reinterpret_cast<float4*>(own + 16 * kk + 4) = make_float4(xa[kk][1].x * mr, xa[kk][1].y * mr, xa[kk][1].z * mr, xa[kk][1].w * mr);
+            }
+            if (lane < 6 * LPF) {
+                float* hrow = ntile + (lane / LPF) * RSN + 8 * (lane % LPF);
+                *reinterpret_cast<float4*>(hrow) = make_float4(hv[0].x * hrs, hv[0].y * hrs, hv[0].z * hrs, hv[0].w * hrs);
+                *reinterpret_cast<float4*>(hrow + 4) = make_float4(hv[1].x * hrs, hv[1].y * hrs, hv[1].z * hrs, hv[1].w * hrs);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // wave-private tile: written and read by this wave only
+#pragma unroll
+            for (int kk = 0; kk < KK1; ++kk)
+#pragma unroll
+                for (int h2 = 0; h2 < 2; ++h2) {
+                    const int c = 16 * kk + 8 * fh + 4 * h2;
+                    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                    for (int k = 0; k < 7; ++k) {
+                        const float4 u4 = *reinterpret_cast<const float4*>(ntile + (fr + k) * RSN + c);
+                        const float4 w4 = *reinterpret_cast<const float4*>(vdw + k * C + c);
+                        acc.x = fmaf(w4.x, u4.x, acc.x); acc.y = fmaf(w4.y, u4.y, acc.y);
+                        acc.z = fmaf(w4.z, u4.z, acc.z); acc.w = fmaf(w4.w, u4.w, acc.w);
+                    }
+                    const float4 g4 = *reinterpret_cast<const float4*>(vmn + c);
+                    const float4 b4 = *reinterpret_cast<const float4*>(vdb + c);
+                    const float4 m4 = *reinterpret_cast<const float4*>(vmg + c);
+                    float4& xv = xa[kk][h2];
+                    xv.x = fmaf(m4.x, fmaf(g4.x, acc.x, b4.x), xv.x); xv.y = fmaf(m4.y, fmaf(g4.y, acc.y, b4.y), xv.y);
+                    xv.z = fmaf(m4.z, fmaf(g4.z, acc.z, b4.z), xv.z); xv.w = fmaf(m4.w, fmaf(g4.w, acc.w, b4.w), xv.w);
+                }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // all reads of the tile are done before the next tile's writes
+        }
         // ---- RMSNorm of the lane's frame (channels split over the two lane halves) -> split bf16 B fragments ----
         float ss = 0.f;
 #pragma unroll
@@ -177,7 +260,7 @@ __global__ __launch_bounds__(NWV * 64, (C == 64 && SPLIT != 3 && NWV == 4) ? FW_
         // waves moved them (profiles/r02j_*, r02f_*).  The tile stays in registers instead (C / 2 per lane) and is brought from the
         // B-fragment layout (8 consecutive channels per lane half) into the accumulator layout (4-channel groups) by one
         // v_permlane32_swap per register in the epilogue.
-        constexpr bool KEEPX = FW_KEEPX && (SPLIT != 3 || C == 32);   // (C = 64 at split-bf16 is out of registers: it re-reads)
+        constexpr bool KEEPX = MIX || (FW_KEEPX && (SPLIT != 3 || C == 32));   // (C = 64 at split-bf16 is out of registers: it re-reads)
         float4 xk[KK1][2];
         if (KEEPX) {
 #pragma unroll
@@ -456,12 +539,13 @@ __global__ __launch_bounds__(NWV * 64, (C == 64 && SPLIT != 3 && NWV == 4) ? FW_
 #ifndef FW_NWV32
 #define FW_NWV32 8
 #endif
-template <int C, int SPLIT>
+template <int C, int SPLIT, bool MIX = false>
 static hipError_t ffn_wave_go(const FfnWaveArgs& a, hipStream_t st) {
     constexpr int NWV = (C == 32 && SPLIT != 3) ? FW_NWV32 : (C == 64 && SPLIT != 3) ? FW_NWV64 : 8;
-    constexpr size_t lds = (size_t)(SPLIT == 3 ? 2 : 1) * 2 * (8 * C * C) + (size_t)(4 * C + 3 * C) * 4;
+    constexpr size_t lds = (size_t)(SPLIT == 3 ? 2 : 1) * 2 * (8 * C * C) + (size_t)(4 * C + 3 * C) * 4 +
+                           (MIX ? (size_t)(10 * C + NWV * 38 * (C + 4)) * 4 : 0);
     static_assert(lds <= 160 * 1024, "weights must fit LDS");
-    auto kern = codec_ffn_wave_kernel<C, SPLIT, NWV>;
+    auto kern = codec_ffn_wave_kernel<C, SPLIT, NWV, MIX>;
     static DevOnce once;
     int cus = 256;
     hipError_t e = once.ensure([&] {
@@ -489,4 +573,24 @@ hipError_t launch_codec_ffn_wave(float* x, RowMap img, const float* norm_w, cons
     ProfScope ps(st, C == 64 ? "codec_ffn_wave<64>" : "codec_ffn_wave<32>", 4.0 * M * (double)C * F, 8.0 * M * C + 8.0 * (double)C * F);
     if (C == 64) return split == 3 ? ffn_wave_go<64, 3>(a, st) : split == PREC_F16 ? ffn_wave_go<64, 2>(a, st) : ffn_wave_go<64, 1>(a, st);
     return split == 3 ? ffn_wave_go<32, 3>(a, st) : split == PREC_F16 ? ffn_wave_go<32, 2>(a, st) : ffn_wave_go<32, 1>(a, st);
+}
+
+// the whole block (mixer + FFN) in one pass for C in {32, 64} at the single-array formats (and C = 32 at split-bf16):
+// xout = block(xin); xin != xout, both images with zero pad frames; needs T % 32 == 0 (img.rpb) and 7 conv taps
+bool codec_block_wave_ok(int C, int F, int K, int T, int split) {
+    return (C == 32 || C == 64) && F == 4 * C && K == 7 && T > 0 && T % 32 == 0 && (split != 3 || C == 32);
+}
+hipError_t launch_codec_block_wave(const float* xin, float* xout, RowMap img, const float* mnorm_w, const float* dw_w, const float* dw_b,
+                                   const float* mgamma, const float* norm_w, const bf16_t* w1hi, const bf16_t* w1lo, int ld1,
+                                   const float* b1, const bf16_t* w2hi, const bf16_t* w2lo, const float* b2, const float* gamma, int M,
+                                   int C, int F, int K, float eps, int split, hipStream_t st) {
+    if (!codec_block_wave_ok(C, F, K, img.rpb, split) || xin == xout || img.ld != C || img.off % 4 || ld1 % 8 || img.bstride % 4 ||
+        M % 32)
+        return hipErrorInvalidValue;
+    if (M <= 0) return hipSuccess;
+    FfnWaveArgs a{xout, img, norm_w, w1hi, w1lo, ld1, b1, w2hi, w2lo, b2, gamma, M, eps, xin, mnorm_w, dw_w, dw_b, mgamma};
+    ProfScope ps(st, C == 64 ? "codec_block_wave<64>" : "codec_block_wave<32>", 4.0 * M * (double)C * F + 2.0 * M * C * (K + 4),
+                 8.0 * M * C + 8.0 * (double)C * F);
+    if (C == 64) return split == PREC_F16 ? ffn_wave_go<64, 2, true>(a, st) : ffn_wave_go<64, 1, true>(a, st);
+    return split == 3 ? ffn_wave_go<32, 3, true>(a, st) : split == PREC_F16 ? ffn_wave_go<32, 2, true>(a, st) : ffn_wave_go<32, 1, true>(a, st);
 }

@@ -43,6 +43,7 @@ Engine::Engine(int device) : device_(device) {
     if (const char* t1 = getenv("SMTTS_GEMM_T160")) g_gemm3_t160 = atoi(t1);
     const char* s = getenv("SMTTS_SINGLE_STREAM");
     if (s && *s == '1') dual_stream_ = false;
+    if ((s = getenv("SMTTS_BLOCK_WAVE"))) block_wave_ = atoi(s) != 0;
     if ((s = getenv("SMTTS_UP_G3_MINK")) && atoi(s) >= 64) up_g3_mink_ = atoi(s);
     if ((s = getenv("SMTTS_KSPLIT_OUT")) && atoi(s) >= 1 && atoi(s) <= kSplitK) ksplit_out_ = atoi(s);
     if ((s = getenv("SMTTS_KSPLIT_ENC")) && atoi(s) >= 1 && atoi(s) <= kSplitK) ksplit_enc_ = atoi(s);
@@ -1177,6 +1178,14 @@ int Engine::codec_block(hipStream_t st, const CodecBlockW& w, float** xp, float*
     bf16_t* const n2lo_f = sm_lo_for(pf, n2lo);  // (hi, lo) pairs handed to producers: the format the FFN GEMMs read
     auto wsel = [pf](const PW& w) { return pf == PREC_F16 ? w.h16 : w.hi; };
     bool n2_done = false;  // the FFN's normalised input was already produced by the fused depthwise-conv kernel
+    // narrowest stages: the whole block in one pass over the image (mixer + FFN, codec_ffn_wave.hip MIX kernels)
+    if (fused_ffn_ && block_wave_ && codec_block_wave_ok(C, F, cspec_.kernel, T, pf) && w.w1.K == C && w.w2.K == F) {
+        HIPC(launch_codec_block_wave(x, *xaltp, img, w.norm_w, w.dw_w, w.dw_b, w.gamma, w.ffn_norm_w, wsel(w.w1), w.w1.lo, w.w1.K, w.b1,
+                                     wsel(w.w2), w.w2.lo, w.b2, w.ffn_gamma, M, C, F, cspec_.kernel, cspec_.eps, pf, st));
+        *xp = *xaltp;
+        *xaltp = x;
+        return 0;
+    }
     // mixer: RMSNorm -> causal depthwise conv -> LayerScale residual
     if (C <= 256 && 256 % (C / 4) == 0 && cspec_.kernel <= 7 && fused_ffn_) {  // narrow stages: one out-of-place kernel, then swap images
         HIPC(launch_mixer_fused(x, *xaltp, w.norm_w, w.dw_w, w.dw_b, w.gamma, B, T, C, cspec_.kernel, pad, cspec_.eps, st));

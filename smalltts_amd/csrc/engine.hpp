@@ -210,6 +210,7 @@ class Engine {
     int preset_ = PREC_BF16X3;
     int prec_[SITE_COUNT] = {3, 3, 3, 3, 3, 3};
     bool fused_ffn_ = true;  // test hook: smtts_test_set_fused_ffn
+    bool block_wave_ = true;  // codec stages with C = 32 / 64: mixer + FFN in one kernel (SMTTS_BLOCK_WAVE=0: mixer_fused + codec_ffn_wave)
     int up_g3_mink_ = 2048;  // codec ConvTranspose-as-GEMM: gemm3 on a converted copy of the image from this K up (SMTTS_UP_G3_MINK; below: fp32-A kernel)
     int ksplit_enc_ = 4;  // split-K of the encoders' residual projections (1 = fused-epilogue GEMM + separate RMSNorm)
     int ksplit_out_ = 3, ksplit_ff2_ = 3;  // (<= kSplitK; 150 tiles x 3 = 450 workgroups = one round at 2 per CU) split-K factors of the two N = 960 DiT projections (1 = fused epilogue)

@@ -116,6 +116,12 @@ hipError_t launch_zero_pad_frames(float* x, int B, int T, int C, int pad, hipStr
 hipError_t launch_codec_ffn_wave(float* x, RowMap img, const float* norm_w, const bf16_t* w1hi, const bf16_t* w1lo, int ld1,
                                  const float* b1, const bf16_t* w2hi, const bf16_t* w2lo, const float* b2, const float* gamma,
                                  int M, int C, int F, float eps, int split, hipStream_t st);
+// C in {32, 64}: mixer + FFN of one codec block in ONE pass over the image (codec_ffn_wave.hip, MIX kernels): xout = block(xin)
+bool codec_block_wave_ok(int C, int F, int K, int T, int split);
+hipError_t launch_codec_block_wave(const float* xin, float* xout, RowMap img, const float* mnorm_w, const float* dw_w, const float* dw_b,
+                                   const float* mgamma, const float* norm_w, const bf16_t* w1hi, const bf16_t* w1lo, int ld1,
+                                   const float* b1, const bf16_t* w2hi, const bf16_t* w2lo, const float* b2, const float* gamma, int M,
+                                   int C, int F, int K, float eps, int split, hipStream_t st);
 // C in {128, 256}: weights streamed through an LDS ring (codec_ffn_stream.hip); w1 [F][C], w2t = launch_w2_tile_pack(W2 [C][F])
 hipError_t launch_codec_ffn_stream(float* x, RowMap img, const float* norm_w, const bf16_t* w1hi, const bf16_t* w1lo,
                                    const float* b1, const bf16_t* w2thi, const bf16_t* w2tlo, const float* b2, const float* gamma,
