@@ -224,7 +224,14 @@ __global__ __launch_bounds__(NWV * 64, (C == 64 && SPLIT != 3 && NWV == 4) ? FW_
                     xv.x = fmaf(m4.x, fmaf(g4.x, acc.x, b4.x), xv.x); xv.y = fmaf(m4.y, fmaf(g4.y, acc.y, b4.y), xv.y);
                     xv.z = fmaf(m4.z, fmaf(g4.z, acc.z, b4.z), xv.z); xv.w = fmaf(m4.w, fmaf(g4.w, acc.w, b4.w), xv.w);
                 }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // all reads of the tile are done before the next tile's writes
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // every lane's conv reads are done: the tile's rows can be reused
+            // the residual add at the end of the block needs x_mid again: it waits in the (now free) n-tile instead of C / 2 registers
+            // per lane (at C = 64 those registers spilled), and the epilogue reads it back directly in the accumulator layout
+#pragma unroll
+            for (int kk = 0; kk < KK1; ++kk) {
+                *reinterpret_cast<float4*>(own + 16 * kk) = xa[kk][0];
+                *reinterpret_cast<float4*>(own + 16 * kk + 4) = xa[kk][1];
+            }
         }
         // ---- RMSNorm of the lane's frame (channels split over the two lane halves) -> split bf16 B fragments ----
         float ss = 0.f;
@@ -260,7 +267,7 @@ __global__ __launch_bounds__(NWV * 64, (C == 64 && SPLIT != 3 && NWV == 4) ? FW_
         // waves moved them (profiles/r02j_*, r02f_*).  The tile stays in registers instead (C / 2 per lane) and is brought from the
         // B-fragment layout (8 consecutive channels per lane half) into the accumulator layout (4-channel groups) by one
         // v_permlane32_swap per register in the epilogue.
-        constexpr bool KEEPX = MIX || (FW_KEEPX && (SPLIT != 3 || C == 32));   // (C = 64 at split-bf16 is out of registers: it re-reads)
+        constexpr bool KEEPX = !MIX && FW_KEEPX && (SPLIT != 3 || C == 32);   // (C = 64 at split-bf16 is out of registers: it re-reads)
         float4 xk[KK1][2];
         if (KEEPX) {
 #pragma unroll
@@ -512,6 +519,12 @@ __global__ __launch_bounds__(NWV * 64, (C == 64 && SPLIT != 3 && NWV == 4) ? FW_
                     xo[kk / 2][2 * (kk % 2)] = make_float4(xe[0], xe[1], xe[2], xe[3]);
                     xo[kk / 2][2 * (kk % 2) + 1] = make_float4(xo2[0], xo2[1], xo2[2], xo2[3]);
                 }
+            } else if (MIX) {   // x_mid from the wave's n-tile (written there after the conv)
+                const float* xm = ntile + (6 + fr) * RSN + 4 * fh;
+#pragma unroll
+                for (int ot = 0; ot < NOT; ++ot)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) xo[ot][q] = *reinterpret_cast<const float4*>(xm + 32 * ot + 8 * q);
             } else {
 #pragma unroll
                 for (int ot = 0; ot < NOT; ++ot)
