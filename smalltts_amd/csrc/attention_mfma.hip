@@ -2,7 +2,11 @@
 //
 // One workgroup (4 waves) = 32 queries of one (batch, head); keys/values stream through LDS in 64-key chunks
 // with an online softmax, so Ktot is unbounded.  Inputs are the pre-normalised / pre-rotated q, k (qk_prep_kernel)
-// and v rows of the packed projection buffer plus the cross-KV cache.
+// and v rows of the packed projection buffer plus the cross-KV cache.  PREP = true folds qk_prep into the staging passes: the
+// raw projection rows are RMS-normalised per head, scaled by the q_norm / k_norm weights and rotated (dit.py:95-108) on their
+// way into LDS — a row's dims sit in one aligned group of DHP / 4 lanes and the rotation pairs (2i, 2i + 1) in one lane — so the
+// projection buffer is read once and never rewritten (one launch and one fp32 round trip less per block; the self keys are
+// normalised once per 32-query tile, which is noise next to the staging itself).
 //
 //   S^T[key][query] = K . Q^T       A = K chunk  [64 keys][DHP dims]  (row-major, dims contiguous)
 //                                   B = Q tile   [32 queries][DHP]    -> every lane owns ONE query column,
@@ -13,10 +17,48 @@
 // Every wave computes the full S^T chunk (cheap: 48 MFMAs) so the softmax state is wave-local, and owns one 32-dim
 // tile of O^T.  All operands are split into bf16 hi/lo and each product takes 3 MFMAs (lo*hi + hi*lo + hi*hi).
 // LDS images use 16-B chunks XOR-swizzled by row so ds_read_b128 fragment reads are conflict free.
+#include <type_traits>
+
 #include "kernels.hpp"
 #include "prof.hpp"
 
-template <int DH>
+// sum over the aligned group of TPR (16 or 32) lanes that holds one row, left in every lane of the group: DPP inside a row of 16
+// lanes (quad permutes, then the two mirrors), one ds_swizzle for the other row — no ds_bpermute round trips
+template <int TPR>
+__device__ __forceinline__ float row_group_sum(float v) {
+    auto dpp = [](float x, auto ctrl) {
+        return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), decltype(ctrl)::value, 0xf, 0xf, false));
+    };
+    v += dpp(v, std::integral_constant<int, 0xB1>{});    // quad_perm [1 0 3 2]
+    v += dpp(v, std::integral_constant<int, 0x4E>{});    // quad_perm [2 3 0 1]
+    v += dpp(v, std::integral_constant<int, 0x141>{});   // row_half_mirror: the other quad of the 8
+    v += dpp(v, std::integral_constant<int, 0x140>{});   // row_mirror: the other 8 of the 16
+    if (TPR == 32) v += __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, v), 0x401F));   // lane ^ 16
+    return v;
+}
+
+// RoPE factors of this lane's 4 dims for position `pos` (cos = 1, sin = 0 outside the rotated dims or when `on` is false),
+// loaded ahead of the row reduction so the two round trips overlap
+struct Rope4 { float4 c, s; };
+__device__ __forceinline__ Rope4 rope4_load(const AttnArgs& a, int pos, int d, bool on) {
+    Rope4 r{make_float4(1.f, 1.f, 1.f, 1.f), make_float4(0.f, 0.f, 0.f, 0.f)};
+    if (on && d < a.rot_dim) {   // rot_dim % 4 == 0 (checked by the launcher)
+        r.c = *reinterpret_cast<const float4*>(a.rope_cos + (long)pos * a.rot_dim + d);
+        r.s = *reinterpret_cast<const float4*>(a.rope_sin + (long)pos * a.rot_dim + d);
+    }
+    return r;
+}
+
+// RMSNorm_head(row) * w, then RoPE on the pairs (2i, 2i + 1), for this lane's 4 consecutive dims (v = 0 in pad dims)
+template <int DH, int TPR>
+__device__ __forceinline__ float4 prep_row4(float4 v, float4 w4, const Rope4& r, float eps) {
+    const float ss = row_group_sum<TPR>(v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w);
+    const float rstd = __builtin_amdgcn_rsqf(ss * (1.0f / (float)DH) + eps);
+    const float4 y = make_float4(v.x * rstd * w4.x, v.y * rstd * w4.y, v.z * rstd * w4.z, v.w * rstd * w4.w);
+    return make_float4(y.x * r.c.x - y.y * r.s.x, y.y * r.c.y + y.x * r.s.y, y.z * r.c.z - y.w * r.s.z, y.w * r.c.w + y.z * r.s.w);
+}
+
+template <int DH, bool PREP>
 __global__ __launch_bounds__(256) void attention_mfma_kernel(AttnArgs a) {
     constexpr int DHP = DH <= 64 ? 64 : 128;  // padded head dim (K of QK^T), zero filled
     constexpr int KC = 64, QT = 32;
@@ -37,18 +79,34 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(AttnArgs a) {
 
     auto swz = [](int row, int c) { return CPR == 16 ? (c ^ (row & 15)) : (c ^ ((row >> 1) & 7)); };
 
-    // ---- stage Q (pre-scaled), split hi/lo: thread -> (query, 4 dims) -----------------------------------
-    for (int i = tid; i < QT * (DHP / 4); i += 256) {
-        const int r = i / (DHP / 4), d4 = i % (DHP / 4), n = q0 + r, d = d4 * 4;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (n < N && d < DH) v = *reinterpret_cast<const float4*>(a.q + (long)b * a.bs + (long)n * a.rs + h * DH + d);
-        const float f[4] = {v.x * sm_scale, v.y * sm_scale, v.z * sm_scale, v.w * sm_scale};
-        bf16x4 hh, ll;
+    // ---- stage Q (pre-scaled), split hi/lo: thread -> (query, 4 dims); every load of the tile is issued before the first use
+    {
+        constexpr int TPR = DHP / 4, NQP = QT * TPR / 256;   // lanes per row, passes (2 or 4)
+        const int d = (tid % TPR) * 4;
+        float4 qv[NQP];
+        Rope4 qr[NQP];
+        float4 qw4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (PREP && d < DH) qw4 = *reinterpret_cast<const float4*>(a.qw + h * DH + d);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { hh[e] = (bf16_t)f[e]; ll[e] = (bf16_t)(f[e] - (float)hh[e]); }
-        const int off = r * QPITCH + (swz(r, d >> 3) << 4) + (d & 7) * 2;
-        *reinterpret_cast<bf16x4*>(smem + OFF_Q + off) = hh;
-        *reinterpret_cast<bf16x4*>(smem + OFF_Q + Q_ARR + off) = ll;
+        for (int j = 0; j < NQP; ++j) {
+            const int r = tid / TPR + j * (256 / TPR), n = q0 + r;
+            qv[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (n < N && d < DH) qv[j] = *reinterpret_cast<const float4*>(a.q + (long)b * a.bs + (long)n * a.rs + h * DH + d);
+            if (PREP) qr[j] = rope4_load(a, n, d, n < N);
+        }
+#pragma unroll
+        for (int j = 0; j < NQP; ++j) {
+            const int r = tid / TPR + j * (256 / TPR);
+            float4 v = qv[j];
+            if (PREP) v = prep_row4<DH, TPR>(v, qw4, qr[j], a.eps);
+            const float f[4] = {v.x * sm_scale, v.y * sm_scale, v.z * sm_scale, v.w * sm_scale};
+            bf16x4 hh, ll;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { hh[e] = (bf16_t)f[e]; ll[e] = (bf16_t)(f[e] - (float)hh[e]); }
+            const int off = r * QPITCH + (swz(r, d >> 3) << 4) + (d & 7) * 2;
+            *reinterpret_cast<bf16x4*>(smem + OFF_Q + off) = hh;
+            *reinterpret_cast<bf16x4*>(smem + OFF_Q + Q_ARR + off) = ll;
+        }
     }
 
     float m_run = -INFINITY, l_run = 0.f;  // per query (lane & 31); both lane halves keep identical copies
@@ -66,8 +124,12 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(AttnArgs a) {
             constexpr int ITEMS = KC * TPR / 256;        // keys per thread (4 or 8)
             const int r0 = (tid / TPR) * ITEMS, d = (tid % TPR) * 4;
             float4 kq[ITEMS], vq[ITEMS];
+            Rope4 kr[PREP ? ITEMS : 1];
+            float4 kw4 = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (PREP && d < DH) kw4 = *reinterpret_cast<const float4*>(a.kw + h * DH + d);
 #pragma unroll
             for (int it = 0; it < ITEMS; ++it) {
+                if (PREP) kr[it] = rope4_load(a, c0 + r0 + it, d, c0 + r0 + it < N);
                 int gk = c0 + r0 + it;
                 gk = gk < Ktot ? gk : Ktot - 1;          // clamp: always a readable row; masked out by vmask
                 const int dc = d < DH ? d : DH - 4;      // clamp inside the row; pad dims are zeroed below
@@ -91,6 +153,13 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(AttnArgs a) {
             for (int it = 0; it < ITEMS; ++it) {
                 const int r = r0 + it;
                 const bool real = (c0 + r < Ktot) && d < DH;
+                if (PREP && c0 < N) {   // self keys arrive raw; the cross-KV cache was normalised when it was built.  (c0 is uniform:
+                    const bool self = c0 + r < N;   // chunks with no self key skip the pass; lanes never diverge around the DPP sum)
+                    float4 raw = kq[it];
+                    if (d >= DH) raw = make_float4(0.f, 0.f, 0.f, 0.f);   // (clamped column: not part of the row)
+                    const float4 kn = prep_row4<DH, TPR>(raw, kw4, kr[it], a.eps);
+                    if (self) kq[it] = kn;
+                }
                 const float kf[4] = {kq[it].x, kq[it].y, kq[it].z, kq[it].w};
                 bf16x4 kh, kl;
 #pragma unroll
@@ -253,11 +322,11 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(AttnArgs a) {
     }
 }
 
-template <int DH>
+template <int DH, bool PREP>
 static hipError_t attn_mfma_go(const AttnArgs& a, hipStream_t st) {
     constexpr int DHP = DH <= 64 ? 64 : 128;
     constexpr size_t lds = 2 * (32 * DHP * 2) + 2 * (64 * DHP * 2) + 2 * (DHP * 128);
-    auto kern = attention_mfma_kernel<DH>;
+    auto kern = attention_mfma_kernel<DH, PREP>;
     static DevOnce once;
     hipError_t e = once.ensure([&] {
         return hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -268,18 +337,21 @@ static hipError_t attn_mfma_go(const AttnArgs& a, hipStream_t st) {
     return hipGetLastError();
 }
 
-// requires a.prenormed (q, k already RMS-normalised + rotated by launch_qk_prep) and 16-B aligned rows
+// a.prenormed = 1: q, k already RMS-normalised + rotated in place by launch_qk_prep; 0: raw projections, prepared while staging.
+// 16-B aligned rows either way.
 hipError_t launch_attention_mfma(const AttnArgs& a, hipStream_t st) {
     if (a.N <= 0 || a.B <= 0) return hipSuccess;
-    if (!a.prenormed || (a.rs % 4) || (a.bs % 4) || (a.dh % 4) || (a.ors % 4) || (a.obs % 4)) return hipErrorInvalidValue;
+    if ((a.rs % 4) || (a.bs % 4) || (a.dh % 4) || (a.ors % 4) || (a.obs % 4)) return hipErrorInvalidValue;
+    if (!a.prenormed && ((a.rot_dim % 4) || a.rot_dim > a.dh || !a.qw || !a.kw || (a.rot_dim && (!a.rope_cos || !a.rope_sin))))
+        return hipErrorInvalidValue;
     const double kt = a.N + (a.k_ref ? a.R : 0) + (a.k_text ? a.P : 0);
     const double bh = (double)a.B * a.H;
     ProfScope ps(st, a.dh == 120 ? "attention_mfma<120>" : a.dh == 64 ? "attention_mfma<64>" : "attention_mfma<128>",
                  4.0 * bh * a.N * kt * a.dh, 4.0 * bh * a.dh * (5.0 * a.N + 2.0 * (kt - a.N)));
     switch (a.dh) {
-        case 64: return attn_mfma_go<64>(a, st);
-        case 120: return attn_mfma_go<120>(a, st);
-        case 128: return attn_mfma_go<128>(a, st);
+        case 64: return a.prenormed ? attn_mfma_go<64, false>(a, st) : attn_mfma_go<64, true>(a, st);
+        case 120: return a.prenormed ? attn_mfma_go<120, false>(a, st) : attn_mfma_go<120, true>(a, st);
+        case 128: return a.prenormed ? attn_mfma_go<128, false>(a, st) : attn_mfma_go<128, true>(a, st);
     }
     return hipErrorInvalidValue;
 }

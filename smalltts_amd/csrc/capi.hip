@@ -155,7 +155,11 @@ int smtts_test_gemm3(smtts_handle h, void* stream, const float* A, const float* 
     return E.test_gemm3(ST(stream), A, W, bias, M, N, K, act, split, cfg, C);
 }
 int smtts_test_set_fused_ffn(smtts_handle h, int on) { NULLCHK; E.set_fused_ffn(on != 0); return 0; }
-int smtts_test_set_attention_mfma(smtts_handle h, int on) { NULLCHK; E.set_attn_mfma(on != 0); return 0; }
+int smtts_test_set_attention_mfma(smtts_handle h, int mode) { NULLCHK;   // 0: fp32 VALU kernel, 1: matrix cores with q / k prep fused (default), 2: matrix cores after a separate qk_prep launch
+    E.set_attn_mfma(mode != 0);
+    E.set_attn_prep_fused(mode != 2);
+    return 0;
+}
 
 // ---- test hooks -------------------------------------------------------------------------------
 int smtts_test_gemm(smtts_handle h, void* stream, const float* A, int lda, const float* W, const float* bias, int M,
@@ -206,7 +210,9 @@ int smtts_test_attention_mfma(smtts_handle h, void* stream, const float* qkvg, c
         return E.fail("test_attention_mfma: alloc failed");
     (void)hipMemcpyAsync(tmp, qkvg, nq * 4, hipMemcpyDeviceToDevice, ST(stream));  // qk_prep works in place
     (void)launch_rope_cossin(rope, rc, rs, nr, ST(stream));
-    a.q = tmp; a.k = tmp + D; a.v = tmp + 2 * D; a.gate = tmp + 3 * D;
+    const bool fused = E.attn_prep_fused();   // fused prep reads the caller's buffer as it is
+    const float* src = fused ? qkvg : tmp;
+    a.q = src; a.k = src + D; a.v = src + 2 * D; a.gate = src + 3 * D;
     a.bs = (long)N * 4 * D; a.rs = 4 * D;
     a.qw = qw; a.kw = kw; a.eps = eps; a.rope_cos = rc; a.rope_sin = rs; a.rot_dim = rot_dim;
     a.k_ref = R > 0 ? k_ref : nullptr; a.v_ref = v_ref; a.R = R;
@@ -214,8 +220,8 @@ int smtts_test_attention_mfma(smtts_handle h, void* stream, const float* qkvg, c
     a.mask_self = mask_self; a.mask_ref = mask_ref; a.mask_text = mask_text;
     a.out = out; a.obs = (long)N * D; a.ors = D;
     a.B = B; a.N = N; a.H = H; a.dh = dh;
-    a.prenormed = 1;
-    hipError_t e = launch_qk_prep(a, ST(stream));
+    a.prenormed = fused ? 0 : 1;
+    hipError_t e = fused ? hipSuccess : launch_qk_prep(a, ST(stream));
     if (e == hipSuccess) e = launch_attention_mfma(a, ST(stream));
     (void)hipStreamSynchronize(ST(stream));
     (void)hipFree(tmp); (void)hipFree(rc); (void)hipFree(rs);

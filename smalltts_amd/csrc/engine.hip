@@ -44,6 +44,7 @@ Engine::Engine(int device) : device_(device) {
     const char* s = getenv("SMTTS_SINGLE_STREAM");
     if (s && *s == '1') dual_stream_ = false;
     if ((s = getenv("SMTTS_BLOCK_WAVE"))) block_wave_ = atoi(s) != 0;
+    if ((s = getenv("SMTTS_ATTN_PREP"))) attn_prep_fused_ = atoi(s) != 0;
     if ((s = getenv("SMTTS_UP_G3_MINK")) && atoi(s) >= 64) up_g3_mink_ = atoi(s);
     if ((s = getenv("SMTTS_KSPLIT_OUT")) && atoi(s) >= 1 && atoi(s) <= kSplitK) ksplit_out_ = atoi(s);
     if ((s = getenv("SMTTS_KSPLIT_ENC")) && atoi(s) >= 1 && atoi(s) <= kSplitK) ksplit_enc_ = atoi(s);
@@ -733,8 +734,8 @@ int Engine::run_encoder(hipStream_t st, const EncoderW& e, void* wsv, int B, int
         a.mask_self = key_mask;
         a.out = nullptr; a.out_hi = o.hi; a.out_lo = o.lo; a.obs = (long)S * D; a.ors = D;
         a.B = B; a.N = S; a.H = e.heads; a.dh = e.dh;
-        a.prenormed = 1;
-        HIPC(launch_qk_prep(a, st));
+        a.prenormed = !(attn_mfma_ && attn_prep_fused_);   // fused: the matrix-core kernel normalises + rotates q / k while staging
+        if (a.prenormed) HIPC(launch_qk_prep(a, st));
         HIPC(attn_mfma_ ? launch_attention_mfma(a, st) : launch_attention(a, st));
         EpiResid<0> r1{w.x, rd, nullptr, nullptr, 0, 0, 0, 1, nullptr};
         NextLN n1{b.mn, nullptr, y.hi, y.lo, true, e.eps};
@@ -982,8 +983,8 @@ int Engine::denoise_core(hipStream_t st, const float* x_t, const uint8_t* mask, 
         a.mask_self = mask; a.mask_ref = ref_mask; a.mask_text = ph_mask;
         a.out = nullptr; a.out_hi = ob.hi; a.out_lo = ob.lo; a.obs = (long)N * kHidden; a.ors = kHidden;
         a.B = B; a.N = N; a.H = kHeads; a.dh = kDh;
-        a.prenormed = 1;
-        HIPC(launch_qk_prep(a, st));
+        a.prenormed = !(attn_mfma_ && attn_prep_fused_);   // fused: the matrix-core kernel normalises + rotates q / k while staging
+        if (a.prenormed) HIPC(launch_qk_prep(a, st));
         HIPC(attn_mfma_ ? launch_attention_mfma(a, st) : launch_attention(a, st));
         // to_out + mask + gated residual (dit.py:117-118,198), then the MLP AdaLN (dit.py:199)
         EpiResid<0> r1{w.x, rh, nullptr, m + 2 * kHidden, kModLd, mod_row0, mod_rstride, N, mask};

@@ -125,6 +125,8 @@ class Engine {
     int tuning() const { return tuning_; }
     void set_fused_ffn(bool on) { fused_ffn_ = on; }
     void set_attn_mfma(bool on) { attn_mfma_ = on; }
+    void set_attn_prep_fused(bool on) { attn_prep_fused_ = on; }
+    bool attn_prep_fused() const { return attn_prep_fused_; }
     void set_dual_stream(bool on) { dual_stream_ = on; }
     int precision() const { return preset_; }
 
@@ -218,6 +220,7 @@ class Engine {
     hipStream_t aux_ = nullptr;
     hipEvent_t ev_fork_ = nullptr, ev_join_ = nullptr;
     int ensure_aux();
+    bool attn_prep_fused_ = true;  // q / k head-norm + RoPE inside attention_mfma's staging (false: separate qk_prep launch, in place)
     bool attn_mfma_ = true;  // matrix-core attention (attention_mfma.hip); false = fp32 VALU kernel (attention.hip)
     Profiler prof_;
     bool prof_on_ = false;

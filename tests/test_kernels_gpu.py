@@ -172,7 +172,7 @@ def _attn_ref(qkvg, qw, kw, eps, rope, rot, H, dh, kr, vr, kt, vt, ms, mr, mt):
 @pytest.mark.parametrize("B,N,H,dh,rot,R,P", [(2, 75, 8, 120, 64, 15, 30), (3, 21, 8, 64, 64, 0, 0),
                                              (2, 40, 4, 128, 128, 0, 0), (2, 130, 8, 120, 64, 70, 90),
                                              (1, 5, 8, 120, 64, 3, 2)])
-@pytest.mark.parametrize("mfma", [False, True])
+@pytest.mark.parametrize("mfma", [False, "fused", "prep"])
 def test_attention(eng, B, N, H, dh, rot, R, P, mfma):
     D = H * dh
     qkvg = _rand(B, N, 4 * D, seed=20)
@@ -199,7 +199,7 @@ def test_attention_all_keys_masked_gives_zero(eng):
     w = torch.ones(H, dh)
     rope = torch.zeros(N, dh)
     ms = torch.ones(B, N, dtype=torch.bool); ms[1] = False
-    for mfma in (False, True):
+    for mfma in (False, "fused", "prep"):
         got = eng.test_attention(qkvg, w, w, 1e-5, rope, dh, H, dh, mask_self=ms, mfma=mfma).cpu()
         assert torch.isfinite(got).all() and float(got[1].abs().max()) == 0.0 and float(got[0].abs().max()) > 0
 
