@@ -35,6 +35,7 @@ int g_gemm3_nfast = 1;  // gemm3 tile order: N fastest when M > N (SMTTS_GEMM_NF
 thread_local Profiler* g_prof = nullptr;
 thread_local const char* g_prof_tag = nullptr;
 
+static int g_small_m_splitk = 1;   // SMTTS_SMALLM_SPLITK=0: A/B switch for the K-sliced small-M products of the codec
 Engine::Engine(int device) : device_(device) {
     if (const char* nf = getenv("SMTTS_GEMM_NFAST")) g_gemm3_nfast = atoi(nf);
     if (const char* dp = getenv("SMTTS_GEMM_DEEP")) g_gemm3_deep = atoi(dp);
@@ -44,11 +45,14 @@ Engine::Engine(int device) : device_(device) {
     const char* s = getenv("SMTTS_SINGLE_STREAM");
     if (s && *s == '1') dual_stream_ = false;
     if ((s = getenv("SMTTS_BLOCK_WAVE"))) block_wave_ = atoi(s) != 0;
-    if ((s = getenv("SMTTS_ATTN_PREP"))) attn_prep_fused_ = atoi(s) != 0;
+    if ((s = getenv("SMTTS_SMALLM_SPLITK"))) g_small_m_splitk = atoi(s);
+    if ((s = getenv("SMTTS_ATTN_PREP"))) attn_prep_fused_ = atoi(s);   // 0: separate qk_prep launch, 1: fused up to one workgroup per CU, 2: always fused
     if ((s = getenv("SMTTS_UP_G3_MINK")) && atoi(s) >= 64) up_g3_mink_ = atoi(s);
     if ((s = getenv("SMTTS_KSPLIT_OUT")) && atoi(s) >= 1 && atoi(s) <= kSplitK) ksplit_out_ = atoi(s);
     if ((s = getenv("SMTTS_KSPLIT_ENC")) && atoi(s) >= 1 && atoi(s) <= kSplitK) ksplit_enc_ = atoi(s);
     if ((s = getenv("SMTTS_KSPLIT_FF2")) && atoi(s) >= 1 && atoi(s) <= kSplitK) ksplit_ff2_ = atoi(s);
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) num_cus_ = cus;
 }
 
 void Engine::set_tuning(int mode) {
@@ -692,6 +696,30 @@ static hipError_t gemm3_resid_splitk(const Gemm3Operands& g0, const EpiResid<0>&
                                g.M, g.N, st, &r.xmap);
 }
 
+// K slices that spread a weight-bound product (few rows, long K) over the chip.  The count depends on (K, row class) only, never
+// on M itself, so that results stay bit-identical across batch sizes inside a class (tests/test_fullsize_gpu.py: a batch of 2
+// shares its prefix with the batch of 1).  Slices of >= 16 k-tiles (>= 32 in the 513..2048-row class).  1 = leave the product alone.
+static int small_m_splits(int M, int K, int max_few, int max_some) {
+    if (!g_small_m_splitk) return 1;
+    const int nk = K / 64;
+    int sp = 1;
+    if (M <= 512) sp = nk / 16 < max_few ? nk / 16 : max_few;
+    else if (M <= 2048) sp = nk / 32 < max_some ? nk / 32 : max_some;
+    return sp < 2 ? 1 : sp;
+}
+// out = A x W^T + bias as K slices into fp32 partials + one fixed-order reduce pass (no residual: the reduce overwrites)
+static hipError_t gemm3_store_splitk(const Gemm3Operands& g0, float* partial, int splits, int split, const float* bias, float* out,
+                                     const RowMap& omap, hipStream_t st) {
+    Gemm3Operands g = g0;
+    const int nk = g.K / 64;
+    g.ksplit_tiles = (nk + splits - 1) / splits;
+    const int used = (nk + g.ksplit_tiles - 1) / g.ksplit_tiles;
+    EpiStore<ACT_NONE> e{partial, rowmap_plain(g.N), (long)g.M * g.N, nullptr, 0, 1.f, nullptr, nullptr, nullptr};
+    hipError_t err = gemm3_store(g, ACT_NONE, e, used, split, st, G3_64x64);
+    if (err != hipSuccess) return err;
+    return launch_splitk_resid(partial, used, out, bias, nullptr, 0, 0, 0, 1, nullptr, g.M, g.N, st, &omap, true);
+}
+
 // ---------------------------------------------------------------------------------------------
 // K10: encoder stack (style.py:70-105 / phonemes.py:131-167), x (fp32 residual) updated in place.
 // GEMM inputs (y, o, ffh) live as split bf16 pairs written by the producing kernel.
@@ -734,7 +762,7 @@ int Engine::run_encoder(hipStream_t st, const EncoderW& e, void* wsv, int B, int
         a.mask_self = key_mask;
         a.out = nullptr; a.out_hi = o.hi; a.out_lo = o.lo; a.obs = (long)S * D; a.ors = D;
         a.B = B; a.N = S; a.H = e.heads; a.dh = e.dh;
-        a.prenormed = !(attn_mfma_ && attn_prep_fused_);   // fused: the matrix-core kernel normalises + rotates q / k while staging
+        a.prenormed = !attn_fuse_prep(a);   // fused: the matrix-core kernel normalises + rotates q / k while staging
         if (a.prenormed) HIPC(launch_qk_prep(a, st));
         HIPC(attn_mfma_ ? launch_attention_mfma(a, st) : launch_attention(a, st));
         EpiResid<0> r1{w.x, rd, nullptr, nullptr, 0, 0, 0, 1, nullptr};
@@ -898,6 +926,15 @@ struct CoreWs {
 };
 }  // namespace
 
+// q / k prep inside attention_mfma pays while the attention grid is at most one workgroup per CU (B = 8: 192 workgroups, 26.5 ->
+// 21.0 us per block); the fused kernel holds 322 VGPRs, so a grid of several rounds (the teacher's 3B-row CFG batches: 576
+// workgroups) loses the second resident workgroup per CU and the separate qk_prep launch wins (128-step teacher 257 vs 269 ms)
+bool Engine::attn_fuse_prep(const AttnArgs& a) const {
+    if (!attn_mfma_ || !attn_prep_fused_) return false;
+    const long wgs = (long)((a.N + 31) / 32) * a.H * a.B;
+    return attn_prep_fused_ > 1 || wgs <= num_cus_;
+}
+
 size_t Engine::denoise_core_bytes(int B, int N) const {
     Bump b(nullptr);
     CoreWs w;
@@ -983,7 +1020,7 @@ int Engine::denoise_core(hipStream_t st, const float* x_t, const uint8_t* mask, 
         a.mask_self = mask; a.mask_ref = ref_mask; a.mask_text = ph_mask;
         a.out = nullptr; a.out_hi = ob.hi; a.out_lo = ob.lo; a.obs = (long)N * kHidden; a.ors = kHidden;
         a.B = B; a.N = N; a.H = kHeads; a.dh = kDh;
-        a.prenormed = !(attn_mfma_ && attn_prep_fused_);   // fused: the matrix-core kernel normalises + rotates q / k while staging
+        a.prenormed = !attn_fuse_prep(a);   // fused: the matrix-core kernel normalises + rotates q / k while staging
         if (a.prenormed) HIPC(launch_qk_prep(a, st));
         HIPC(attn_mfma_ ? launch_attention_mfma(a, st) : launch_attention(a, st));
         // to_out + mask + gated residual (dit.py:117-118,198), then the MLP AdaLN (dit.py:199)
@@ -1251,6 +1288,16 @@ int Engine::codec_block(hipStream_t st, const CodecBlockW& w, float** xp, float*
             return 0;
         }
     }
+    {
+        // fewer rows still (the codec ENCODER's coarse stages on 2-s references: 120 x 2048 x 8192 is 64 tiles that each walk the
+        // whole K: 47 us at 0.7 TB/s of weights): K slices on 64x64 tiles + the same reduce
+        const int splits = M <= 480 ? small_m_splits(M, F, 8, 1) : 1;
+        if (splits >= 2 && fused_ffn_ && (size_t)splits * M * C * 2 <= n2_elems && C % 4 == 0) {
+            float* part = reinterpret_cast<float*>(n2hi);
+            HIPC(gemm3_resid_splitk(ops3(hid, rf, w.w2, M, pf), r, part, splits, pf, st, NextLN(), G3_64x64));
+            return 0;
+        }
+    }
     HIPC(gemm3_resid(ops3(hid, rf, w.w2, M, pf), 2, r, pf, st));
     return 0;
 }
@@ -1416,6 +1463,24 @@ int Engine::codec_encode(hipStream_t st, const float* audio, int B, int S_, floa
     float* xn = w.xb;
     int Ti = S_;
     int C = enc_.stages[0].C;
+    // The coarse end of the encoder on short references is a handful of rows against a long K (2-s references: the last strided
+    // conv is 120 x 2048 x 16384, the head 120 x 64 x 14336): as row tiles alone that is 2-32 workgroups streaming 134 MB of
+    // weights (374 / 254 us).  There: convert the (small) image once to the GEMM operand format — pads included, they are the
+    // causal zeros — and run gemm3 over the overlapping rows as K slices + one reduce.  Returns true when it took the product.
+    bool conv_err = false;
+    const int pcv = prec_[SITE_CODEC_CONV];
+    auto conv_small_m = [&](const float* img, long img_rows, int Cin, const RowMap& am, const PW& wt, const float* bias, float* out,
+                            const RowMap& om, int M) -> bool {
+        const int splits = (fused_ffn_ && wt.K >= 2048) ? small_m_splits(M, wt.K, 8, 4) : 1;
+        if (splits < 2 || wt.K % 64 || Cin % 4 || wt.N % 4 || (size_t)img_rows * Cin > max_img || (size_t)splits * M * wt.N * 2 > max_hid)
+            return false;
+        SplitBuf xs{w.n2hi, w.n2lo};
+        float* part = reinterpret_cast<float*>(w.hhi);   // max_hid bf16 = max_hid / 2 floats
+        hipError_t e = launch_to_split(img, rowmap_plain(Cin), xs.hi, xs.as(pcv).lo, rowmap_plain(Cin), (int)img_rows, Cin, st);
+        if (e == hipSuccess) e = gemm3_store_splitk(ops3(xs, am, wt, M, pcv), part, splits, pcv, bias, out, om, st);
+        if (e != hipSuccess) { fail_hip(e, "codec_encode: split-K conv"); conv_err = true; }
+        return true;
+    };
     HIPC(launch_zero_pad_frames(x, B, Ti, C, pad, st));
     HIPC(launch_zero_pad_frames(xn, B, Ti, C, pad, st));
     HIPC(launch_zero_pad_frames(w.nb, B, Ti, C, pad, st));
@@ -1431,7 +1496,9 @@ int Engine::codec_encode(hipStream_t st, const float* audio, int B, int S_, floa
             HIPC(launch_zero_pad_frames(w.nb, B, Tn, Cn, pad, st));
             RowMap am = rowmap_batched((long)r * C, Tn, (long)(pad + Ti) * C, (long)(pad - r) * C);
             RowMap om = rowmap_batched(Cn, Tn, (long)(pad + Tn) * Cn, (long)pad * Cn);
-            HIPC(gemm_store(ops(x, am, sg.resample, B * Tn), ACT_NONE, store_to(xn, om, sg.resample_bias), 1, pcv3, st));
+            if (!conv_small_m(x, (long)B * (pad + Ti), C, am, sg.resample, sg.resample_bias, xn, om, B * Tn))
+                HIPC(gemm_store(ops(x, am, sg.resample, B * Tn), ACT_NONE, store_to(xn, om, sg.resample_bias), 1, pcv3, st));
+            if (conv_err) return 1;
             float* t = x; x = xn; xn = t;
             Ti = Tn;
             C = Cn;
@@ -1446,9 +1513,10 @@ int Engine::codec_encode(hipStream_t st, const float* audio, int B, int S_, floa
         x = w.nb;
     }
     RowMap am = rowmap_batched(C, Ti, (long)(pad + Ti) * C, (long)(pad - (Kc - 1)) * C);
-    HIPC(gemm_store(ops(x, am, enc_.head, B * Ti), ACT_NONE, store_to(latents, rowmap_plain(s.latent_dim), enc_.head_b), 1,
-                    pcv3, st));
-    return 0;
+    if (!conv_small_m(x, (long)B * (pad + Ti), C, am, enc_.head, enc_.head_b, latents, rowmap_plain(s.latent_dim), B * Ti))
+        HIPC(gemm_store(ops(x, am, enc_.head, B * Ti), ACT_NONE, store_to(latents, rowmap_plain(s.latent_dim), enc_.head_b), 1,
+                        pcv3, st));
+    return conv_err ? 1 : 0;
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -707,7 +707,8 @@ hipError_t launch_rope_cossin(const float* ang, float* c, float* s, int n, hipSt
 __global__ __launch_bounds__(256) void splitk_resid_kernel(const float* __restrict__ part, int S, float* __restrict__ x,
                                                            const float* __restrict__ bias, const float* __restrict__ gate,
                                                            long gld, int grow0, int grstride, int rpb,
-                                                           const uint8_t* __restrict__ rowmask, int M, int N4, RowMap xmap) {
+                                                           const uint8_t* __restrict__ rowmask, int M, int N4, RowMap xmap,
+                                                           int overwrite) {
     long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (long)M * N4) return;
     const int m = (int)(i / N4), c = (int)(i % N4);
@@ -725,7 +726,7 @@ __global__ __launch_bounds__(256) void splitk_resid_kernel(const float* __restri
     float4 g = make_float4(1.f, 1.f, 1.f, 1.f);
     if (gate) g = reinterpret_cast<const float4*>(gate + (long)(grow0 + (m / rpb) * grstride) * gld)[c];
     float4* xr = reinterpret_cast<float4*>(x + xmap.at(m)) + c;  // residual image row m (plain [M][N] or a padded codec image)
-    float4 xv = *xr;
+    float4 xv = overwrite ? make_float4(0.f, 0.f, 0.f, 0.f) : *xr;   // overwrite: x = gate * (sum + bias), closes a split-K product that has no residual
     xv.x += g.x * acc.x; xv.y += g.y * acc.y; xv.z += g.z * acc.z; xv.w += g.w * acc.w;
     *xr = xv;
 }
@@ -840,14 +841,14 @@ hipError_t launch_splitk_resid_ln(const float* part, int S, float* x, const floa
 
 hipError_t launch_splitk_resid(const float* part, int S, float* x, const float* bias, const float* gate, long gld,
                                int grow0, int grstride, int rows_per_batch, const uint8_t* rowmask, int M, int N,
-                               hipStream_t st, const RowMap* xmap) {
+                               hipStream_t st, const RowMap* xmap, bool overwrite) {
     const RowMap xm = xmap ? *xmap : rowmap_plain(N);
     if (N % 4 || gld % 4 || xm.ld % 4 || xm.off % 4 || xm.bstride % 4 || rows_per_batch <= 0) return hipErrorInvalidValue;
     long n = (long)M * (N / 4);
     if (n == 0) return hipSuccess;
     ProfScope ps(st, "splitk_resid", 1.0 * M * N * (S + 2), 4.0 * M * N * (S + 2));
     hipLaunchKernelGGL(splitk_resid_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, part, S, x, bias, gate, gld,
-                       grow0, grstride, rows_per_batch, rowmask, M, N / 4, xm);
+                       grow0, grstride, rows_per_batch, rowmask, M, N / 4, xm, overwrite ? 1 : 0);
     LAUNCH_CHECK();
 }
 

@@ -143,7 +143,8 @@ hipError_t launch_splitk_resid_ln(const float* part, int S, float* x, const floa
                                   bool rms = false /* true: y = RMSNorm(x; weight = shift, eps), encoders */);
 hipError_t launch_splitk_resid(const float* part, int S, float* x, const float* bias, const float* gate, long gld,
                                int grow0, int grstride, int rows_per_batch, const uint8_t* rowmask, int M, int N,
-                               hipStream_t st, const RowMap* xmap = nullptr /* rows of x; default plain [M][N] */);
+                               hipStream_t st, const RowMap* xmap = nullptr /* rows of x; default plain [M][N] */,
+                               bool overwrite = false /* x = gate * (sum + bias) instead of x += ... */);
 
 // Fused mixer for C <= 256 (out of place: tiles read K-1 halo frames that belong to the neighbouring tile, so the
 // update cannot be done in place):  xout[b][t][c] = xin + gamma[c] * (bias[c] + sum_k w[k][c] * n[t-(K-1)+k][c]) with

@@ -9,14 +9,14 @@ eng = HipEngine(0, "bf16x3")
 eng.load_synthetic(bench.SEED, parts=("dit", "decoder")); eng.finalize()
 inp = bench.make_inputs(torch.device("cuda", 0), 0)
 for i in range(3):
-    bench.one_step(eng, inp, i, None, "dmd4")
+    bench.one_step(eng, inp, i)
 torch.cuda.synchronize()
 n = 10
 t0 = time.perf_counter()
 per = []
 for i in range(n):
     a = time.perf_counter()
-    bench.one_step(eng, inp, 100 + i, None, "dmd4")
+    bench.one_step(eng, inp, 100 + i)
     per.append(time.perf_counter() - a)
 t1 = time.perf_counter()
 torch.cuda.synchronize()

@@ -27,11 +27,11 @@ def main():
     eng.finalize()
     inp = bench.make_inputs(torch.device("cuda", 0), 0)
     for i in range(2):
-        bench.one_step(eng, inp, 10 + i, None, a.workload)
+        bench.one_step(eng, inp, 10 + i, workload=a.workload)
     torch.cuda.synchronize()
     eng.profile(True, tagged=True)
     for i in range(a.reps):
-        bench.one_step(eng, inp, 900 + i, None, a.workload)
+        bench.one_step(eng, inp, 900 + i, workload=a.workload)
     torch.cuda.synchronize()
     rows = eng.profile_report()
     eng.profile(False)
