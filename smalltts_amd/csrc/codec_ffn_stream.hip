@@ -234,8 +234,12 @@ __global__ __launch_bounds__(NW * 64) void codec_ffn_stream_kernel(FfnStreamArgs
                 int lo;
                 if (g < NG1) { ad = sl + (w1_a0 ^ (((2 * g) & 15) << 4)) + ((2 * g) >> 4) * 256; lo = W1T; }
                 else { const int g2 = g - NG1; ad = sl + w2_off[g2 / NOT] + (g2 % NOT) * 32 * 64; lo = W2T; }
+#ifdef FS_ELIM_FRAG   // (timing experiments only, results are wrong: FS_ELIM_*)
+                wf[g % NB][0] = nh[g % KK1]; wf[g % NB][1] = nl[g % KK1]; (void)ad; (void)lo;
+#else
                 wf[g % NB][0] = *reinterpret_cast<const bf16x8*>(ad);
                 if (SPLIT == 3) wf[g % NB][1] = *reinterpret_cast<const bf16x8*>(ad + lo);
+#endif
             };
 #pragma unroll
             for (int g = 0; g < PFD; ++g)
@@ -341,7 +345,13 @@ __global__ __launch_bounds__(NW * 64) void codec_ffn_stream_kernel(FfnStreamArgs
                 for (int ps = 0; ps < NPASS; ++ps) {
                     const int c = g * NPASS + ps;
                     __builtin_amdgcn_sched_barrier(0);
+#ifdef FS_ELIM_MFMA
+                    asm volatile("" :: "v"(wf[g % NB][0]));
+                    if (g < NG1) { hw[g & 15] += 1.0f; } else { acc2[(g - NG1) % NOT][g & 15] += fr_.h[(g - NG1) / NOT][0] == (bf16_t)0.5f ? 1.f : 0.f; }
+                    if (false) {
+#else
                     if (g < NG1) {
+#endif
                         // pass order: the two cross terms first, hi . hi last
                         if (SPLIT == 3 && ps == 0) hw = mfma16<SPLIT>(wf[g % NB][1], nh[g < NG1 ? g : 0], hw);
                         else if (SPLIT == 3 && ps == 1) hw = mfma16<SPLIT>(wf[g % NB][0], nl[g < NG1 ? g : 0], hw);
@@ -352,11 +362,26 @@ __global__ __launch_bounds__(NW * 64) void codec_ffn_stream_kernel(FfnStreamArgs
                         else if (SPLIT == 3 && ps == 1) acc2[ot] = mfma16<SPLIT>(wf[g % NB][0], fr_.l[s2], acc2[ot]);
                         else acc2[ot] = mfma16<SPLIT>(wf[g % NB][0], fr_.h[s2], acc2[ot]);
                     }
+#ifdef FS_ELIM_GELU
+                    if (G && c < 2) {   // bare conversion of the tile (keeps the first product alive): 8 cvt + the lane swap
+                        const int s2 = c;
+                        unsigned hp[4], fhh[4];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) hp[j] = cvt_pk_f16_satpos(hr[8 * s2 + 2 * j], hr[8 * s2 + 2 * j + 1]);
+#pragma unroll
+                        for (int e = 0; e < 2; ++e) {
+                            auto rh = __builtin_amdgcn_permlane32_swap(hp[e], hp[2 + e], false, false);
+                            fhh[e] = rh[0]; fhh[2 + e] = rh[1];
+                        }
+                        fw.h[s2] = __builtin_bit_cast(bf16x8, *reinterpret_cast<uint4*>(fhh));
+                    }
+#else
                     if (G)
 #pragma unroll
                         for (int k = NTASK * c / NCH; k < NTASK * (c + 1) / NCH; ++k) {
                             if constexpr (PK) task_q5(k); else task(k);
                         }
+#endif
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
