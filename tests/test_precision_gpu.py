@@ -179,3 +179,29 @@ def test_gemm3_fp16_single_pass_vs_torch(eng, M, N, K, cfg):
     assert torch.isfinite(got2).all()
     r1 = (A2[1].half().double()[None] @ W.half().double().t())[0]
     assert rel_l2(got2[1].numpy(), r1.numpy()) < 1e-5 and float(r1.abs().max()) > 0
+
+
+def test_default_precision_teacher_128_steps_stays_inside_the_contract(eng, dit_weights):
+    """BASELINE config 5 at the SHIPPED precision: 128 chained ODE + CFG steps (distill.py:60-134 ingredients) against the fp32
+    oracle, x0-hat of every step — fp16 operand rounding is re-injected 128 times, so this is where drift would show.  The
+    split-bf16 version of this test (test_dit_gpu.py) asserts 5e-4; here the north star's 1e-3 contract itself is the bar."""
+    gen = torch.Generator().manual_seed(51)
+    B, N, R, P, steps = 2, 20, 6, 9, 128
+    ref = torch.randn(B, R, 64, generator=gen)
+    ids = torch.randint(1, 198, (B, P), generator=gen)
+    pm = torch.ones(B, P, dtype=torch.bool); rl = torch.full((B,), R)
+    mask = torch.ones(B, N, dtype=torch.bool); mask[1, 15:] = False
+    noise = torch.randn(B, N, 64, generator=gen)
+    ref3, len3, ids3, pm3 = O.cfg_conditions(ref, rl, ids, pm)
+    keep = []
+    with torch.no_grad():
+        oc = O.encode_conditions(dit_weights, ref3, len3, ids3, pm3)
+        ox = O.sample_teacher_ode(dit_weights, oc, pm3, mask, noise, steps, keep=keep)
+    cache3 = eng.cond_encode(ref3, len3, ids3, pm3)
+    x, per_step = eng.sample(cache3, mask, num_steps=steps, mode="ode", cfg=True, noise=noise, return_steps=True)
+    m = mask.numpy()
+    errs = [rel_l2(per_step[i].cpu().numpy()[m], keep[i].numpy()[m]) for i in range(steps)]
+    end = rel_l2(x.cpu().numpy()[m], ox.numpy()[m])
+    print(f"\n[teacher 128 @ f16 mixed] x0-hat rel L2 vs oracle: step 0 {errs[0]:.2e}, 31 {errs[31]:.2e}, 63 {errs[63]:.2e}, "
+          f"127 {errs[127]:.2e}, max {max(errs):.2e} at step {int(np.argmax(errs))}; final latents {end:.2e}")
+    assert max(errs) < 1e-3 and end < 1e-3, f"128-step chain at the default precision: max {max(errs):.3e}, end {end:.3e}"
