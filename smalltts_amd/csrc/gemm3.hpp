@@ -269,7 +269,7 @@ enum Gemm3Cfg {
                         // where one MFMA per fragment pair leaves the k-loop bound by ds_read_b128 traffic; 2 workgroups per CU
 };
 
-static inline int gemm3_pick_cfg(int M, int N, bool paired) {
+static inline int gemm3_pick_cfg(int M, int N, bool paired, bool single = false /* one array per operand (fp16 / bf16) */) {
     extern int g_gemm3_w4_minm;   // single-array formats: 128x128 with four 64x64 waves from this M up (0 = never); split-bf16 falls back
     // measured (profiles/r02k_ab_keepx_w4.txt): the wide, short-K first FFN product of the codec's GEMM stages gains (24000 x 2048 x 512:
     // 122 -> 98 us, 4800 x 4096 x 1024: 86 -> 72 us), the narrow long-K second product loses (94 -> 102, 64 -> 81 us) -> wide N only
@@ -293,6 +293,14 @@ static inline int gemm3_pick_cfg(int M, int N, bool paired) {
         if (c160 < 0.96 * c64 && c160 < 0.96 * c128) return G3_160x128;
     }
     const long t128 = (long)((M + 127) / 128) * ((N + 127) / 128);
+    if (single) {
+        // single-array formats hold two 128x128 workgroups (2 x 64 KiB of ring) or four 64x64 ones per CU, so their one-round
+        // capacities are 512 / 1024 tiles (profiles/r02ae_gemm_cfg_sweep.txt, fp16): the teacher's 1800 x 3840 x 960 QKVG as 450
+        // tiles of 128x128 27.5 us against 34.4 as 870 of 64x128; the B = 8 QKVG (600 x 3840) as 600 tiles of 64x64 15.3 against 17.6
+        const long t64 = (long)((M + 63) / 64) * ((N + 63) / 64);
+        if (M <= 640 && t128 >= 128 && t128 <= 256 && t64 > 512 && t64 <= 1024) return G3_64x64;
+        if (t128 > 256 && t128 < 512) return G3_128x128;
+    }
     if (t128 >= 512 || (t128 >= 128 && t128 <= 256)) return G3_128x128;
     const long t64x128 = (long)((M + 63) / 64) * ((N + 127) / 128);
     if (t64x128 >= 200) return G3_64x128;
@@ -313,7 +321,13 @@ template <int SPLIT, class Epi>
 static inline hipError_t gemm3_launch_split(const Gemm3Operands& g, const Epi& epi, int Z, int cfg, hipStream_t st) {
     extern int g_gemm3_deep;
     if constexpr (SPLIT != 3) {
-        if (g_gemm3_deep) {
+        // deep rings pay when the whole grid is resident at once (one latency-bound round); a grid of several rounds at the deep
+        // ring's occupancy runs faster shallow with more workgroups per CU (teacher QKVG, 450 tiles of 128x128: 35.1 us deep — two
+        // rounds at one workgroup per CU — against 27.5 shallow; B = 8 QKVG as 600 tiles of 64x64: 20.4 against 15.3)
+        const long bm = cfg == G3_64x128 || cfg == G3_64x64 ? 64 : cfg == G3_160x128 ? 160 : 128, bn = cfg == G3_64x64 ? 64 : 128;
+        const long tiles = ((g.M + bm - 1) / bm) * ((g.N + bn - 1) / bn) * (Z > 0 ? Z : 1);
+        const long deep_slots = cfg == G3_64x64 ? 512 : 256;
+        if (g_gemm3_deep && tiles <= deep_slots) {
             switch (cfg) {
                 case G3_128x128:
                     return gemm3_launch_cfg<128, 128, 4, 2, SPLIT, 4, Epi>(g, epi, Z, st);
@@ -362,7 +376,7 @@ static inline hipError_t gemm3_launch(const Gemm3Operands& g_in, const Epi& epi,
     const Gemm3Operands& g0 = g_in;
     if (g0.M <= 0 || g0.N <= 0) return hipSuccess;
     if (!gemm3_ok(g0)) return hipErrorInvalidValue;
-    if (cfg < 0) cfg = gemm3_pick_cfg(g0.M, g0.N, Epi::PAIRED);
+    if (cfg < 0) cfg = gemm3_pick_cfg(g0.M, g0.N, Epi::PAIRED, split != PREC_BF16X3);
     extern int g_gemm3_nfast;
     Gemm3Operands g = g_in;
     extern int g_gemm3_stage16;

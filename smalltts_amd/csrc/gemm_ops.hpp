@@ -32,7 +32,7 @@ hipError_t gemm_convpos(const GemmOperands& g, bool final, const EpiConvPos<0>& 
 
 // ---- v3 (split-A, DMA ring, 8 waves) entry points: definitions in gemm3_ops.hip --------------------------
 static inline std::string gemm3_prof_name(const Gemm3Operands& g, bool paired, int cfg, int split, const char* epi) {
-    if (cfg < 0) cfg = gemm3_pick_cfg(g.M, g.N, paired);
+    if (cfg < 0) cfg = gemm3_pick_cfg(g.M, g.N, paired, split != PREC_BF16X3);
     static const char* tiles[] = {"64x128", "128x128", "64x64", "128x64", "128x32", "160x128", "128x128w4"};
     return std::string("gemm3<") + tiles[cfg] + ",s" + std::to_string(split) + "," + epi + ">";
 }
