@@ -160,7 +160,7 @@ int smtts_test_attention_mfma(smtts_handle h, void* stream, const float* qkvg, c
                               const uint8_t* mask_ref, const uint8_t* mask_text, int B, int N, int H, int dh, float* out);
 /* engine-wide switch: 1 (default) = matrix-core attention, 0 = fp32 VALU attention kernel */
 /* mode 0: fp32 VALU attention; 1: matrix cores, q / k head-norm + RoPE fused into the staging (default); 2: matrix cores after a
- * separate in-place qk_prep launch */
+ * separate in-place qk_prep launch; + 4: never the resident-K/V form of the matrix-core kernel (process-wide A/B switch) */
 int smtts_test_set_attention_mfma(smtts_handle h, int mode);
 
 #ifdef __cplusplus

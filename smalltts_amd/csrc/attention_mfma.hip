@@ -58,21 +58,27 @@ __device__ __forceinline__ float4 prep_row4(float4 v, float4 w4, const Rope4& r,
     return make_float4(y.x * r.c.x - y.y * r.s.x, y.y * r.c.y + y.x * r.s.y, y.z * r.c.z - y.w * r.s.z, y.w * r.c.w + y.z * r.s.w);
 }
 
-template <int DH, bool PREP>
+// RES = 0: one workgroup per 32-query tile, keys / values streamed chunk by chunk (any Ktot).  RES = n: one workgroup per (batch,
+// head); ALL keys / values (at most n chunks of 64) are staged — and, with PREP, normalised — ONCE and stay in LDS while the
+// workgroup walks its query tiles.  For grids that are several rounds of the streaming form (the teacher's 3B-row CFG batches:
+// 576 workgroups that each re-stage the same 120 keys) this removes two thirds of the staging, which is most of this kernel's time.
+// Same arithmetic in the same order per (query, key) as RES = 0: the two forms are bit-identical (test_kernels_gpu.py).
+template <int DH, bool PREP, int RES>
 __global__ __launch_bounds__(256) void attention_mfma_kernel(AttnArgs a) {
     constexpr int DHP = DH <= 64 ? 64 : 128;  // padded head dim (K of QK^T), zero filled
     constexpr int KC = 64, QT = 32;
     constexpr int QPITCH = DHP * 2;            // bytes per row of the Q / K images
     constexpr int CPR = QPITCH / 16;           // 16-B chunks per row (8 or 16)
     constexpr int Q_ARR = QT * QPITCH, K_ARR = KC * QPITCH, V_ARR = DHP * 128;  // Vt rows: 64 keys x 2 B = 128 B
-    constexpr int OFF_Q = 0, OFF_K = OFF_Q + 2 * Q_ARR, OFF_V = OFF_K + 2 * K_ARR;
+    constexpr int NRES = RES ? RES : 1;        // resident chunk buffers
+    constexpr int OFF_Q = 0, OFF_K0 = OFF_Q + 2 * Q_ARR, OFF_V0 = OFF_K0 + NRES * 2 * K_ARR;
     constexpr int NDT = DHP / 32;              // 32-dim tiles of O^T (2 or 4); wave w owns tile w (w < NDT)
     constexpr int KS1 = DHP / 16;              // k16 steps of S^T
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int q0 = blockIdx.x * QT, h = blockIdx.y, b = blockIdx.z;
+    const int h = blockIdx.y, b = blockIdx.z;
     const int N = a.N, R = a.k_ref ? a.R : 0, P = a.k_text ? a.P : 0, Ktot = N + R + P;
     const float sm_scale = 1.0f / sqrtf((float)DH);
     const int fr = lane & 31, fh = lane >> 5;
@@ -80,7 +86,7 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(AttnArgs a) {
     auto swz = [](int row, int c) { return CPR == 16 ? (c ^ (row & 15)) : (c ^ ((row >> 1) & 7)); };
 
     // ---- stage Q (pre-scaled), split hi/lo: thread -> (query, 4 dims); every load of the tile is issued before the first use
-    {
+    auto stage_q = [&](int q0) {
         constexpr int TPR = DHP / 4, NQP = QT * TPR / 256;   // lanes per row, passes (2 or 4)
         const int d = (tid % TPR) * 4;
         float4 qv[NQP];
@@ -107,18 +113,15 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(AttnArgs a) {
             *reinterpret_cast<bf16x4*>(smem + OFF_Q + off) = hh;
             *reinterpret_cast<bf16x4*>(smem + OFF_Q + Q_ARR + off) = ll;
         }
-    }
+    };
 
     float m_run = -INFINITY, l_run = 0.f;  // per query (lane & 31); both lane halves keep identical copies
     floatx16 oacc;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) oacc[r] = 0.f;
 
-    for (int c0 = 0; c0 < Ktot; c0 += KC) {
-        __syncthreads();  // previous chunk consumed (and Q image visible on the first pass)
-        // ---- stage K chunk [key][dim] and V^T chunk [dim][key], split hi/lo.  All global loads of the chunk are
-        // issued before the first LDS store (one memory round trip per chunk, not one per item).  A thread owns 4 dims of
-        // ITEMS CONSECUTIVE keys, so its V^T output is one 16-B (8 keys) or 8-B (4 keys) piece per dim row. ------------------
+    // ---- stage K chunk [key][dim] and V^T chunk [dim][key] of keys c0 .. c0 + 63 into the buffers at OFF_K / OFF_V, split hi/lo.
+    // All global loads of the chunk are issued before the first LDS store (one memory round trip per chunk, not one per item).
+    // A thread owns 4 dims of ITEMS CONSECUTIVE keys, so its V^T output is one 16-B (8 keys) or 8-B (4 keys) piece per dim row.
+    auto stage_kv = [&](int c0, int OFF_K, int OFF_V) {
         {
             constexpr int TPR = DHP / 4;                 // threads per key row (16 or 32)
             constexpr int ITEMS = KC * TPR / 256;        // keys per thread (4 or 8)
@@ -189,19 +192,21 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(AttnArgs a) {
                 *reinterpret_cast<bf16xI*>(smem + OFF_V + V_ARR + voff) = vl;
             }
         }
-        // key validity of this chunk as a 64-bit mask (lane = key), identical in every wave
+    };
+    // key validity of a chunk as a 64-bit mask (lane = key), identical in every wave
+    auto chunk_mask = [&](int c0) -> unsigned long long {
         bool kval = false;
-        {
-            const int gk = c0 + lane;
-            if (gk < Ktot) {
-                const uint8_t* mk = gk < N ? a.mask_self : (gk < N + R ? a.mask_ref : a.mask_text);
-                const int mi = gk < N ? b * N + gk : (gk < N + R ? b * R + (gk - N) : b * P + (gk - N - R));
-                kval = !mk || mk[mi];
-            }
+        const int gk = c0 + lane;
+        if (gk < Ktot) {
+            const uint8_t* mk = gk < N ? a.mask_self : (gk < N + R ? a.mask_ref : a.mask_text);
+            const int mi = gk < N ? b * N + gk : (gk < N + R ? b * R + (gk - N) : b * P + (gk - N - R));
+            kval = !mk || mk[mi];
         }
-        const unsigned long long vmask = __ballot(kval);
-        __syncthreads();
+        return __ballot(kval);
+    };
 
+    // ---- one chunk of keys against the staged query tile: S^T, online softmax, O^T += V^T P^T ---------------------------------
+    auto compute_chunk = [&](int OFF_K, int OFF_V, unsigned long long vmask) {
         // ---- S^T chunk: 2 key tiles x 32 queries ----------------------------------------------------------------
         floatx16 s[2];
 #pragma unroll
@@ -295,9 +300,10 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(AttnArgs a) {
                 oacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, ph, oacc, 0, 0, 0);
             }
         }
-    }
+    };
 
     // ---- normalise, gate, store: lane = query fr, rows = dims 32 w + (r&3) + 8 (r>>2) + 4 fh ---------------------------
+    auto finish = [&](int q0) {
     const int n = q0 + fr;
     if (w < NDT && n < N) {
         const float inv = l_run > 0.f ? 1.0f / l_run : 0.f;
@@ -320,21 +326,70 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(AttnArgs a) {
             }
         }
     }
+    };
+    auto reset = [&] {
+        m_run = -INFINITY; l_run = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[r] = 0.f;
+    };
+
+    if (RES == 0) {
+        const int q0 = blockIdx.x * QT;
+        stage_q(q0);
+        reset();
+        for (int c0 = 0; c0 < Ktot; c0 += KC) {
+            __syncthreads();  // previous chunk consumed (and Q image visible on the first pass)
+            stage_kv(c0, OFF_K0, OFF_V0);
+            const unsigned long long vmask = chunk_mask(c0);
+            __syncthreads();
+            compute_chunk(OFF_K0, OFF_V0, vmask);
+        }
+        finish(q0);
+    } else {
+        unsigned long long vm[NRES];
+#pragma unroll
+        for (int c = 0; c < NRES; ++c) {
+            vm[c] = 0;
+            if (c * KC < Ktot) {   // (uniform)
+                stage_kv(c * KC, OFF_K0 + c * 2 * K_ARR, OFF_V0 + c * 2 * V_ARR);
+                vm[c] = chunk_mask(c * KC);
+            }
+        }
+        for (int q0 = 0; q0 < N; q0 += QT) {
+            __syncthreads();   // the previous tile's reads of the Q image are done
+            stage_q(q0);
+            reset();
+            __syncthreads();   // Q tile (and, on the first pass, every K / V chunk) visible
+#pragma unroll
+            for (int c = 0; c < NRES; ++c)
+                if (c * KC < Ktot) compute_chunk(OFF_K0 + c * 2 * K_ARR, OFF_V0 + c * 2 * V_ARR, vm[c]);
+            finish(q0);
+        }
+    }
 }
 
-template <int DH, bool PREP>
+template <int DH, bool PREP, int RES = 0>
 static hipError_t attn_mfma_go(const AttnArgs& a, hipStream_t st) {
     constexpr int DHP = DH <= 64 ? 64 : 128;
-    constexpr size_t lds = 2 * (32 * DHP * 2) + 2 * (64 * DHP * 2) + 2 * (DHP * 128);
-    auto kern = attention_mfma_kernel<DH, PREP>;
+    constexpr size_t lds = 2 * (32 * DHP * 2) + (RES ? RES : 1) * (2 * (64 * DHP * 2) + 2 * (DHP * 128));
+    static_assert(lds <= 160 * 1024, "resident K / V exceed LDS");
+    auto kern = attention_mfma_kernel<DH, PREP, RES>;
     static DevOnce once;
     hipError_t e = once.ensure([&] {
         return hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     });
     if (e != hipSuccess) return e;
-    dim3 grid((a.N + 31) / 32, a.H, a.B);
+    dim3 grid(RES ? 1 : (a.N + 31) / 32, a.H, a.B);
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, a);
     return hipGetLastError();
+}
+
+// The resident form pays when the streaming grid would be several rounds and the (batch, head) grid still fills the chip's better
+// half: the teacher's CFG batches (B = 24: 576 -> 192 workgroups).  B = 8 (192 -> 64 workgroups) keeps the streaming form.
+int g_attn_resident = 1;   // SMTTS_ATTN_RES=0: never (A/B switch, read by the engine)
+bool attention_mfma_resident(const AttnArgs& a) {
+    const int kt = a.N + (a.k_ref ? a.R : 0) + (a.k_text ? a.P : 0);
+    return g_attn_resident && a.dh == 120 && kt <= 128 && a.N > 32 && (long)a.B * a.H >= 128;
 }
 
 // a.prenormed = 1: q, k already RMS-normalised + rotated in place by launch_qk_prep; 0: raw projections, prepared while staging.
@@ -350,7 +405,9 @@ hipError_t launch_attention_mfma(const AttnArgs& a, hipStream_t st) {
                  4.0 * bh * a.N * kt * a.dh, 4.0 * bh * a.dh * (5.0 * a.N + 2.0 * (kt - a.N)));
     switch (a.dh) {
         case 64: return a.prenormed ? attn_mfma_go<64, false>(a, st) : attn_mfma_go<64, true>(a, st);
-        case 120: return a.prenormed ? attn_mfma_go<120, false>(a, st) : attn_mfma_go<120, true>(a, st);
+        case 120:
+            if (attention_mfma_resident(a)) return a.prenormed ? attn_mfma_go<120, false, 2>(a, st) : attn_mfma_go<120, true, 2>(a, st);
+            return a.prenormed ? attn_mfma_go<120, false>(a, st) : attn_mfma_go<120, true>(a, st);
         case 128: return a.prenormed ? attn_mfma_go<128, false>(a, st) : attn_mfma_go<128, true>(a, st);
     }
     return hipErrorInvalidValue;

@@ -46,6 +46,7 @@ Engine::Engine(int device) : device_(device) {
     if (s && *s == '1') dual_stream_ = false;
     if ((s = getenv("SMTTS_BLOCK_WAVE"))) block_wave_ = atoi(s) != 0;
     if ((s = getenv("SMTTS_SMALLM_SPLITK"))) g_small_m_splitk = atoi(s);
+    if ((s = getenv("SMTTS_ATTN_RES"))) g_attn_resident = atoi(s);
     if ((s = getenv("SMTTS_ATTN_PREP"))) attn_prep_fused_ = atoi(s);   // 0: separate qk_prep launch, 1: fused up to one workgroup per CU, 2: always fused
     if ((s = getenv("SMTTS_UP_G3_MINK")) && atoi(s) >= 64) up_g3_mink_ = atoi(s);
     if ((s = getenv("SMTTS_KSPLIT_OUT")) && atoi(s) >= 1 && atoi(s) <= kSplitK) ksplit_out_ = atoi(s);
@@ -931,6 +932,7 @@ struct CoreWs {
 // workgroups) loses the second resident workgroup per CU and the separate qk_prep launch wins (128-step teacher 257 vs 269 ms)
 bool Engine::attn_fuse_prep(const AttnArgs& a) const {
     if (!attn_mfma_ || !attn_prep_fused_) return false;
+    if (attention_mfma_resident(a)) return true;   // keys are prepared once per (batch, head) there: no redundancy to weigh
     const long wgs = (long)((a.N + 31) / 32) * a.H * a.B;
     return attn_prep_fused_ > 1 || wgs <= num_cus_;
 }

@@ -45,6 +45,10 @@ struct AttnArgs {
 hipError_t launch_attention(const AttnArgs& a, hipStream_t st);
 // Matrix-core variant (attention_mfma.hip): same arguments, needs prenormed = 1.
 hipError_t launch_attention_mfma(const AttnArgs& a, hipStream_t st);
+// true when launch_attention_mfma will take its resident-K/V form for these arguments (one workgroup per (batch, head), every key
+// staged and prepared once): the q / k prep is then always worth fusing
+bool attention_mfma_resident(const AttnArgs& a);
+extern int g_attn_resident;
 // In place on the packed projection buffer: q <- RoPE(RMSNorm_head(q) * qw), k <- RoPE(RMSNorm_head(k) * kw)
 // (dit.py:95-108); one wave per (row, head, q|k).  Uses the q/k/bs/rs/qw/kw/eps/rope/rot_dim/B/N/H/dh fields.
 hipError_t launch_qk_prep(const AttnArgs& a, hipStream_t st);

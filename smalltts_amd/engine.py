@@ -378,8 +378,10 @@ class HipEngine:
         P = 0 if k_text is None else k_text.shape[2]
         out = torch.empty(B, N, H * dh, device=self.device)
         fn = self.lib.smtts_test_attention_mfma if mfma else self.lib.smtts_test_attention
-        if mfma:   # True / "fused": q / k prep inside the attention kernel (the engine default); "prep": separate qk_prep launch
-            self._ck(self.lib.smtts_test_set_attention_mfma(self.h, 2 if mfma == "prep" else 1), "set_attention_mfma")
+        if mfma:   # True / "fused": q / k prep inside the attention kernel (the engine default); "prep": separate qk_prep launch;
+            # a "+stream" suffix keeps the streaming form where the resident-K/V form would apply
+            mode = (2 if str(mfma).startswith("prep") else 1) + (4 if str(mfma).endswith("+stream") else 0)
+            self._ck(self.lib.smtts_test_set_attention_mfma(self.h, mode), "set_attention_mfma")
         self._ck(fn(self.h, self._stream(), _p(qkvg), _p(qw), _p(kw), eps, _p(rope), rot_dim,
                                                _p(k_ref), _p(v_ref), R, _p(k_text), _p(v_text), P, _p(mask_self),
                                                _p(mask_ref), _p(mask_text), B, N, H, dh, _p(out)), "test_attention")

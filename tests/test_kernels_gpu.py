@@ -171,7 +171,7 @@ def _attn_ref(qkvg, qw, kw, eps, rope, rot, H, dh, kr, vr, kt, vt, ms, mr, mt):
 
 @pytest.mark.parametrize("B,N,H,dh,rot,R,P", [(2, 75, 8, 120, 64, 15, 30), (3, 21, 8, 64, 64, 0, 0),
                                              (2, 40, 4, 128, 128, 0, 0), (2, 130, 8, 120, 64, 70, 90),
-                                             (1, 5, 8, 120, 64, 3, 2)])
+                                             (1, 5, 8, 120, 64, 3, 2), (16, 75, 8, 120, 64, 15, 30)])   # last: resident-K/V form
 @pytest.mark.parametrize("mfma", [False, "fused", "prep"])
 def test_attention(eng, B, N, H, dh, rot, R, P, mfma):
     D = H * dh
@@ -191,6 +191,26 @@ def test_attention(eng, B, N, H, dh, rot, R, P, mfma):
     got = eng.test_attention(qkvg, qw, kw, 1e-6, rope, rot, H, dh, kr, vr, kt, vt, ms, mr, mt, mfma=mfma).cpu()
     err = rel_l2(got.numpy(), ref.numpy())
     assert err < (3e-5 if mfma else 1e-5), f"attention (mfma={mfma}): {err:.3e}"
+
+
+def test_attention_resident_form_is_bit_identical_to_the_streaming_form(eng):
+    """B x H >= 128 and <= 128 keys: one workgroup per (batch, head) keeps every key / value in LDS across its query tiles
+    (the teacher's CFG batches).  Same arithmetic in the same order -> the same bits as the 32-query streaming workgroups."""
+    B, N, H, dh, rot, R, P = 16, 75, 8, 120, 64, 15, 30
+    D = H * dh
+    qkvg = _rand(B, N, 4 * D, seed=40)
+    qw, kw = 1 + 0.2 * _rand(H, dh, seed=41), 1 + 0.2 * _rand(H, dh, seed=42)
+    inv = 1.0 / (1e4 ** (torch.arange(0, rot, 2).float() / rot))
+    rope = (torch.arange(N).float()[:, None] * inv[None]).repeat_interleave(2, -1).contiguous()
+    ms = torch.ones(B, N, dtype=torch.bool); ms[3, 60:] = False
+    kr, vr = _rand(B, H, R, dh, seed=43), _rand(B, H, R, dh, seed=44)
+    kt, vt = _rand(B, H, P, dh, seed=45), _rand(B, H, P, dh, seed=46)
+    mr = torch.ones(B, R, dtype=torch.bool); mr[1, 7:] = False
+    mt = torch.ones(B, P, dtype=torch.bool); mt[2, :] = False
+    for mode in ("fused", "prep"):
+        res = eng.test_attention(qkvg, qw, kw, 1e-6, rope, rot, H, dh, kr, vr, kt, vt, ms, mr, mt, mfma=mode).cpu()
+        stream = eng.test_attention(qkvg, qw, kw, 1e-6, rope, rot, H, dh, kr, vr, kt, vt, ms, mr, mt, mfma=mode + "+stream").cpu()
+        assert torch.equal(res, stream), f"{mode}: resident vs streaming max diff {float((res - stream).abs().max()):.3e}"
 
 
 def test_attention_all_keys_masked_gives_zero(eng):
