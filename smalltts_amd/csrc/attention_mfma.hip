@@ -389,7 +389,7 @@ static hipError_t attn_mfma_go(const AttnArgs& a, hipStream_t st) {
 int g_attn_resident = 1;   // SMTTS_ATTN_RES=0: never (A/B switch, read by the engine)
 bool attention_mfma_resident(const AttnArgs& a) {
     const int kt = a.N + (a.k_ref ? a.R : 0) + (a.k_text ? a.P : 0);
-    return g_attn_resident && a.dh == 120 && kt <= 128 && a.N > 32 && (long)a.B * a.H >= 128;
+    return g_attn_resident && a.dh == 120 && kt <= 128 && a.N > 32 && (long)a.B * a.H >= (g_attn_resident >= 2 ? g_attn_resident : 128);   // (>= 2: A/B override of the grid threshold)
 }
 
 // a.prenormed = 1: q, k already RMS-normalised + rotated in place by launch_qk_prep; 0: raw projections, prepared while staging.
