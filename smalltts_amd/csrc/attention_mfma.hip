@@ -63,21 +63,27 @@ __device__ __forceinline__ float4 prep_row4(float4 v, float4 w4, const Rope4& r,
 // workgroup walks its query tiles.  For grids that are several rounds of the streaming form (the teacher's 3B-row CFG batches:
 // 576 workgroups that each re-stage the same 120 keys) this removes two thirds of the staging, which is most of this kernel's time.
 // Same arithmetic in the same order per (query, key) as RES = 0: the two forms are bit-identical (test_kernels_gpu.py).
+// The resident form runs TWO 4-wave groups: all eight waves stage the keys / values, then each group takes every other query tile
+// (own Q image, own softmax state), so a (batch, head) of three tiles costs one staging + two tile rounds instead of three.
 template <int DH, bool PREP, int RES>
-__global__ __launch_bounds__(256) void attention_mfma_kernel(AttnArgs a) {
+__global__ __launch_bounds__(RES ? 512 : 256) void attention_mfma_kernel(AttnArgs a) {
     constexpr int DHP = DH <= 64 ? 64 : 128;  // padded head dim (K of QK^T), zero filled
     constexpr int KC = 64, QT = 32;
     constexpr int QPITCH = DHP * 2;            // bytes per row of the Q / K images
     constexpr int CPR = QPITCH / 16;           // 16-B chunks per row (8 or 16)
     constexpr int Q_ARR = QT * QPITCH, K_ARR = KC * QPITCH, V_ARR = DHP * 128;  // Vt rows: 64 keys x 2 B = 128 B
     constexpr int NRES = RES ? RES : 1;        // resident chunk buffers
-    constexpr int OFF_Q = 0, OFF_K0 = OFF_Q + 2 * Q_ARR, OFF_V0 = OFF_K0 + NRES * 2 * K_ARR;
+    constexpr int NG = RES ? 2 : 1, NT = 256 * NG;   // query-tile groups of 4 waves, threads
+    constexpr int OFF_K0 = NG * 2 * Q_ARR, OFF_V0 = OFF_K0 + NRES * 2 * K_ARR;
     constexpr int NDT = DHP / 32;              // 32-dim tiles of O^T (2 or 4); wave w owns tile w (w < NDT)
     constexpr int KS1 = DHP / 16;              // k16 steps of S^T
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63;
-    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int gtid = tid & 255;                                          // thread inside its 4-wave group
+    const int grp = __builtin_amdgcn_readfirstlane(tid >> 8);           // group (0 unless RES)
+    const int w = __builtin_amdgcn_readfirstlane((tid >> 6) & 3);       // wave inside the group: owns O^T tile w
+    const int OFF_Q = grp * 2 * Q_ARR;                                   // the group's own Q image
     const int h = blockIdx.y, b = blockIdx.z;
     const int N = a.N, R = a.k_ref ? a.R : 0, P = a.k_text ? a.P : 0, Ktot = N + R + P;
     const float sm_scale = 1.0f / sqrtf((float)DH);
@@ -88,21 +94,21 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(AttnArgs a) {
     // ---- stage Q (pre-scaled), split hi/lo: thread -> (query, 4 dims); every load of the tile is issued before the first use
     auto stage_q = [&](int q0) {
         constexpr int TPR = DHP / 4, NQP = QT * TPR / 256;   // lanes per row, passes (2 or 4)
-        const int d = (tid % TPR) * 4;
+        const int d = (gtid % TPR) * 4;
         float4 qv[NQP];
         Rope4 qr[NQP];
         float4 qw4 = make_float4(0.f, 0.f, 0.f, 0.f);
         if (PREP && d < DH) qw4 = *reinterpret_cast<const float4*>(a.qw + h * DH + d);
 #pragma unroll
         for (int j = 0; j < NQP; ++j) {
-            const int r = tid / TPR + j * (256 / TPR), n = q0 + r;
+            const int r = gtid / TPR + j * (256 / TPR), n = q0 + r;
             qv[j] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (n < N && d < DH) qv[j] = *reinterpret_cast<const float4*>(a.q + (long)b * a.bs + (long)n * a.rs + h * DH + d);
             if (PREP) qr[j] = rope4_load(a, n, d, n < N);
         }
 #pragma unroll
         for (int j = 0; j < NQP; ++j) {
-            const int r = tid / TPR + j * (256 / TPR);
+            const int r = gtid / TPR + j * (256 / TPR);
             float4 v = qv[j];
             if (PREP) v = prep_row4<DH, TPR>(v, qw4, qr[j], a.eps);
             const float f[4] = {v.x * sm_scale, v.y * sm_scale, v.z * sm_scale, v.w * sm_scale};
@@ -124,7 +130,7 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(AttnArgs a) {
     auto stage_kv = [&](int c0, int OFF_K, int OFF_V) {
         {
             constexpr int TPR = DHP / 4;                 // threads per key row (16 or 32)
-            constexpr int ITEMS = KC * TPR / 256;        // keys per thread (4 or 8)
+            constexpr int ITEMS = KC * TPR / NT;         // keys per thread (2, 4 or 8)
             const int r0 = (tid / TPR) * ITEMS, d = (tid % TPR) * 4;
             float4 kq[ITEMS], vq[ITEMS];
             Rope4 kr[PREP ? ITEMS : 1];
@@ -355,15 +361,19 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(AttnArgs a) {
                 vm[c] = chunk_mask(c * KC);
             }
         }
-        for (int q0 = 0; q0 < N; q0 += QT) {
-            __syncthreads();   // the previous tile's reads of the Q image are done
-            stage_q(q0);
+        for (int qb = 0; qb < N; qb += NG * QT) {   // both groups walk the same number of rounds (barriers are workgroup-wide)
+            const int q0 = qb + grp * QT;
+            const bool live = q0 < N;               // (uniform per wave)
+            __syncthreads();   // the previous round's reads of the Q images are done
+            if (live) stage_q(q0);
             reset();
-            __syncthreads();   // Q tile (and, on the first pass, every K / V chunk) visible
+            __syncthreads();   // Q tiles (and, on the first round, every K / V chunk) visible
+            if (live) {
 #pragma unroll
-            for (int c = 0; c < NRES; ++c)
-                if (c * KC < Ktot) compute_chunk(OFF_K0 + c * 2 * K_ARR, OFF_V0 + c * 2 * V_ARR, vm[c]);
-            finish(q0);
+                for (int c = 0; c < NRES; ++c)
+                    if (c * KC < Ktot) compute_chunk(OFF_K0 + c * 2 * K_ARR, OFF_V0 + c * 2 * V_ARR, vm[c]);
+                finish(q0);
+            }
         }
     }
 }
@@ -371,7 +381,7 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(AttnArgs a) {
 template <int DH, bool PREP, int RES = 0>
 static hipError_t attn_mfma_go(const AttnArgs& a, hipStream_t st) {
     constexpr int DHP = DH <= 64 ? 64 : 128;
-    constexpr size_t lds = 2 * (32 * DHP * 2) + (RES ? RES : 1) * (2 * (64 * DHP * 2) + 2 * (DHP * 128));
+    constexpr size_t lds = (RES ? 2 : 1) * 2 * (32 * DHP * 2) + (RES ? RES : 1) * (2 * (64 * DHP * 2) + 2 * (DHP * 128));
     static_assert(lds <= 160 * 1024, "resident K / V exceed LDS");
     auto kern = attention_mfma_kernel<DH, PREP, RES>;
     static DevOnce once;
@@ -380,7 +390,7 @@ static hipError_t attn_mfma_go(const AttnArgs& a, hipStream_t st) {
     });
     if (e != hipSuccess) return e;
     dim3 grid(RES ? 1 : (a.N + 31) / 32, a.H, a.B);
-    hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, a);
+    hipLaunchKernelGGL(kern, grid, dim3(RES ? 512 : 256), lds, st, a);
     return hipGetLastError();
 }
 
