@@ -278,14 +278,25 @@ def make_handler(batcher: Batcher, tokenizer: str = "espeak"):
                 return self._send(404, b"not found")
             try:
                 q = urllib.parse.parse_qs(url.query)
+                n = int(self.headers.get("content-length") or 0)
+                # The body is taken off the socket before ANY answer: a client that writes its whole request before it reads
+                # (http.client, curl) would otherwise see EPIPE / a reset instead of the status.  Over the limit it is discarded,
+                # a bounded amount of it; beyond that the connection is simply closed after the answer.
+                if n > BODY_LIMIT:
+                    left = min(n, 8 * BODY_LIMIT)
+                    while left > 0:
+                        chunk = self.rfile.read(min(left, 1 << 16))
+                        if not chunk:
+                            break
+                        left -= len(chunk)
+                    self.close_connection = True
+                    raise HttpError(413, "length limit exceeded")
+                body = self.rfile.read(n)
                 try:
                     duration = float(q["duration"][0])
                 except Exception:
                     raise HttpError(400, "Failed to deserialize query string: missing field `duration`")
-                n = int(self.headers.get("content-length") or 0)
-                if n > BODY_LIMIT:
-                    raise HttpError(413, "length limit exceeded")
-                fields = parse_multipart(self.headers.get("content-type", ""), self.rfile.read(n))
+                fields = parse_multipart(self.headers.get("content-type", ""), body)
                 if "audio" not in fields:
                     raise HttpError(400, "missing 'audio'")
                 if "text" not in fields and "tokens" not in fields:
