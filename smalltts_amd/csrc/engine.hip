@@ -47,6 +47,7 @@ Engine::Engine(int device) : device_(device) {
     if ((s = getenv("SMTTS_BLOCK_WAVE"))) block_wave_ = atoi(s) != 0;
     if ((s = getenv("SMTTS_SMALLM_SPLITK"))) g_small_m_splitk = atoi(s);
     if ((s = getenv("SMTTS_ATTN_RES"))) g_attn_resident = atoi(s);
+    if ((s = getenv("SMTTS_CONVPOS_BY_GROUP"))) convpos_by_group_ = atoi(s) != 0;
     if ((s = getenv("SMTTS_ATTN_PREP"))) attn_prep_fused_ = atoi(s);   // 0: separate qk_prep launch, 1: fused up to one workgroup per CU, 2: always fused
     if ((s = getenv("SMTTS_UP_G3_MINK")) && atoi(s) >= 64) up_g3_mink_ = atoi(s);
     if ((s = getenv("SMTTS_KSPLIT_OUT")) && atoi(s) >= 1 && atoi(s) <= kSplitK) ksplit_out_ = atoi(s);
@@ -969,21 +970,25 @@ int Engine::denoise_core(hipStream_t st, const float* x_t, const uint8_t* mask, 
     HIPC(hipMemsetAsync(w.gm2.lo, 0, w.gm_elems * 2, st));
     {
         // grouped conv k=31 as B*G small GEMMs: z = b*G + g, rows = frames, K = 31 taps x 64 (padded) channels
+        // one product per GROUP over the rows of the whole batch (z = g, row m = (b, frame)): B * N rows fill their 64-row tiles
+        // (600 rows: 94 %) where one product per (utterance, group) left the second tile of N = 75 rows at 11 of 64 (SMTTS_CONVPOS_BY_GROUP=0)
         const long zs = (long)(N + 2 * kConvPad) * kConvGs;
-        Gemm3Operands g = ops3(w.gm1, rowmap_plain(kConvGs), conv1_, N, pc, 0, kConvCpg);
+        const RowMap am = convpos_by_group_ ? rowmap_batched(kConvGs, N, (long)kConvG * zs, 0) : rowmap_plain(kConvGs);
+        const int rows = convpos_by_group_ ? B * N : N, nz = convpos_by_group_ ? kConvG : B * kConvG;
+        Gemm3Operands g = ops3(w.gm1, am, conv1_, rows, pc, 0, kConvCpg);
         g.a_z = zs;
         g.w_z = (long)kConvCpg * conv1_.K;
         g.w_zmod = kConvG;
         EpiConvPos<0> e1{nullptr, nullptr, rawp("dit.input_embed.conv_pos_embed.conv1.bias"), mask, kConvG, kConvCpg, N,
-                         kConvPad, kConvGs, gm2.hi, gm2.lo};
-        HIPC(gemm3_convpos(g, false, e1, B * kConvG, pc, st));
-        g = ops3(w.gm2, rowmap_plain(kConvGs), conv2_, N, pc, 0, kConvCpg);
+                         kConvPad, kConvGs, gm2.hi, gm2.lo, convpos_by_group_ ? 1 : 0};
+        HIPC(gemm3_convpos(g, false, e1, nz, pc, st));
+        g = ops3(w.gm2, am, conv2_, rows, pc, 0, kConvCpg);
         g.a_z = zs;
         g.w_z = (long)kConvCpg * conv2_.K;
         g.w_zmod = kConvG;
         EpiConvPos<0> e2{w.x, w.h, rawp("dit.input_embed.conv_pos_embed.conv2.bias"), mask, kConvG, kConvCpg, N,
-                         kConvPad, kConvGs, nullptr, nullptr};
-        HIPC(gemm3_convpos(g, true, e2, B * kConvG, pc, st));
+                         kConvPad, kConvGs, nullptr, nullptr, convpos_by_group_ ? 1 : 0};
+        HIPC(gemm3_convpos(g, true, e2, nz, pc, st));
     }
     // zero the padded tail columns [2400, 2432) of the FF hidden once per call
     HIPC(hipMemsetAsync(w.ffh.hi, 0, (size_t)M * kFFp * 2, st));

@@ -222,6 +222,7 @@ class Engine {
     int ensure_aux();
     int attn_prep_fused_ = 1;  // q / k head-norm + RoPE inside attention_mfma's staging: 1 = when the grid is <= one workgroup per CU, 2 = always, 0 = separate qk_prep launch (in place)
     int num_cus_ = 256;
+    bool convpos_by_group_ = true;  // grouped conv pos-embed as one product per group over the batch's rows (false: per (utterance, group))
     bool attn_fuse_prep(const struct AttnArgs& a) const;
     bool attn_mfma_ = true;  // matrix-core attention (attention_mfma.hip); false = fp32 VALU kernel (attention.hip)
     Profiler prof_;

@@ -431,21 +431,23 @@ struct EpiConvPos {
     int G, cpg, T, pad, gstride;  // gstride = padded channels per group in gm image
     bf16_t* ohi;          // FINAL == 0: optional split output image
     bf16_t* olo;
+    int by_group = 0;     // 0: z = b * G + g, rows = frames of one utterance; 1: z = g, rows = (b, frame) of the whole batch
     __device__ __forceinline__ void rows(int z, int mb, int M, RowCtx& rc) const {
-        const int b = z / G;
         rc.valid = 0;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int m = epi_row(mb, r);
             const bool ok = m < M;
             const int mm = ok ? m : 0;
-            rc.aux[r] = mask[b * T + mm];
-            rc.off[r] = FINAL ? ((long)b * T + mm) * (G * cpg) : ((long)z * (T + 2 * pad) + pad + mm) * gstride;
+            const int b = by_group ? mm / T : z / G, t = by_group ? mm - b * T : mm;
+            const long zz = by_group ? (long)b * G + z : z;
+            rc.aux[r] = mask[b * T + t];
+            rc.off[r] = FINAL ? ((long)b * T + t) * (G * cpg) : (zz * (T + 2 * pad) + pad + t) * gstride;
             rc.valid |= (ok ? 1u : 0u) << r;
         }
     }
     __device__ __forceinline__ void col(int z, int n, const RowCtx& rc, const floatx16& acc) const {
-        const int ch = (z % G) * cpg + n;
+        const int ch = (by_group ? z : z % G) * cpg + n;
         const float bv = bias[ch];
         float hv[16];
 #pragma unroll
