@@ -274,7 +274,13 @@ static inline int gemm3_pick_cfg(int M, int N, bool paired, bool single = false 
     // measured (profiles/r02k_ab_keepx_w4.txt): the wide, short-K first FFN product of the codec's GEMM stages gains (24000 x 2048 x 512:
     // 122 -> 98 us, 4800 x 4096 x 1024: 86 -> 72 us), the narrow long-K second product loses (94 -> 102, 64 -> 81 us) -> wide N only
     if (g_gemm3_w4_minm > 0 && M >= g_gemm3_w4_minm && N >= 2048) return G3_128x128_W4;
-    if (paired) return G3_128x128;
+    if (paired) {
+        // the SwiGLU pair epilogue needs 32x64 wave tiles: 128x128 or 160x128.  Single-array formats run two such workgroups per
+        // CU, so 512 tiles are one round: the teacher's 1800 x 4800 FF1 is 570 tiles of 128x128 (two rounds) but 456 of 160x128
+        const long t128p = (long)((M + 127) / 128) * ((N + 127) / 128), t160p = (long)((M + 159) / 160) * ((N + 127) / 128);
+        if (single && t128p > 512 && t160p <= 512) return G3_160x128;
+        return G3_128x128;
+    }
     if (N <= 32) return G3_128x32;
     if (N <= 64) return M >= 2048 ? G3_128x64 : G3_64x64;
     // cost model measured on MI355X: time ~ rounds(tiles / 256 CUs) x bytes ingested per workgroup / ~40 GB/s.
@@ -338,8 +344,7 @@ static inline hipError_t gemm3_launch_split(const Gemm3Operands& g, const Epi& e
                     if constexpr (!Epi::PAIRED) return gemm3_launch_cfg<64, 64, 2, 2, SPLIT, 4, Epi>(g, epi, Z, st);
                     break;
                 case G3_160x128:
-                    if constexpr (!Epi::PAIRED) return gemm3_launch_cfg<160, 128, 5, 2, SPLIT, 4, Epi>(g, epi, Z, st);
-                    break;
+                    return gemm3_launch_cfg<160, 128, 5, 2, SPLIT, 4, Epi>(g, epi, Z, st);
                 default:
                     break;  // the tall 128x64 / 128x32 shapes (codec, M >= 2048) keep their depth: many rounds, never latency-bound
             }
@@ -360,9 +365,8 @@ static inline hipError_t gemm3_launch_split(const Gemm3Operands& g, const Epi& e
         case G3_128x32:
             if constexpr (!Epi::PAIRED) return gemm3_launch_cfg<128, 32, 4, 1, SPLIT, 2, Epi>(g, epi, Z, st);
             break;
-        case G3_160x128:
-            if constexpr (!Epi::PAIRED) return gemm3_launch_cfg<160, 128, 5, 2, SPLIT, 2, Epi>(g, epi, Z, st);
-            break;
+        case G3_160x128:   // (32x64 wave tiles: also valid for the paired SwiGLU epilogue)
+            return gemm3_launch_cfg<160, 128, 5, 2, SPLIT, 2, Epi>(g, epi, Z, st);
         case G3_128x128_W4:
             if constexpr (SPLIT != 3) return gemm3_launch_cfg<128, 128, 2, 2, SPLIT, 2, Epi>(g, epi, Z, st);
             break;

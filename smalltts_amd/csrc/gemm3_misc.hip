@@ -1,8 +1,9 @@
 #include "gemm_ops.hpp"
 #include "prof.hpp"
 hipError_t gemm3_swiglu(const Gemm3Operands& g, const EpiSwiGLU& p, int split, hipStream_t st) {
-    ProfScope ps(st, gemm3_prof_name(g, true, G3_128x128, split, "swiglu"), gemm3_flops(g, 1), gemm3_bytes(g, 1, split, 2.0), gemm_bytes8d(g.N, g.K, (g.ksplit_tiles ? 1 : 1)));
-    return gemm3_launch(g, p, 1, split, st, G3_128x128);
+    const int cfg = gemm3_pick_cfg(g.M, g.N, true, split != PREC_BF16X3);
+    ProfScope ps(st, gemm3_prof_name(g, true, cfg, split, "swiglu"), gemm3_flops(g, 1), gemm3_bytes(g, 1, split, 2.0), gemm_bytes8d(g.N, g.K, (g.ksplit_tiles ? 1 : 1)));
+    return gemm3_launch(g, p, 1, split, st, cfg);
 }
 hipError_t gemm3_kv(const Gemm3Operands& g, const EpiKV& p, int split, hipStream_t st) {
     ProfScope ps(st, gemm3_prof_name(g, false, -1, split, "kv_scatter"), gemm3_flops(g, 1), gemm3_bytes(g, 1, split, 4.0), gemm_bytes8d(g.N, g.K, (g.ksplit_tiles ? 1 : 1)));

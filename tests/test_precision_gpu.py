@@ -205,3 +205,25 @@ def test_default_precision_teacher_128_steps_stays_inside_the_contract(eng, dit_
     print(f"\n[teacher 128 @ f16 mixed] x0-hat rel L2 vs oracle: step 0 {errs[0]:.2e}, 31 {errs[31]:.2e}, 63 {errs[63]:.2e}, "
           f"127 {errs[127]:.2e}, max {max(errs):.2e} at step {int(np.argmax(errs))}; final latents {end:.2e}")
     assert max(errs) < 1e-3 and end < 1e-3, f"128-step chain at the default precision: max {max(errs):.3e}, end {end:.3e}"
+
+
+def test_default_precision_teacher_cfg_at_bench_size_vs_oracle(eng, dit_weights):
+    """Config 5's row count at the shipped precision: B = 8 x N = 75 with CFG = 1800 rows per denoiser call — the shapes that take
+    the one-round tile choices of the single-array formats (128x128 QKVG on shallow rings, 160x128 SwiGLU pairs), the resident-K/V
+    attention form (24 x 8 workgroups) and the per-group conv pos-embed over 1800 rows; two chained ODE + CFG steps."""
+    gen = torch.Generator().manual_seed(15)
+    B, N, R, P, steps = 8, 75, 15, 30, 2
+    ref = torch.randn(B, R, 64, generator=gen)
+    ids = torch.randint(1, 198, (B, P), generator=gen)
+    pm = torch.ones(B, P, dtype=torch.bool); rl = torch.full((B,), R)
+    mask = torch.ones(B, N, dtype=torch.bool)
+    noise = torch.randn(B, N, 64, generator=gen)
+    ref3, len3, ids3, pm3 = O.cfg_conditions(ref, rl, ids, pm)
+    with torch.no_grad():
+        oc = O.encode_conditions(dit_weights, ref3, len3, ids3, pm3)
+        ox = O.sample_teacher_ode(dit_weights, oc, pm3, mask, noise, steps)
+    cache3 = eng.cond_encode(ref3, len3, ids3, pm3)
+    x = eng.sample(cache3, mask, num_steps=steps, mode="ode", cfg=True, noise=noise).cpu().numpy()
+    err = rel_l2(x, ox.numpy())
+    print(f"\n[teacher CFG, 1800 rows @ f16 mixed] latents rel L2 vs oracle {err:.2e}")
+    assert err < 1e-3, f"teacher ODE at 1800 rows, default precision: rel L2 {err:.3e}"
