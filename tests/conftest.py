@@ -13,6 +13,15 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # The CPU oracles are graphs of small torch ops: on the 256-core GPU box torch's default (all cores) is 3-30x SLOWER than 16
+    # threads (bench.py's thread probe: 176 ms per denoiser call at 16 threads, 483 at 64, minutes at 256), and the oracle side is
+    # most of the GPU suite's wall time.  SMTTS_TEST_THREADS overrides.
+    try:
+        import torch
+        n = int(os.environ.get("SMTTS_TEST_THREADS", "0")) or min(16, os.cpu_count() or 1)
+        torch.set_num_threads(max(1, n))
+    except Exception:
+        pass
 
 
 def golden(name):
