@@ -159,8 +159,8 @@ int smtts_test_attention_mfma(smtts_handle h, void* stream, const float* qkvg, c
                               const float* k_text, const float* v_text, int P, const uint8_t* mask_self,
                               const uint8_t* mask_ref, const uint8_t* mask_text, int B, int N, int H, int dh, float* out);
 /* engine-wide switch: 1 (default) = matrix-core attention, 0 = fp32 VALU attention kernel */
-/* mode 0: fp32 VALU attention; 1: matrix cores, q / k head-norm + RoPE fused into the staging (default); 2: matrix cores after a
- * separate in-place qk_prep launch; + 4: never the resident-K/V form of the matrix-core kernel (process-wide A/B switch) */
+/* mode 0: fp32 VALU attention; 1: matrix cores, q / k head-norm + RoPE fused into the staging; 2: matrix cores after a
+ * separate in-place qk_prep launch; 3: matrix cores, prep placement as the engine defaults (separate launch, SMTTS_ATTN_PREP); + 4: never the resident-K/V form of the matrix-core kernel (process-wide A/B switch) */
 int smtts_test_set_attention_mfma(smtts_handle h, int mode);
 
 #ifdef __cplusplus

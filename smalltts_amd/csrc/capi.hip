@@ -157,7 +157,8 @@ int smtts_test_gemm3(smtts_handle h, void* stream, const float* A, const float* 
 int smtts_test_set_fused_ffn(smtts_handle h, int on) { NULLCHK; E.set_fused_ffn(on != 0); return 0; }
 int smtts_test_set_attention_mfma(smtts_handle h, int mode) { NULLCHK;   // 0: fp32 VALU kernel, 1: matrix cores with q / k prep fused (default), 2: matrix cores after a separate qk_prep launch
     E.set_attn_mfma((mode & 3) != 0);
-    E.set_attn_prep_fused((mode & 3) != 2);
+    if ((mode & 3) == 3) E.reset_attn_prep_fused();   // 3: matrix cores, prep placement back to the engine default
+    else E.set_attn_prep_fused((mode & 3) != 2);
     g_attn_resident = (mode & 4) ? 0 : 1;   // + 4: streaming form only (process-wide switch; the resident-K/V form is the default where it applies)
     return 0;
 }

@@ -960,8 +960,8 @@ int Engine::denoise_core(hipStream_t st, const float* x_t, const uint8_t* mask, 
     const RowMap rh = rowmap_plain(kHidden);
     // operand formats: the block GEMMs run at SITE_DIT_BLOCK precision, the latent in-projection / conv pos-embed / velocity
     // head at SITE_COND; each activation buffer is written in the format of the GEMM that reads it
-    const int pb = prec_[SITE_DIT_BLOCK], pc = prec_[SITE_COND];
-    const SplitBuf gm1 = w.gm1.as(pc), gm2 = w.gm2.as(pc), yb = w.y.as(pb), ob = w.o.as(pb), ffh = w.ffh.as(pb);
+    const int pb = prec_[SITE_DIT_BLOCK], pc = prec_[SITE_COND], pcp = prec_[SITE_CONVPOS];
+    const SplitBuf gm1 = w.gm1.as(pcp), gm2 = w.gm2.as(pcp), yb = w.y.as(pb), ob = w.o.as(pb), ffh = w.ffh.as(pb);
     // D2 input embedding (dit.py:246-253): h = proj(x); x = mask*mish(conv2(mask*mish(conv1(mask*h)))) + h
     HIPC(gemm_store(ops(x_t, rowmap_plain(kLatent), inproj_, M), ACT_NONE,
                     store_to(w.h, rh, rawp("dit.input_embed.proj.bias")), 1, pc, st));
@@ -975,20 +975,20 @@ int Engine::denoise_core(hipStream_t st, const float* x_t, const uint8_t* mask, 
         const long zs = (long)(N + 2 * kConvPad) * kConvGs;
         const RowMap am = convpos_by_group_ ? rowmap_batched(kConvGs, N, (long)kConvG * zs, 0) : rowmap_plain(kConvGs);
         const int rows = convpos_by_group_ ? B * N : N, nz = convpos_by_group_ ? kConvG : B * kConvG;
-        Gemm3Operands g = ops3(w.gm1, am, conv1_, rows, pc, 0, kConvCpg);
+        Gemm3Operands g = ops3(w.gm1, am, conv1_, rows, pcp, 0, kConvCpg);
         g.a_z = zs;
         g.w_z = (long)kConvCpg * conv1_.K;
         g.w_zmod = kConvG;
         EpiConvPos<0> e1{nullptr, nullptr, rawp("dit.input_embed.conv_pos_embed.conv1.bias"), mask, kConvG, kConvCpg, N,
                          kConvPad, kConvGs, gm2.hi, gm2.lo, convpos_by_group_ ? 1 : 0};
-        HIPC(gemm3_convpos(g, false, e1, nz, pc, st));
-        g = ops3(w.gm2, am, conv2_, rows, pc, 0, kConvCpg);
+        HIPC(gemm3_convpos(g, false, e1, nz, pcp, st));
+        g = ops3(w.gm2, am, conv2_, rows, pcp, 0, kConvCpg);
         g.a_z = zs;
         g.w_z = (long)kConvCpg * conv2_.K;
         g.w_zmod = kConvG;
         EpiConvPos<0> e2{w.x, w.h, rawp("dit.input_embed.conv_pos_embed.conv2.bias"), mask, kConvG, kConvCpg, N,
                          kConvPad, kConvGs, nullptr, nullptr, convpos_by_group_ ? 1 : 0};
-        HIPC(gemm3_convpos(g, true, e2, nz, pc, st));
+        HIPC(gemm3_convpos(g, true, e2, nz, pcp, st));
     }
     // zero the padded tail columns [2400, 2432) of the FF hidden once per call
     HIPC(hipMemsetAsync(w.ffh.hi, 0, (size_t)M * kFFp * 2, st));

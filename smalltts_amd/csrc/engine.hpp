@@ -103,13 +103,14 @@ class Engine {
                 SITE_COND = 3,        // time / AdaLN modulation chain, latent in-projection, conv pos-embed, velocity head, style in-proj
                 SITE_CODEC_FFN = 4,   // codec block FFNs (fused kernels and the wide-stage GEMM pairs)
                 SITE_CODEC_CONV = 5,  // codec stem / resampling (ConvTranspose, strided conv) / encoder head GEMMs
-                SITE_COUNT = 6 };
+                SITE_CONVPOS = 6,     // the grouped conv k = 31 pos-embed of the DiT input embedding (split out of SITE_COND: 1.2 % of a batch's time)
+                SITE_COUNT = 7 };
     // preset: 3 = split-bf16 everywhere (fp32-class), 1 = single-pass bf16 everywhere, 2 = "f16 mixed": single-pass fp16 on
     // the block / encoder / cross-KV / codec-FFN GEMMs, split-bf16 on SITE_COND and SITE_CODEC_CONV
     void set_precision(int preset) {
         preset_ = preset == PREC_BF16 ? PREC_BF16 : preset == PREC_F16 ? PREC_F16 : PREC_BF16X3;
         for (int i = 0; i < SITE_COUNT; ++i) prec_[i] = preset_;
-        if (preset_ == PREC_F16) prec_[SITE_COND] = prec_[SITE_CODEC_CONV] = PREC_BF16X3;
+        if (preset_ == PREC_F16) prec_[SITE_COND] = prec_[SITE_CODEC_CONV] = prec_[SITE_CONVPOS] = PREC_BF16X3;
     }
     int set_site_precision(int site, int prec) {
         if (site < 0 || site >= SITE_COUNT || prec < 1 || prec > 3) return fail("set_site_precision: bad site / precision");
@@ -127,6 +128,7 @@ class Engine {
     void set_attn_mfma(bool on) { attn_mfma_ = on; }
     void set_attn_prep_fused(bool on) { attn_prep_fused_ = on ? 2 : 0; }   // (test hook: the kernel test wants the asked-for variant at any grid)
     bool attn_prep_fused() const { return attn_prep_fused_ != 0; }
+    void reset_attn_prep_fused() { const char* s = getenv("SMTTS_ATTN_PREP"); attn_prep_fused_ = s ? atoi(s) : 0; }
     void set_dual_stream(bool on) { dual_stream_ = on; }
     int precision() const { return preset_; }
 
@@ -210,7 +212,7 @@ class Engine {
     int tuning_ = TUNE_LATENCY;
     bool dual_stream_latency_ = true;  // the dual-stream setting that TUNE_LATENCY restores
     int preset_ = PREC_BF16X3;
-    int prec_[SITE_COUNT] = {3, 3, 3, 3, 3, 3};
+    int prec_[SITE_COUNT] = {3, 3, 3, 3, 3, 3, 3};
     bool fused_ffn_ = true;  // test hook: smtts_test_set_fused_ffn
     bool block_wave_ = true;  // codec stages with C = 32 / 64: mixer + FFN in one kernel (SMTTS_BLOCK_WAVE=0: mixer_fused + codec_ffn_wave)
     int up_g3_mink_ = 2048;  // codec ConvTranspose-as-GEMM: gemm3 on a converted copy of the image from this K up (SMTTS_UP_G3_MINK; below: fp32-A kernel)
@@ -220,7 +222,12 @@ class Engine {
     hipStream_t aux_ = nullptr;
     hipEvent_t ev_fork_ = nullptr, ev_join_ = nullptr;
     int ensure_aux();
-    int attn_prep_fused_ = 1;  // q / k head-norm + RoPE inside attention_mfma's staging: 1 = when the grid is <= one workgroup per CU, 2 = always, 0 = separate qk_prep launch (in place)
+    // q / k head-norm + RoPE inside attention_mfma's staging: 1 = when the grid is <= one workgroup per CU, 2 = always, 0 = separate
+    // qk_prep launch (in place).  DEFAULT 0: the fused kernels are faster (26.5 -> 21.0 us per DiT block) and bit-exact alone, but
+    // with other HIP streams active (dual-stream encoders, batches in flight) their results stopped repeating bit for bit —
+    // whole utterances off by ~5e-2 in the style encoder, 23 of 24 in-flight rounds different (tools/stress_determinism.py,
+    // profiles/r02bl_*).  Neither the kernel alone nor two of them side by side reproduce it; the separate launch never showed it.
+    int attn_prep_fused_ = 0;
     int num_cus_ = 256;
     bool convpos_by_group_ = true;  // grouped conv pos-embed as one product per group over the batch's rows (false: per (utterance, group))
     bool attn_fuse_prep(const struct AttnArgs& a) const;

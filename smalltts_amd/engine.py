@@ -18,7 +18,7 @@ from .weights import (DEFAULT_CODEC, CodecSpec, codec_decoder_param_specs, codec
 N_LAYERS, N_HEADS, HEAD_DIM, LATENT = 12, 8, 120, 64
 ACT = {"none": 0, "silu": 1, "gelu": 2, "mish": 3}
 PRECISION = {"bf16x3": 3, "f16": 2, "bf16": 1}   # presets of smtts_set_precision (include/smalltts_hip.h)
-SITES = {"dit_block": 0, "encoder": 1, "cross_kv": 2, "cond": 3, "codec_ffn": 4, "codec_conv": 5}
+SITES = {"dit_block": 0, "encoder": 1, "cross_kv": 2, "cond": 3, "codec_ffn": 4, "codec_conv": 5, "convpos": 6}
 DEFAULT_PRECISION = "f16"
 
 
@@ -386,5 +386,5 @@ class HipEngine:
                                                _p(k_ref), _p(v_ref), R, _p(k_text), _p(v_text), P, _p(mask_self),
                                                _p(mask_ref), _p(mask_text), B, N, H, dh, _p(out)), "test_attention")
         if mfma:
-            self._ck(self.lib.smtts_test_set_attention_mfma(self.h, 1), "set_attention_mfma")
+            self._ck(self.lib.smtts_test_set_attention_mfma(self.h, 3), "set_attention_mfma")
         return out

@@ -317,3 +317,49 @@ def test_wrong_shaped_checkpoint_is_a_clean_error_naming_the_tensor(tmp_path):
     e.finalize()
     assert e.has("dit")
     e.close()
+
+
+def test_results_repeat_bit_for_bit_next_to_other_streams():
+    """Bitwise repeatability with other HIP streams active — the two situations the product creates itself: the condition
+    encoders on two streams (latency tuning) and three batches in flight on three streams (throughput tuning, bench.py's
+    headline mode).  A fused q / k-prep attention kernel that was bit-exact alone failed exactly here, so this
+    runs the full-size bench shapes: 20 repeats of cond_encode, 6 rounds of three batches against the batches run alone."""
+    import bench
+    from smalltts_amd.engine import HipEngine
+    dev = torch.device("cuda", 0)
+    eng = HipEngine(0)
+    eng.load_synthetic(bench.SEED, parts=("dit", "decoder"))
+    eng.finalize()
+    inp = bench.make_inputs(dev, 0)
+
+    def cond():
+        c = eng.cond_encode(inp["ref"], inp["ref_len"], inp["ids"], inp["ph_mask"], debug=True)
+        return {k: v.clone() for k, v in c.items() if torch.is_tensor(v)}
+
+    a = cond()
+    for i in range(20):
+        b = cond()
+        diff = [k for k in a if not torch.equal(a[k], b[k])]
+        assert not diff, f"cond_encode repeat {i}: {diff} differ"
+    prev = eng.set_tuning("throughput")
+    try:
+        alone = [bench.one_step(eng, inp, 100 + i).clone() for i in range(3)]
+        streams = [torch.cuda.Stream(dev) for _ in range(3)]
+        for it in range(6):
+            outs = [None] * 3
+            cur = torch.cuda.current_stream(dev)
+            for s in streams:
+                s.wait_stream(cur)
+            for i in range(3):
+                with torch.cuda.stream(streams[i]):
+                    eng.use_workspace(f"batch{i}")
+                    outs[i] = bench.one_step(eng, inp, 100 + i)
+            eng.use_workspace(None)
+            for s in streams:
+                cur.wait_stream(s)
+            torch.cuda.synchronize()
+            for i in range(3):
+                assert torch.equal(outs[i], alone[i]), f"round {it}: batch {i} in flight differs from the same batch alone"
+    finally:
+        eng.use_workspace(None)
+        eng.set_tuning(prev)

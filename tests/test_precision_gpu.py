@@ -82,10 +82,12 @@ def test_default_precision_at_bench_shape_and_site_ladder(eng, dit_weights):
     err = rel_l2(run(), ox)
     rows = [("f16 (default)", err)]
     try:
-        for site in ("dit_block", "encoder", "cross_kv", "cond"):
+        for site in ("dit_block", "encoder", "cross_kv", "cond", "convpos"):
             eng.set_precision(f"bf16x3,{site}=f16")
             rows.append((f"bf16x3 + {site}=f16", rel_l2(run(), ox)))
-        eng.set_precision("f16,cond=f16")
+        eng.set_precision("f16,convpos=f16")
+        rows.append(("f16 + convpos=f16", rel_l2(run(), ox)))
+        eng.set_precision("f16,cond=f16,convpos=f16")
         rows.append(("f16 everywhere incl. cond", rel_l2(run(), ox)))
         eng.set_precision("bf16x3")
         rows.append(("bf16x3", rel_l2(run(), ox)))
