@@ -10,7 +10,7 @@ from smalltts_amd.engine import HipEngine
 
 iters = int(sys.argv[1]) if len(sys.argv) > 1 else 24
 dev = torch.device("cuda", 0)
-eng = HipEngine(0); eng.load_synthetic(bench.SEED, parts=("dit", "decoder")); eng.finalize()
+eng = HipEngine(0); eng.load_synthetic(bench.SEED, parts=("dit", "decoder", "encoder")); eng.finalize()
 inp = bench.make_inputs(dev, 0)
 
 
@@ -72,3 +72,24 @@ for it in range(rounds):
     bad += any(not torch.equal(outs[i], ref_audio[i]) for i in range(3))
 eng.set_tuning(prev)
 print(f"teacher CFG batches, three in flight: {bad} of {rounds} rounds differ from the batches run alone")
+
+# the clone workload (codec encode of the references in every step: K-sliced few-row products, encoder block kernels)
+prev = eng.set_tuning("throughput")
+ref_audio = [bench.one_step(eng, inp, 300 + i, workload="clone").clone() for i in range(3)]
+bad = 0
+for it in range(rounds):
+    outs = [None] * 3
+    cur = torch.cuda.current_stream(dev)
+    for s in streams:
+        s.wait_stream(cur)
+    for i in range(3):
+        with torch.cuda.stream(streams[i]):
+            eng.use_workspace(f"batch{i}")
+            outs[i] = bench.one_step(eng, inp, 300 + i, workload="clone")
+    eng.use_workspace(None)
+    for s in streams:
+        cur.wait_stream(s)
+    torch.cuda.synchronize()
+    bad += any(not torch.equal(outs[i], ref_audio[i]) for i in range(3))
+eng.set_tuning(prev)
+print(f"clone workload, three in flight: {bad} of {rounds} rounds differ from the batches run alone")
