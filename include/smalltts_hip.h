@@ -18,8 +18,18 @@
  * (e.g. torch tensor.data_ptr()); `stream` is a hipStream_t passed as void* (NULL = default stream);
  * all work is enqueued asynchronously on `stream`.  The caller owns inputs, outputs and workspace
  * (query the size first); the library owns weights only.  Return 0 = ok, non-zero = error with the
- * message available from smtts_last_error().  A handle is single-stream and not thread-safe: one
- * handle per GPU (the reference also allows one inference in flight, src/server/src/main.rs:24,138).
+ * message available from smtts_last_error().
+ *
+ * Threading / streams (the same rules as smalltts_amd/csrc/engine.hpp:4-8): a handle is NOT thread-safe — one handle per GPU,
+ * driven by ONE host thread (the reference also has one Session per pipeline behind a mutex, src/server/src/main.rs:24,138).
+ * That thread MAY keep several operator calls in flight on DIFFERENT streams, provided that
+ *   (1) every call in flight has its own workspace and its own output buffers (all per-call scratch lives in the workspace;
+ *       weights are read-only after smtts_finalize);
+ *   (2) smtts_set_tuning(h, 1) ("throughput") was selected first — it also turns the engine-owned side stream of
+ *       smtts_cond_encode off, whose single stream + event pair would otherwise be shared by the calls in flight;
+ *   (3) per-kernel profiling (smtts_profile_enable) is off: it assumes one call at a time.
+ * Calls on one stream are ordered like any other work on that stream; results do not depend on what runs on the other streams
+ * (tests/test_api_gpu.py::test_results_repeat_bit_for_bit_next_to_other_streams).
  * bool tensors are 1 byte per element (numpy/torch bool).
  */
 #ifndef SMALLTTS_HIP_H
@@ -51,14 +61,18 @@ int smtts_set_codec_spec(smtts_handle h, int latent_dim, int n_filters, int kern
                          const int* ratios, int n_ratios, const int* depths /* n_ratios + 1 */);
 int smtts_finalize(smtts_handle h);
 /* GEMM operand precision preset (fp32 accumulation, fp32 residual stream / norms / softmax / sampler state in all of them):
- *   3 = split-bf16 everywhere: x = hi + lo, three bf16 MFMAs per product (fp32-class results; engine default)
- *   2 = "f16 mixed": ONE fp16 MFMA per product on the DiT-block / encoder / cross-KV / codec-FFN GEMMs (>= 95 % of the flops and
+ *   2 = "f16 mixed" — THE DEFAULT of a new handle (smtts_default_precision() == 2; the Python host side sets the same):
+ *       ONE fp16 MFMA per product on the DiT-block / encoder / cross-KV / codec-FFN GEMMs (>= 95 % of the flops and
  *       weight bytes), split-bf16 on the conditioning chain, latent in / out projections and codec resampling convs
- *       (measured: latent rel-L2 ~1.5e-4 vs the fp32 oracle; smalltts_amd default)
+ *       (measured: latent rel-L2 ~1.5e-4 vs the fp32 oracle, inside the 1e-3 contract)
+ *   3 = split-bf16 everywhere: x = hi + lo, three bf16 MFMAs per product (fp32-class results, ~1.4x the time)
  *   1 = single-pass bf16 everywhere (latent rel-L2 ~4e-3: outside the 1e-3 contract, kept for A/B) */
 int smtts_set_precision(smtts_handle h, int preset);
+int smtts_get_precision(smtts_handle h);   /* the preset in force (1 / 2 / 3) */
+int smtts_default_precision(void);         /* host-only: the preset smtts_create starts with */
 /* one GEMM site group at a time: site 0 DiT blocks, 1 encoders, 2 cross-KV, 3 conditioning / in / out projections,
- * 4 codec FFNs, 5 codec stem / resampling convs; prec 1 bf16, 2 fp16, 3 split-bf16 (call after smtts_set_precision) */
+ * 4 codec FFNs, 5 codec stem / resampling convs, 6 conv pos-embed, 7 attention operands (q, k, v, gate, probabilities);
+ * prec 1 bf16, 2 fp16, 3 split-bf16 (call after smtts_set_precision) */
 int smtts_set_site_precision(smtts_handle h, int site, int prec);
 int smtts_has_part(smtts_handle h, int part); /* 0 dit, 1 codec decoder, 2 codec encoder */
 
@@ -72,7 +86,7 @@ int smtts_cond_encode(smtts_handle h, void* stream, const float* ref, const int6
                       float* k_text, float* v_text, void* ws, size_t ws_bytes, float* ref_seq_out, float* mem_out);
 
 /* ---- denoiser --------------------------------------------------------------------------------- */
-size_t smtts_denoise_workspace_bytes(smtts_handle h, int B, int N);
+size_t smtts_denoise_workspace_bytes(smtts_handle h, int B, int N, int R, int P);
 /* x_t f32 (B,N,64); mask bool (B,N); t f32 (B); caches as above; rope f32 (1,N,64) angles or NULL
  * -> velocity f32 (B,N,64) */
 int smtts_denoise_step(smtts_handle h, void* stream, const float* x_t, const uint8_t* mask, const float* t,
@@ -81,7 +95,7 @@ int smtts_denoise_step(smtts_handle h, void* stream, const float* x_t, const uin
                        float* velocity, void* ws, size_t ws_bytes);
 
 /* ---- sampler ---------------------------------------------------------------------------------- */
-size_t smtts_sample_workspace_bytes(smtts_handle h, int B, int N, int n_steps, int cfg);
+size_t smtts_sample_workspace_bytes(smtts_handle h, int B, int N, int R, int P, int n_steps, int cfg);
 /* mode 0: x=0; for t in linspace(1,0,n): x_t = a x + s eps_i; v = denoise; x = a x_t - s v  (DMD student)
  * mode 1: deterministic ODE from x_1 = s(1) eps (teacher), see DESIGN.md
  * cfg != 0: mask/caches/cond masks carry 3B rows [cond; text dropped; speaker dropped]; x has B rows;
@@ -131,7 +145,7 @@ int smtts_set_tuning(smtts_handle h, int mode);
 
 /* per-kernel HIP-event timing on the launch stream (bench.py roofline): enable, run, then read a JSON array
  * [{"name","launches","ms","flops","bytes"}] of algorithmic work and measured time per kernel class */
-int smtts_profile_enable(smtts_handle h, int on);
+int smtts_profile_enable(smtts_handle h, int on);   /* 0 off, 1 per kernel class, 2 + pipeline phase prefix, 3 + GEMM shapes */
 int smtts_profile_report(smtts_handle h, char* buf, size_t cap);
 
 /* ---- single-kernel test hooks (used by tests/ to check kernels in isolation) -------------------- */
@@ -159,8 +173,9 @@ int smtts_test_attention_mfma(smtts_handle h, void* stream, const float* qkvg, c
                               const float* k_text, const float* v_text, int P, const uint8_t* mask_self,
                               const uint8_t* mask_ref, const uint8_t* mask_text, int B, int N, int H, int dh, float* out);
 /* engine-wide switch: 1 (default) = matrix-core attention, 0 = fp32 VALU attention kernel */
-/* mode 0: fp32 VALU attention; 1: matrix cores, q / k head-norm + RoPE fused into the staging; 2: matrix cores after a
- * separate in-place qk_prep launch; 3: matrix cores, prep placement as the engine defaults (separate launch, SMTTS_ATTN_PREP); + 4: never the resident-K/V form of the matrix-core kernel (process-wide A/B switch) */
+/* default (bit 3 clear): the DMA + MFMA kernel on producer-written operand images (attention_img.hip).  + 8: the round-2 kernels,
+ * selected by the low bits — 0: fp32 VALU attention; 1: matrix cores, q / k head-norm + RoPE fused into the staging; 2: matrix cores
+ * after a separate in-place qk_prep launch; 3: matrix cores, prep placement as the engine defaults; + 4: never their resident-K/V form */
 int smtts_test_set_attention_mfma(smtts_handle h, int mode);
 
 #ifdef __cplusplus

@@ -30,13 +30,15 @@ SIGNATURES: Dict[str, Tuple[object, List[object]]] = {
     "smtts_set_codec_spec": (i32, [vp, i32, i32, i32, i32, f32, C.POINTER(i32), i32, C.POINTER(i32)]),
     "smtts_finalize": (i32, [vp]),
     "smtts_set_precision": (i32, [vp, i32]),
+    "smtts_get_precision": (i32, [vp]),
+    "smtts_default_precision": (i32, []),
     "smtts_set_site_precision": (i32, [vp, i32, i32]),
     "smtts_has_part": (i32, [vp, i32]),
     "smtts_cond_workspace_bytes": (sz, [vp, i32, i32, i32]),
     "smtts_cond_encode": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, sz, vp, vp]),
-    "smtts_denoise_workspace_bytes": (sz, [vp, i32, i32]),
+    "smtts_denoise_workspace_bytes": (sz, [vp, i32, i32, i32, i32]),
     "smtts_denoise_step": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, sz]),
-    "smtts_sample_workspace_bytes": (sz, [vp, i32, i32, i32, i32]),
+    "smtts_sample_workspace_bytes": (sz, [vp, i32, i32, i32, i32, i32, i32]),
     "smtts_sample": (i32, [vp, vp, i32, i32, i32, f32, f32, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, u64,
                            vp, vp, vp, sz]),
     "smtts_codec_hop": (i32, [vp]),

@@ -54,6 +54,14 @@ def _validated(tensors: Dict[str, object], source: str, codec: CodecSpec) -> Dic
     unknown = [k for k in tensors if k not in want]
     if unknown and len(unknown) == len(tensors):
         raise ValueError(f"{source}: none of its {len(tensors)} tensors is a parameter of this build (first: {unknown[0]!r})")
+    # A codec.* tensor the engine WOULD apply (biases, layer scales and the final norm are optional at run time) but that the
+    # CodecSpec in force says is absent must not vanish silently: the audio would come out wrong with no error.
+    full = dict(all_param_specs(CodecSpec(**{**codec.to_dict(), "conv_bias": True, "ffn_bias": True, "layer_scale": True, "final_norm": True})))
+    dropped = [k for k in unknown if k in full]
+    if dropped:
+        raise ValueError(f"{source}: tensor {dropped[0]!r} (+{len(dropped) - 1} more) is an optional codec parameter that this "
+                         "CodecSpec switches off (conv_bias / ffn_bias / layer_scale / final_norm) — it would be ignored; "
+                         "load it with the matching spec (convert.py --codec-spec, or a .smtts file that carries its spec)")
     return {k: v for k, v in tensors.items() if k in want}
 
 
@@ -145,7 +153,10 @@ class SmallTTS:
                    else get_engine(weights, int(d), precision, parts=("dit", "decoder", "encoder")))
             if not eng.has("dit"):
                 _load_weights_into(eng, weights or DEFAULT_WEIGHTS, ("dit", "decoder", "encoder"))
-            self._replicas.append(SmallTTS(engine=eng, num_steps=num_steps, seed=seed))
+            # replica seeds are derived from (seed, replica index): with one shared seed every shard would draw the same noise
+            # for its k-th batch (correlated outputs across GPUs)
+            rseed = None if seed is None else int(np.random.SeedSequence([int(seed), len(self._replicas)]).generate_state(1, np.uint64)[0] >> 1)
+            self._replicas.append(SmallTTS(engine=eng, num_steps=num_steps, seed=rseed))
 
     def _next_seed(self) -> int:
         # the reference draws noise from numpy's global RNG (infer/onnx.py:104); seeding numpy (or seed=)

@@ -22,6 +22,10 @@
 #include "kernels.hpp"
 #include "prof.hpp"
 
+#ifndef SMTTS_DBG
+#define SMTTS_DBG 0   // r03 debug variants of the fused-prep kernel (tools/sessions/r03a.sh); 0 = product code
+#endif
+
 // sum over the aligned group of TPR (16 or 32) lanes that holds one row, left in every lane of the group: DPP inside a row of 16
 // lanes (quad permutes, then the two mirrors), one ds_swizzle for the other row — no ds_bpermute round trips
 template <int TPR>
@@ -42,7 +46,7 @@ __device__ __forceinline__ float row_group_sum(float v) {
 struct Rope4 { float4 c, s; };
 __device__ __forceinline__ Rope4 rope4_load(const AttnArgs& a, int pos, int d, bool on) {
     Rope4 r{make_float4(1.f, 1.f, 1.f, 1.f), make_float4(0.f, 0.f, 0.f, 0.f)};
-    if (on && d < a.rot_dim) {   // rot_dim % 4 == 0 (checked by the launcher)
+    if (SMTTS_DBG != 2 && on && d < a.rot_dim) {   // rot_dim % 4 == 0 (checked by the launcher)
         r.c = *reinterpret_cast<const float4*>(a.rope_cos + (long)pos * a.rot_dim + d);
         r.s = *reinterpret_cast<const float4*>(a.rope_sin + (long)pos * a.rot_dim + d);
     }
@@ -52,8 +56,26 @@ __device__ __forceinline__ Rope4 rope4_load(const AttnArgs& a, int pos, int d, b
 // RMSNorm_head(row) * w, then RoPE on the pairs (2i, 2i + 1), for this lane's 4 consecutive dims (v = 0 in pad dims)
 template <int DH, int TPR>
 __device__ __forceinline__ float4 prep_row4(float4 v, float4 w4, const Rope4& r, float eps) {
+#if SMTTS_DBG == 4
+    const float rstd = 1.0f + eps;
+#else
     const float ss = row_group_sum<TPR>(v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w);
-    const float rstd = __builtin_amdgcn_rsqf(ss * (1.0f / (float)DH) + eps);
+#if SMTTS_DBG == 10   // no transcendental instruction at all: bit-trick seed + 4 Newton steps on the FMA pipe
+    const float xx = ss * (1.0f / (float)DH) + eps;
+    float rstd = __builtin_bit_cast(float, 0x5f3759df - (__builtin_bit_cast(int, xx) >> 1));
+#pragma unroll
+    for (int it = 0; it < 4; ++it) rstd = rstd * (1.5f - 0.5f * xx * rstd * rstd);
+#else
+    float rstd = __builtin_amdgcn_rsqf(ss * (1.0f / (float)DH) + eps);
+#endif
+#if SMTTS_DBG == 8
+    asm volatile("s_nop 7\n\ts_nop 7" : "+v"(rstd));
+#elif SMTTS_DBG == 11
+    asm volatile("s_nop 0" : "+v"(rstd));
+#elif SMTTS_DBG == 12
+    asm volatile("s_nop 3" : "+v"(rstd));
+#endif
+#endif
     const float4 y = make_float4(v.x * rstd * w4.x, v.y * rstd * w4.y, v.z * rstd * w4.z, v.w * rstd * w4.w);
     return make_float4(y.x * r.c.x - y.y * r.s.x, y.y * r.c.y + y.x * r.s.y, y.z * r.c.z - y.w * r.s.z, y.w * r.c.w + y.z * r.s.w);
 }
@@ -90,6 +112,10 @@ __global__ __launch_bounds__(RES ? 512 : 256) void attention_mfma_kernel(AttnArg
     const int fr = lane & 31, fh = lane >> 5;
 
     auto swz = [](int row, int c) { return CPR == 16 ? (c ^ (row & 15)) : (c ^ ((row >> 1) & 7)); };
+#if SMTTS_DBG == 1
+    for (int i = tid; i < a.dbg_lds_bytes / 4; i += NT) reinterpret_cast<unsigned*>(smem)[i] = 0x7fc00000u;
+    __syncthreads();
+#endif
 
     // ---- stage Q (pre-scaled), split hi/lo: thread -> (query, 4 dims); every load of the tile is issued before the first use
     auto stage_q = [&](int q0) {
@@ -98,19 +124,47 @@ __global__ __launch_bounds__(RES ? 512 : 256) void attention_mfma_kernel(AttnArg
         float4 qv[NQP];
         Rope4 qr[NQP];
         float4 qw4 = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (PREP && d < DH) qw4 = *reinterpret_cast<const float4*>(a.qw + h * DH + d);
+        if (SMTTS_DBG == 3) qw4 = make_float4(1.f, 1.f, 1.f, 1.f);
+        else if (PREP && d < DH) qw4 = *reinterpret_cast<const float4*>(a.qw + h * DH + d);
 #pragma unroll
         for (int j = 0; j < NQP; ++j) {
             const int r = gtid / TPR + j * (256 / TPR), n = q0 + r;
+#if SMTTS_DBG == 14 || SMTTS_DBG == 15   // every load unconditional (clamped), consumed only after ONE full wait (+ 16 wait states at 14)
+            {
+                const int nc = n < N ? n : N - 1, dc = d < DH ? d : DH - 4;
+                qv[j] = *reinterpret_cast<const float4*>(a.q + (long)b * a.bs + (long)nc * a.rs + h * DH + dc);
+                const int dr = dc < a.rot_dim ? dc : 0;
+                qr[j].c = *reinterpret_cast<const float4*>(a.rope_cos + (long)nc * a.rot_dim + dr);
+                qr[j].s = *reinterpret_cast<const float4*>(a.rope_sin + (long)nc * a.rot_dim + dr);
+            }
+            continue;
+#endif
             qv[j] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (n < N && d < DH) qv[j] = *reinterpret_cast<const float4*>(a.q + (long)b * a.bs + (long)n * a.rs + h * DH + d);
             if (PREP) qr[j] = rope4_load(a, n, d, n < N);
         }
+#if SMTTS_DBG == 14 || SMTTS_DBG == 15
+#if SMTTS_DBG == 14
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_nop 7\n\ts_nop 7" ::: "memory");
+#else
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+#pragma unroll
+        for (int j = 0; j < NQP; ++j) {
+            const int n = q0 + gtid / TPR + j * (256 / TPR);
+            asm volatile("" : "+v"(qv[j].x), "+v"(qv[j].y), "+v"(qv[j].z), "+v"(qv[j].w));
+            asm volatile("" : "+v"(qr[j].c.x), "+v"(qr[j].c.y), "+v"(qr[j].c.z), "+v"(qr[j].c.w));
+            asm volatile("" : "+v"(qr[j].s.x), "+v"(qr[j].s.y), "+v"(qr[j].s.z), "+v"(qr[j].s.w));
+            if (!(n < N && d < DH)) qv[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (!(n < N && d < a.rot_dim)) { qr[j].c = make_float4(1.f, 1.f, 1.f, 1.f); qr[j].s = make_float4(0.f, 0.f, 0.f, 0.f); }
+        }
+#endif
 #pragma unroll
         for (int j = 0; j < NQP; ++j) {
             const int r = gtid / TPR + j * (256 / TPR);
             float4 v = qv[j];
-            if (PREP) v = prep_row4<DH, TPR>(v, qw4, qr[j], a.eps);
+            if (SMTTS_DBG == 7) { __builtin_amdgcn_s_waitcnt(0); __builtin_amdgcn_sched_barrier(0); }
+            if (PREP && SMTTS_DBG != 6) v = prep_row4<DH, TPR>(v, qw4, qr[j], a.eps);
             const float f[4] = {v.x * sm_scale, v.y * sm_scale, v.z * sm_scale, v.w * sm_scale};
             bf16x4 hh, ll;
 #pragma unroll
@@ -135,7 +189,8 @@ __global__ __launch_bounds__(RES ? 512 : 256) void attention_mfma_kernel(AttnArg
             float4 kq[ITEMS], vq[ITEMS];
             Rope4 kr[PREP ? ITEMS : 1];
             float4 kw4 = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (PREP && d < DH) kw4 = *reinterpret_cast<const float4*>(a.kw + h * DH + d);
+            if (SMTTS_DBG == 3) kw4 = make_float4(1.f, 1.f, 1.f, 1.f);
+            else if (PREP && d < DH) kw4 = *reinterpret_cast<const float4*>(a.kw + h * DH + d);
 #pragma unroll
             for (int it = 0; it < ITEMS; ++it) {
                 if (PREP) kr[it] = rope4_load(a, c0 + r0 + it, d, c0 + r0 + it < N);
@@ -162,7 +217,8 @@ __global__ __launch_bounds__(RES ? 512 : 256) void attention_mfma_kernel(AttnArg
             for (int it = 0; it < ITEMS; ++it) {
                 const int r = r0 + it;
                 const bool real = (c0 + r < Ktot) && d < DH;
-                if (PREP && c0 < N) {   // self keys arrive raw; the cross-KV cache was normalised when it was built.  (c0 is uniform:
+                if (SMTTS_DBG == 7) { __builtin_amdgcn_s_waitcnt(0); __builtin_amdgcn_sched_barrier(0); }
+                if (PREP && SMTTS_DBG != 5 && c0 < N) {   // self keys arrive raw; the cross-KV cache was normalised when it was built.  (c0 is uniform:
                     const bool self = c0 + r < N;   // chunks with no self key skip the pass; lanes never diverge around the DPP sum)
                     float4 raw = kq[it];
                     if (d >= DH) raw = make_float4(0.f, 0.f, 0.f, 0.f);   // (clamped column: not part of the row)
@@ -390,7 +446,15 @@ static hipError_t attn_mfma_go(const AttnArgs& a, hipStream_t st) {
     });
     if (e != hipSuccess) return e;
     dim3 grid(RES ? 1 : (a.N + 31) / 32, a.H, a.B);
-    hipLaunchKernelGGL(kern, grid, dim3(RES ? 512 : 256), lds, st, a);
+    static const size_t dbg_lds = getenv("SMTTS_DBG_ATTN_LDS") ? (size_t)atol(getenv("SMTTS_DBG_ATTN_LDS")) : 0;
+    if (dbg_lds > lds) {   // debug: claim the whole CU's LDS so that no other LDS-using workgroup can share the CU
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dbg_lds);
+        AttnArgs b = a; b.dbg_lds_bytes = (int)lds;
+        hipLaunchKernelGGL(kern, grid, dim3(RES ? 512 : 256), dbg_lds, st, b);
+        return hipGetLastError();
+    }
+    AttnArgs b = a; b.dbg_lds_bytes = (int)lds;
+    hipLaunchKernelGGL(kern, grid, dim3(RES ? 512 : 256), lds, st, b);
     return hipGetLastError();
 }
 

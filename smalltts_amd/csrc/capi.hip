@@ -71,6 +71,8 @@ int smtts_set_precision(smtts_handle h, int preset) { NULLCHK;
     E.set_precision(preset);
     return 0;
 }
+int smtts_get_precision(smtts_handle h) { NULLCHK; return E.precision(); }
+int smtts_default_precision(void) { return kDefaultPrecision; }
 int smtts_set_site_precision(smtts_handle h, int site, int prec) { NULLCHK; return E.set_site_precision(site, prec); }
 int smtts_has_part(smtts_handle h, int part) { NULLCHK0;
     return part == 0 ? E.has_dit() : part == 1 ? E.has_decoder() : part == 2 ? E.has_encoder() : 0;
@@ -84,7 +86,7 @@ int smtts_cond_encode(smtts_handle h, void* stream, const float* ref, const int6
                          ws_bytes, ref_seq_out, mem_out);
 }
 
-size_t smtts_denoise_workspace_bytes(smtts_handle h, int B, int N) { NULLCHK0; return E.denoise_ws_bytes(B, N, B); }
+size_t smtts_denoise_workspace_bytes(smtts_handle h, int B, int N, int R, int P) { NULLCHK0; return E.denoise_ws_bytes(B, N, R, P, B); }
 int smtts_denoise_step(smtts_handle h, void* stream, const float* x_t, const uint8_t* mask, const float* t,
                        const float* k_ref, const float* v_ref, const uint8_t* ref_mask, const float* k_text,
                        const float* v_text, const uint8_t* ph_mask, const float* rope, int B, int N, int R, int P,
@@ -93,8 +95,8 @@ int smtts_denoise_step(smtts_handle h, void* stream, const float* x_t, const uin
                           velocity, ws, ws_bytes);
 }
 
-size_t smtts_sample_workspace_bytes(smtts_handle h, int B, int N, int n_steps, int cfg) { NULLCHK0;
-    return E.sample_ws_bytes(B, N, n_steps, cfg);
+size_t smtts_sample_workspace_bytes(smtts_handle h, int B, int N, int R, int P, int n_steps, int cfg) { NULLCHK0;
+    return E.sample_ws_bytes(B, N, R, P, n_steps, cfg);
 }
 int smtts_sample(smtts_handle h, void* stream, int mode, int n_steps, int cfg, float s_text, float s_spk,
                  const uint8_t* mask, const float* k_ref, const float* v_ref, const uint8_t* ref_mask,
@@ -160,6 +162,7 @@ int smtts_test_set_attention_mfma(smtts_handle h, int mode) { NULLCHK;   // 0: f
     if ((mode & 3) == 3) E.reset_attn_prep_fused();   // 3: matrix cores, prep placement back to the engine default
     else E.set_attn_prep_fused((mode & 3) != 2);
     g_attn_resident = (mode & 4) ? 0 : 1;   // + 4: streaming form only (process-wide switch; the resident-K/V form is the default where it applies)
+    E.set_attn_img((mode & 8) == 0);        // + 8: the round-2 kernels selected by the low bits; without it (default) the DMA + MFMA kernel on producer-written images
     return 0;
 }
 
@@ -202,6 +205,48 @@ int smtts_test_attention_mfma(smtts_handle h, void* stream, const float* qkvg, c
                               const float* rope, int rot_dim, const float* k_ref, const float* v_ref, int R,
                               const float* k_text, const float* v_text, int P, const uint8_t* mask_self,
                               const uint8_t* mask_ref, const uint8_t* mask_text, int B, int N, int H, int dh, float* out) { NULLCHK;
+    if (E.attn_img()) {
+        // round-3 path: stand-alone producer (qkv_pack + cross_pack, L = 1) then the DMA + MFMA kernel, at the SITE_ATTN precision
+        const int D = H * dh, dhp = dh <= 64 ? 64 : 128, Np = pad8(N), Rp = pad8(R > 0 ? R : 0), Cp = Rp + pad8(P > 0 ? P : 0);
+        const int pa = E.site_precision(Engine::SITE_ATTN);
+        const size_t nqk = (size_t)B * H * N * dhp, nvt = (size_t)B * H * dhp * Np, ng = (size_t)B * N * D, nc = (size_t)B * H * Cp * dhp;
+        const int nr = N * rot_dim;
+        bf16_t* img = nullptr; float *rc = nullptr, *rs = nullptr; bf16_t* ob = nullptr;
+        const size_t tot = 2 * (2 * nqk + nvt + ng + 2 * nc) + 64;
+        if (hipMalloc(&img, tot * 2) != hipSuccess || hipMalloc(&rc, (size_t)(nr + 4) * 4) != hipSuccess ||
+            hipMalloc(&rs, (size_t)(nr + 4) * 4) != hipSuccess || hipMalloc(&ob, (size_t)B * N * D * 2 * 2 + 64) != hipSuccess)
+            return E.fail("test_attention_mfma: alloc failed");
+        (void)hipMemsetAsync(img, 0, tot * 2, ST(stream));
+        (void)launch_rope_cossin(rope, rc, rs, nr, ST(stream));
+        bf16_t* p = img;
+        auto take = [&](size_t n) { bf16_t* r = p; p += (n + 7) & ~size_t(7); return r; };
+        QkvPackArgs pk{};
+        pk.qkvg = qkvg; pk.qw = qw; pk.kw = kw; pk.eps = eps; pk.q_scale = 1.0f / sqrtf((float)dh);
+        pk.rope_cos = rc; pk.rope_sin = rs; pk.rot_dim = rot_dim; pk.prec = pa;
+        pk.q = take(nqk); pk.q_lo = take(nqk); pk.k = take(nqk); pk.k_lo = take(nqk); pk.vt = take(nvt); pk.vt_lo = take(nvt);
+        pk.g = take(ng); pk.g_lo = take(ng);
+        pk.B = B; pk.N = N; pk.H = H; pk.dh = dh; pk.dhp = dhp; pk.Np = Np;
+        hipError_t e = launch_qkv_pack(pk, ST(stream));
+        AttnImg ai{};
+        ai.prec = pa;
+        ai.q = pk.q; ai.q_lo = pk.q_lo; ai.k = pk.k; ai.k_lo = pk.k_lo; ai.vt = pk.vt; ai.vt_lo = pk.vt_lo; ai.g = pk.g; ai.g_lo = sm_lo_for(pa, pk.g_lo);
+        if (Cp > 0 && e == hipSuccess) {
+            CrossPackArgs cp{};
+            cp.k_ref = k_ref; cp.v_ref = v_ref; cp.k_text = k_text; cp.v_text = v_text;
+            cp.kc = take(nc); cp.kc_lo = take(nc); cp.vtc = take(nc); cp.vtc_lo = take(nc);
+            cp.prec = pa; cp.L = 1; cp.B = B; cp.H = H; cp.dh = dh; cp.dhp = dhp; cp.R = R > 0 ? R : 0; cp.P = P > 0 ? P : 0; cp.Rp = Rp; cp.Cp = Cp;
+            e = launch_cross_pack(cp, ST(stream));
+            ai.kc = cp.kc; ai.kc_lo = cp.kc_lo; ai.vtc = cp.vtc; ai.vtc_lo = cp.vtc_lo;
+        }
+        ai.mask_self = mask_self; ai.mask_ref = mask_ref; ai.mask_text = mask_text;
+        ai.out_hi = ob; ai.out_lo = ob + (((size_t)B * N * D + 7) & ~size_t(7)); ai.ors = D;   // split pair: hi + lo ~ fp32
+        ai.B = B; ai.N = N; ai.H = H; ai.dh = dh; ai.Np = Np; ai.R = R > 0 ? R : 0; ai.P = P > 0 ? P : 0; ai.Rp = Rp; ai.Cp = Cp;
+        if (e == hipSuccess) e = launch_attention_img(ai, ST(stream));
+        if (e == hipSuccess) e = launch_split_to_f32(ai.out_hi, ai.out_lo, out, (long)B * N * D, ST(stream));
+        (void)hipStreamSynchronize(ST(stream));
+        (void)hipFree(img); (void)hipFree(rc); (void)hipFree(rs); (void)hipFree(ob);
+        return e == hipSuccess ? 0 : E.fail_hip(e, "attention_img");
+    }
     AttnArgs a{};
     const int D = H * dh;
     float *tmp = nullptr, *rc = nullptr, *rs = nullptr;

@@ -217,6 +217,53 @@ __device__ __forceinline__ floatx16 mfma16(const bf16x8& a, const bf16x8& b, con
         return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
 }
 
+// ---- attention operand images (attention_img.hip): element stores in format `prec` and the q / k head prep -------------------
+__device__ __forceinline__ void store_img2(bf16_t* hi, bf16_t* lo, int prec, long off, float a, float b) {   // off even
+    if (prec == PREC_F16) {
+        *reinterpret_cast<unsigned*>(hi + off) = cvt_pk_f16_sat(a, b);
+        return;
+    }
+    bf16_t ah, al, bh, bl;
+    split1(a, ah, al);
+    split1(b, bh, bl);
+    *reinterpret_cast<unsigned*>(hi + off) =
+        (unsigned)__builtin_bit_cast(unsigned short, ah) | ((unsigned)__builtin_bit_cast(unsigned short, bh) << 16);
+    if (prec == PREC_BF16X3)
+        *reinterpret_cast<unsigned*>(lo + off) =
+            (unsigned)__builtin_bit_cast(unsigned short, al) | ((unsigned)__builtin_bit_cast(unsigned short, bl) << 16);
+}
+__device__ __forceinline__ void store_img1(bf16_t* hi, bf16_t* lo, int prec, long off, float v) {
+    if (prec == PREC_F16) {
+        reinterpret_cast<unsigned short*>(hi)[off] = cvt_f16_sat(v);
+    } else {
+        bf16_t hh, ll;
+        split1(v, hh, ll);
+        hi[off] = hh;
+        if (prec == PREC_BF16X3) lo[off] = ll;
+    }
+}
+// the per-pair arithmetic shared by the epilogue and qkv_pack_kernel: (x0, x1) = dims (d, d + 1) of one head row, ss = the row's
+// sum of squares.  Explicit fmaf: both call sites must round identically.
+struct QkPrep {
+    const float* w;        // [H][dh] norm weight of this part
+    const float *rope_cos, *rope_sin;
+    int rot_dim, dh;
+    float eps, scale;      // scale: 1/sqrt(dh) for q, 1 for k
+    __device__ __forceinline__ void apply(float& x0, float& x1, float ss, int h, int d, int n) const {
+        const float rstd = __builtin_amdgcn_rsqf(fmaf(ss, 1.0f / (float)dh, eps));
+        const bool in = d < dh;
+        const float w0 = in ? w[h * dh + d] : 0.f, w1 = in ? w[h * dh + d + 1] : 0.f;
+        x0 = (x0 * rstd) * w0;
+        x1 = (x1 * rstd) * w1;
+        if (d < rot_dim) {
+            const float c = rope_cos[(long)n * rot_dim + d], s = rope_sin[(long)n * rot_dim + d];
+            const float a0 = fmaf(x0, c, -(x1 * s)), a1 = fmaf(x1, c, x0 * s);
+            x0 = a0; x1 = a1;
+        }
+        x0 *= scale; x1 *= scale;
+    }
+};
+
 // LDS pointer for direct-to-LDS DMA operands and a counted wait on this wave's outstanding vector-memory operations
 #define SM_LPTR(p) ((__attribute__((address_space(3))) void*)(p))
 template <int N>

@@ -34,9 +34,11 @@ int g_gemm3_stage16 = 1;  // gemm3: 16-bit outputs through the LDS-staged epilog
 int g_gemm3_nfast = 1;  // gemm3 tile order: N fastest when M > N (SMTTS_GEMM_NFAST=0 restores M fastest everywhere)
 thread_local Profiler* g_prof = nullptr;
 thread_local const char* g_prof_tag = nullptr;
+thread_local int g_prof_shapes = 0;
 
 static int g_small_m_splitk = 1;   // SMTTS_SMALLM_SPLITK=0: A/B switch for the K-sliced small-M products of the codec
 Engine::Engine(int device) : device_(device) {
+    set_precision(kDefaultPrecision);
     if (const char* nf = getenv("SMTTS_GEMM_NFAST")) g_gemm3_nfast = atoi(nf);
     if (const char* dp = getenv("SMTTS_GEMM_DEEP")) g_gemm3_deep = atoi(dp);
     if (const char* s16 = getenv("SMTTS_GEMM_STAGE16")) g_gemm3_stage16 = atoi(s16);
@@ -48,6 +50,8 @@ Engine::Engine(int device) : device_(device) {
     if ((s = getenv("SMTTS_SMALLM_SPLITK"))) g_small_m_splitk = atoi(s);
     if ((s = getenv("SMTTS_ATTN_RES"))) g_attn_resident = atoi(s);
     if ((s = getenv("SMTTS_CONVPOS_BY_GROUP"))) convpos_by_group_ = atoi(s) != 0;
+    if ((s = getenv("SMTTS_ATTN_EPI"))) attn_epi_ = atoi(s) != 0;
+    if ((s = getenv("SMTTS_ATTN_IMG"))) attn_img_ = atoi(s) != 0;
     if ((s = getenv("SMTTS_ATTN_PREP"))) attn_prep_fused_ = atoi(s);   // 0: separate qk_prep launch, 1: fused up to one workgroup per CU, 2: always fused
     if ((s = getenv("SMTTS_UP_G3_MINK")) && atoi(s) >= 64) up_g3_mink_ = atoi(s);
     if ((s = getenv("SMTTS_KSPLIT_OUT")) && atoi(s) >= 1 && atoi(s) <= kSplitK) ksplit_out_ = atoi(s);
@@ -76,7 +80,8 @@ void Engine::profile_enable(int mode) {
     prof_on_ = on;
     prof_.reset();
     g_prof = on ? &prof_ : nullptr;
-    g_prof_tag = mode == 2 ? "" : nullptr;  // 2 = tagged: kernel names carry the pipeline phase
+    g_prof_tag = mode >= 2 ? "" : nullptr;  // 2 = tagged: kernel names carry the pipeline phase
+    g_prof_shapes = mode == 3;               // 3 = tagged + the GEMM classes carry their product's shape
 }
 
 std::string Engine::profile_report() {
@@ -237,12 +242,13 @@ PW Engine::pack_rows(const std::vector<std::string>& names, const std::vector<in
         if (hipMalloc(&dperm, perm->size() * sizeof(int)) != hipSuccess) { (void)hipFree(tmp); return w; }
         (void)hipMemcpyAsync(dperm, perm->data(), perm->size() * sizeof(int), hipMemcpyHostToDevice, 0);
     }
-    w.N = Ntot;
+    const int Nout = perm ? (int)perm->size() : Ntot;   // a permutation may also insert zero rows (entries -1): head padding
+    w.N = Nout;
     w.K = K;
-    w.hi = static_cast<bf16_t*>(dalloc((size_t)Ntot * K * 2));
-    w.lo = static_cast<bf16_t*>(dalloc((size_t)Ntot * K * 2));
-    w.h16 = static_cast<bf16_t*>(dalloc((size_t)Ntot * K * 2));
-    if (!w.hi || !w.lo || !w.h16 || launch_split_rows(tmp, K, w.hi, w.lo, K, Ntot, K, dperm, 0, w.h16) != hipSuccess) w.N = 0;
+    w.hi = static_cast<bf16_t*>(dalloc((size_t)Nout * K * 2));
+    w.lo = static_cast<bf16_t*>(dalloc((size_t)Nout * K * 2));
+    w.h16 = static_cast<bf16_t*>(dalloc((size_t)Nout * K * 2));
+    if (!w.hi || !w.lo || !w.h16 || launch_split_rows(tmp, K, w.hi, w.lo, K, Nout, K, dperm, 0, w.h16) != hipSuccess) w.N = 0;
     (void)hipStreamSynchronize(0);
     (void)hipFree(tmp);
     if (dperm) (void)hipFree(dperm);
@@ -419,6 +425,10 @@ int Engine::finalize_dit() {
     }
 
     std::vector<int> perm = swiglu_perm(kFF);
+    std::vector<int> hperm(4 * kHeads * 128, -1);   // row (part * 8 + h) * 128 + d <- source row part * 960 + h * 120 + d, pad rows zero
+    for (int part = 0; part < 4; ++part)
+        for (int h = 0; h < kHeads; ++h)
+            for (int d = 0; d < kDh; ++d) hperm[(part * kHeads + h) * 128 + d] = part * kHidden + h * kDh + d;
     blocks_.clear();
     for (int i = 0; i < kBlocks; ++i) {
         std::string p = sidx(T, i, "");
@@ -427,12 +437,21 @@ int Engine::finalize_dit() {
                             p + ".attn.gate.weight"});
         b.b_qkvg = concat_vec({p + ".attn.to_q.bias", p + ".attn.to_k_self.bias", p + ".attn.to_v_self.bias", ""},
                               {kHidden});
+        b.qkvgp = pack_rows({p + ".attn.to_q.weight", p + ".attn.to_k_self.weight", p + ".attn.to_v_self.weight",
+                             p + ".attn.gate.weight"}, &hperm);
+        b.b_qkvgp = static_cast<float*>(dalloc(hperm.size() * 4));
+        if (b.b_qkvgp && b.b_qkvg) {   // the padded bias: gather on the host side of a tiny vector
+            std::vector<float> src(4 * kHidden), dst(hperm.size(), 0.f);
+            (void)hipMemcpy(src.data(), b.b_qkvg, src.size() * 4, hipMemcpyDeviceToHost);
+            for (size_t r = 0; r < hperm.size(); ++r) if (hperm[r] >= 0) dst[r] = src[hperm[r]];
+            (void)hipMemcpy(b.b_qkvgp, dst.data(), dst.size() * 4, hipMemcpyHostToDevice);
+        }
         b.out = pack_rows({p + ".attn.to_out.0.weight"});
         b.ff13 = pack_rows({p + ".ff.w1.weight", p + ".ff.w3.weight"}, &perm);
         b.ff2 = pack_rows({p + ".ff.w2.weight"}, nullptr, kFFp);
         b.b1 = rawp(p + ".ff.w1.bias"); b.b3 = rawp(p + ".ff.w3.bias"); b.b2 = rawp(p + ".ff.w2.bias");
         b.qn = rawp(p + ".attn.q_norm.weight"); b.kn = rawp(p + ".attn.k_norm.weight");
-        if (!b.qkvg.N || !b.b_qkvg || !b.out.N || !b.ff13.N || !b.ff2.N || !b.b1 || !b.b3 || !b.b2 || !b.qn || !b.kn)
+        if (!b.qkvg.N || !b.qkvgp.N || !b.b_qkvg || !b.b_qkvgp || !b.out.N || !b.ff13.N || !b.ff2.N || !b.b1 || !b.b3 || !b.b2 || !b.qn || !b.kn)
             return fail("DiT block incomplete: " + p + " (" + err_ + ")");
         blocks_.push_back(b);
     }
@@ -730,6 +749,8 @@ namespace {
 struct EncWs {
     float *x, *qkvg, *seq, *part;
     SplitBuf y, o, ffh, seqs;
+    SplitBuf qi, ki, vti, gi;   // attention operand images (attention_img.hip): [B][H][S][dhp] x 2, [B][H][dhp][pad8(S)], [M][D]
+    size_t vt_elems;
     void plan(Bump& b, int Mx) {
         x = b.take<float>((size_t)Mx * 512);
         part = b.take<float>((size_t)kSplitK * Mx * 512);
@@ -739,6 +760,12 @@ struct EncWs {
         o = take_split(b, (size_t)Mx * 512);
         ffh = take_split(b, (size_t)Mx * 1536);
         seqs = take_split(b, (size_t)Mx * kHidden);
+        // H * dhp = 512 for both encoders (8 x 64, 4 x 128); V^T rows are padded to 8 keys per utterance: at most Mx + 7 * B <= 8 Mx
+        qi = take_split(b, (size_t)Mx * 512);
+        ki = take_split(b, (size_t)Mx * 512);
+        vt_elems = (size_t)Mx * 8 * 512;
+        vti = take_split(b, vt_elems);
+        gi = take_split(b, (size_t)Mx * 512);
     }
 };
 }  // namespace
@@ -755,7 +782,8 @@ int Engine::run_encoder(hipStream_t st, const EncoderW& e, void* wsv, int B, int
     HIPC(launch_rmsnorm(w.x, rd, nullptr, y.hi, y.lo, rd, M, D, e.eps, e.blocks[0].an, st));
     for (size_t l = 0; l < e.blocks.size(); ++l) {
         const EncBlockW& b = e.blocks[l];
-        HIPC(gemm3_store(ops3(w.y, rd, b.qkvg, M, pe), ACT_NONE, store_to(w.qkvg, rowmap_plain(4 * D), nullptr), 1, pe, st));
+        const bool epi = attn_img_ && attn_epi_;   // the GEMM's own epilogue writes the attention operands
+        if (!epi) HIPC(gemm3_store(ops3(w.y, rd, b.qkvg, M, pe), ACT_NONE, store_to(w.qkvg, rowmap_plain(4 * D), nullptr), 1, pe, st));
         AttnArgs a{};
         a.q = w.qkvg; a.k = w.qkvg + D; a.v = w.qkvg + 2 * D; a.gate = w.qkvg + 3 * D;
         a.bs = (long)S * 4 * D; a.rs = 4 * D;
@@ -764,9 +792,43 @@ int Engine::run_encoder(hipStream_t st, const EncoderW& e, void* wsv, int B, int
         a.mask_self = key_mask;
         a.out = nullptr; a.out_hi = o.hi; a.out_lo = o.lo; a.obs = (long)S * D; a.ors = D;
         a.B = B; a.N = S; a.H = e.heads; a.dh = e.dh;
+        if (attn_img_) {
+            // q / k head-norm + RoPE + operand formatting by the producer, then a DMA + MFMA attention kernel (attention_img.hip)
+            const int pa = prec_[SITE_ATTN], Sp = pad8(S);
+            QkvPackArgs pk{};
+            pk.qkvg = w.qkvg; pk.qw = b.qn; pk.kw = b.kn; pk.eps = e.eps; pk.q_scale = 1.0f / sqrtf((float)e.dh);
+            pk.rope_cos = e.rope_cos; pk.rope_sin = e.rope_sin; pk.rot_dim = e.dh; pk.prec = pa;
+            pk.q = w.qi.hi; pk.q_lo = w.qi.lo; pk.k = w.ki.hi; pk.k_lo = w.ki.lo; pk.vt = w.vti.hi; pk.vt_lo = w.vti.lo;
+            pk.g = w.gi.hi; pk.g_lo = w.gi.lo;
+            pk.B = B; pk.N = S; pk.H = e.heads; pk.dh = e.dh; pk.dhp = e.dh <= 64 ? 64 : 128; pk.Np = Sp;
+            if (l == 0 && Sp != S) {   // pad key columns of V^T: zero once per call (the producer only writes n < S)
+                HIPC(hipMemsetAsync(w.vti.hi, 0, (size_t)B * e.heads * pk.dhp * Sp * 2, st));
+                if (pa == PREC_BF16X3) HIPC(hipMemsetAsync(w.vti.lo, 0, (size_t)B * e.heads * pk.dhp * Sp * 2, st));
+            }
+            if (epi) {
+                EpiQKV eq{nullptr, pk.qw, pk.kw, pk.rope_cos, pk.rope_sin, pk.eps, pk.q_scale, pk.rot_dim, pa,
+                          pk.q, pk.q_lo, pk.k, pk.k_lo, pk.vt, pk.vt_lo, pk.g, pk.g_lo, S, e.heads, e.dh, pk.dhp, Sp};
+                HIPC(gemm3_qkv(ops3(w.y, rd, b.qkvg, M, pe), eq, pe, st));   // (both encoders' heads are 64 / 128 wide: no padding)
+            } else {
+                HIPC(launch_qkv_pack(pk, st));
+            }
+            AttnImg ai{};
+            ai.prec = pa;
+            ai.q = pk.q; ai.q_lo = pk.q_lo; ai.k = pk.k; ai.k_lo = pk.k_lo; ai.vt = pk.vt; ai.vt_lo = pk.vt_lo;
+            ai.g = pk.g; ai.g_lo = sm_lo_for(pa, pk.g_lo);
+            ai.mask_self = key_mask;
+            ai.out_hi = o.hi; ai.out_lo = o.lo; ai.ors = D;
+            ai.B = B; ai.N = S; ai.H = e.heads; ai.dh = e.dh; ai.Np = Sp;
+            HIPC(launch_attention_img(ai, st));
+        } else {
         a.prenormed = !attn_fuse_prep(a);   // fused: the matrix-core kernel normalises + rotates q / k while staging
         if (a.prenormed) HIPC(launch_qk_prep(a, st));
+        static char* dbg_dump = getenv("SMTTS_DBG_ATTN_PTR") ? reinterpret_cast<char*>(strtoull(getenv("SMTTS_DBG_ATTN_PTR"), nullptr, 0)) : nullptr;
+        char* dd = dbg_dump && &e == &style_ ? dbg_dump + l * ((size_t)M * 4 * D * 4 + (size_t)M * D * 2) : nullptr;
+        if (dd) HIPC(hipMemcpyAsync(dd, w.qkvg, (size_t)M * 4 * D * 4, hipMemcpyDeviceToDevice, st));   // r03 debug: attention inputs as the kernel sees them
         HIPC(attn_mfma_ ? launch_attention_mfma(a, st) : launch_attention(a, st));
+        if (dd) HIPC(hipMemcpyAsync(dd + (size_t)M * 4 * D * 4, o.hi, (size_t)M * D * 2, hipMemcpyDeviceToDevice, st));   // ... and its output
+        }
         EpiResid<0> r1{w.x, rd, nullptr, nullptr, 0, 0, 0, 1, nullptr};
         NextLN n1{b.mn, nullptr, y.hi, y.lo, true, e.eps};
         if (ksplit_enc_ > 1) {
@@ -909,9 +971,15 @@ struct CoreWs {
     float *h, *x, *qkvg, *part;
     float *rope_c, *rope_s;  // cos / sin of a caller-supplied angle table: per call (several calls may be in flight on different streams)
     SplitBuf gm1, gm2, y, o, ffh;
-    size_t gm_elems;
+    SplitBuf qi, ki, vti, gi;   // attention operand images of the self part: [B][8][N][128] x 2, [B][8][128][pad8(N)], [M][960]
+    size_t gm_elems, vt_elems;
     void plan(Bump& b, int B, int N) {
         const size_t M = (size_t)B * N;
+        qi = take_split(b, M * kHeads * 128);
+        ki = take_split(b, M * kHeads * 128);
+        vt_elems = (size_t)B * kHeads * 128 * pad8(N);
+        vti = take_split(b, vt_elems);
+        gi = take_split(b, M * kHidden);
         gm_elems = (size_t)B * kConvG * (N + 2 * kConvPad) * kConvGs;
         h = b.take<float>(M * kHidden);
         x = b.take<float>(M * kHidden);
@@ -951,7 +1019,7 @@ size_t Engine::denoise_core_bytes(int B, int N) const {
 int Engine::denoise_core(hipStream_t st, const float* x_t, const uint8_t* mask, const float* mod, int mod_row0,
                          int mod_rstride, const float* k_ref, const float* v_ref, const uint8_t* ref_mask,
                          const float* k_text, const float* v_text, const uint8_t* ph_mask, const float* rope, int B,
-                         int N, int R, int P, float* velocity, char* wsp) {
+                         int N, int R, int P, float* velocity, char* wsp, const CrossImg& ci) {
     ProfTag ptag("dit");
     Bump bump(wsp);
     CoreWs w;
@@ -1014,8 +1082,10 @@ int Engine::denoise_core(hipStream_t st, const float* x_t, const uint8_t* mask, 
         const DitBlockW& b = blocks_[l];
         const float* m = mod + (long)l * kModPerBlock;
         // D5 AdaLN-Zero (dit.py:19-25) already in w.y; D6 joint attention (dit.py:95-135)
-        HIPC(gemm3_store(ops3(w.y, rh, b.qkvg, M, pb), ACT_NONE, store_to(w.qkvg, rowmap_plain(4 * kHidden), b.b_qkvg), 1,
-                         pb, st));
+        const bool epi = attn_img_ && attn_epi_;   // the GEMM's own epilogue writes the attention operands
+        if (!epi)
+            HIPC(gemm3_store(ops3(w.y, rh, b.qkvg, M, pb), ACT_NONE, store_to(w.qkvg, rowmap_plain(4 * kHidden), b.b_qkvg), 1,
+                             pb, st));
         AttnArgs a{};
         a.q = w.qkvg; a.k = w.qkvg + kHidden; a.v = w.qkvg + 2 * kHidden; a.gate = w.qkvg + 3 * kHidden;
         a.bs = (long)N * 4 * kHidden; a.rs = 4 * kHidden;
@@ -1027,9 +1097,43 @@ int Engine::denoise_core(hipStream_t st, const float* x_t, const uint8_t* mask, 
         a.mask_self = mask; a.mask_ref = ref_mask; a.mask_text = ph_mask;
         a.out = nullptr; a.out_hi = ob.hi; a.out_lo = ob.lo; a.obs = (long)N * kHidden; a.ors = kHidden;
         a.B = B; a.N = N; a.H = kHeads; a.dh = kDh;
-        a.prenormed = !attn_fuse_prep(a);   // fused: the matrix-core kernel normalises + rotates q / k while staging
-        if (a.prenormed) HIPC(launch_qk_prep(a, st));
-        HIPC(attn_mfma_ ? launch_attention_mfma(a, st) : launch_attention(a, st));
+        if (attn_img_) {
+            const int pa = prec_[SITE_ATTN], Np = pad8(N);
+            QkvPackArgs pk{};
+            pk.qkvg = w.qkvg; pk.qw = b.qn; pk.kw = b.kn; pk.eps = 1e-6f; pk.q_scale = 1.0f / sqrtf((float)kDh);
+            pk.rope_cos = rc; pk.rope_sin = rs; pk.rot_dim = 64; pk.prec = pa;
+            pk.q = w.qi.hi; pk.q_lo = w.qi.lo; pk.k = w.ki.hi; pk.k_lo = w.ki.lo; pk.vt = w.vti.hi; pk.vt_lo = w.vti.lo;
+            pk.g = w.gi.hi; pk.g_lo = w.gi.lo;
+            pk.B = B; pk.N = N; pk.H = kHeads; pk.dh = kDh; pk.dhp = 128; pk.Np = Np;
+            if (l == 0 && Np != N) {   // pad key columns of V^T: zero once per call (the producer only writes n < N)
+                HIPC(hipMemsetAsync(w.vti.hi, 0, w.vt_elems * 2, st));
+                if (pa == PREC_BF16X3) HIPC(hipMemsetAsync(w.vti.lo, 0, w.vt_elems * 2, st));
+            }
+            if (epi) {
+                EpiQKV eq{b.b_qkvgp, pk.qw, pk.kw, pk.rope_cos, pk.rope_sin, pk.eps, pk.q_scale, pk.rot_dim, pa,
+                          pk.q, pk.q_lo, pk.k, pk.k_lo, pk.vt, pk.vt_lo, pk.g, pk.g_lo, N, kHeads, kDh, 128, Np};
+                HIPC(gemm3_qkv(ops3(w.y, rh, b.qkvgp, M, pb), eq, pb, st));
+            } else {
+                HIPC(launch_qkv_pack(pk, st));
+            }
+            AttnImg ai{};
+            ai.prec = pa;
+            ai.q = pk.q; ai.q_lo = pk.q_lo; ai.k = pk.k; ai.k_lo = pk.k_lo; ai.vt = pk.vt; ai.vt_lo = pk.vt_lo;
+            ai.g = pk.g; ai.g_lo = sm_lo_for(pa, pk.g_lo);
+            if (ci.Cp > 0) {
+                const long lc = (long)l * B * kHeads * ci.Cp * 128;
+                ai.kc = ci.kc + lc; ai.vtc = ci.vtc + lc;
+                if (pa == PREC_BF16X3) { ai.kc_lo = ci.kc_lo + lc; ai.vtc_lo = ci.vtc_lo + lc; }
+            }
+            ai.mask_self = mask; ai.mask_ref = ref_mask; ai.mask_text = ph_mask;
+            ai.out_hi = ob.hi; ai.out_lo = ob.lo; ai.ors = kHidden;
+            ai.B = B; ai.N = N; ai.H = kHeads; ai.dh = kDh; ai.Np = Np; ai.R = R; ai.P = P; ai.Rp = ci.Rp; ai.Cp = ci.Cp;
+            HIPC(launch_attention_img(ai, st));
+        } else {
+            a.prenormed = !attn_fuse_prep(a);   // fused: the matrix-core kernel normalises + rotates q / k while staging
+            if (a.prenormed) HIPC(launch_qk_prep(a, st));
+            HIPC(attn_mfma_ ? launch_attention_mfma(a, st) : launch_attention(a, st));
+        }
         // to_out + mask + gated residual (dit.py:117-118,198), then the MLP AdaLN (dit.py:199)
         EpiResid<0> r1{w.x, rh, nullptr, m + 2 * kHidden, kModLd, mod_row0, mod_rstride, N, mask};
         NextLN ln1{m + 3 * kHidden, m + 4 * kHidden, yb.hi, yb.lo};
@@ -1064,11 +1168,38 @@ int Engine::denoise_core(hipStream_t st, const float* x_t, const uint8_t* mask, 
     return 0;
 }
 
-size_t Engine::denoise_ws_bytes(int B, int N, int rows) const {
+// Cross-KV cache of all 12 layers in the attention kernel's operand format: built once per sampler call (or per denoise_step
+// call) from the fp32 rank-5 tensors the C ABI hands over — 25 MB of traffic against 4 x 12 attention launches that then DMA it.
+size_t Engine::cross_img_bytes(int B, int R, int P) const {
+    const size_t Cp = (size_t)pad8(R) + pad8(P);
+    return 4 * ((size_t)kBlocks * B * kHeads * Cp * 128 * 2 + 256) + 256;   // Kc, Vc^T, each hi + lo
+}
+int Engine::pack_cross(hipStream_t st, const float* k_ref, const float* v_ref, const float* k_text, const float* v_text, int B,
+                       int R, int P, char* ws, CrossImg& ci) {
+    ci = CrossImg();
+    if (!attn_img_ || (R <= 0 && P <= 0)) return 0;
+    const int pa = prec_[SITE_ATTN];
+    Bump bump(ws);
+    ci.Rp = pad8(R > 0 ? R : 0);
+    ci.Cp = ci.Rp + pad8(P > 0 ? P : 0);
+    const size_t n = (size_t)kBlocks * B * kHeads * ci.Cp * 128;
+    ci.kc = bump.take<bf16_t>(n); ci.kc_lo = bump.take<bf16_t>(n);
+    ci.vtc = bump.take<bf16_t>(n); ci.vtc_lo = bump.take<bf16_t>(n);
+    CrossPackArgs p{};
+    p.k_ref = k_ref; p.v_ref = v_ref; p.k_text = k_text; p.v_text = v_text;
+    p.kc = ci.kc; p.kc_lo = ci.kc_lo; p.vtc = ci.vtc; p.vtc_lo = ci.vtc_lo;
+    p.prec = pa; p.L = kBlocks; p.B = B; p.H = kHeads; p.dh = kDh; p.dhp = 128;
+    p.R = R > 0 ? R : 0; p.P = P > 0 ? P : 0; p.Rp = ci.Rp; p.Cp = ci.Cp;
+    ProfTag ptag("dit");
+    HIPC(launch_cross_pack(p, st));
+    return 0;
+}
+
+size_t Engine::denoise_ws_bytes(int B, int N, int R, int P, int rows) const {
     Bump b(nullptr);
     ModWs m;
     m.plan(b, rows);
-    return b.off + 256 + denoise_core_bytes(B, N);
+    return b.off + 256 + denoise_core_bytes(B, N) + cross_img_bytes(B, R, P);
 }
 
 int Engine::denoise_step(hipStream_t st, const float* x_t, const uint8_t* mask, const float* t, const float* k_ref,
@@ -1077,15 +1208,17 @@ int Engine::denoise_step(hipStream_t st, const float* x_t, const uint8_t* mask, 
                          void* ws, size_t ws_bytes) {
     if (!dit_ready_) return fail("denoise_step: DiT weights not finalized");
     if (N > kMaxPos) return fail("denoise_step: sequence longer than the rope table (4096)");
-    if (ws_bytes < denoise_ws_bytes(B, N, B)) return fail("denoise_step: workspace too small");
+    if (ws_bytes < denoise_ws_bytes(B, N, R, P, B)) return fail("denoise_step: workspace too small");
     HIPC(hipSetDevice(device_));
     Bump bump(ws);
     ModWs m;
     m.plan(bump, B);
     if (modulation(st, t, B, m.sinb, m.t1, m.temb, m.e1, m.semb, m.mod)) return 1;
     char* core = static_cast<char*>(ws) + ((bump.off + 255) & ~size_t(255));
+    CrossImg ci;
+    if (pack_cross(st, k_ref, v_ref, k_text, v_text, B, R, P, core + ((denoise_core_bytes(B, N) + 255) & ~size_t(255)), ci)) return 1;
     return denoise_core(st, x_t, mask, m.mod, 0, 1, k_ref, v_ref, ref_mask, k_text, v_text, ph_mask, rope, B, N, R, P,
-                        velocity, core);
+                        velocity, core, ci);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1127,13 +1260,13 @@ struct SampleWs {
 };
 }  // namespace
 
-size_t Engine::sample_ws_bytes(int B, int N, int n_steps, int cfg) const {
+size_t Engine::sample_ws_bytes(int B, int N, int R, int P, int n_steps, int cfg) const {
     Bump b(nullptr);
     SampleWs s;
     s.plan(b, B, N, n_steps, cfg);
     ModWs m;
     m.plan(b, n_steps);
-    return b.off + 256 + denoise_core_bytes(cfg ? 3 * B : B, N);
+    return b.off + 256 + denoise_core_bytes(cfg ? 3 * B : B, N) + cross_img_bytes(cfg ? 3 * B : B, R, P);
 }
 
 int Engine::sample(hipStream_t st, int mode, int n_steps, int cfg, float s_text, float s_spk, const uint8_t* mask,
@@ -1143,7 +1276,7 @@ int Engine::sample(hipStream_t st, int mode, int n_steps, int cfg, float s_text,
     if (!dit_ready_) return fail("sample: DiT weights not finalized");
     if (n_steps < 1) return fail("sample: n_steps must be >= 1");
     if (N > kMaxPos) return fail("sample: sequence longer than the rope table (4096)");
-    if (ws_bytes < sample_ws_bytes(B, N, n_steps, cfg)) return fail("sample: workspace too small");
+    if (ws_bytes < sample_ws_bytes(B, N, R, P, n_steps, cfg)) return fail("sample: workspace too small");
     HIPC(hipSetDevice(device_));
     Bump bump(ws);
     SampleWs s;
@@ -1166,16 +1299,18 @@ int Engine::sample(hipStream_t st, int mode, int n_steps, int cfg, float s_text,
     if (modulation(st, s.ts, n_steps, m.sinb, m.t1, m.temb, m.e1, m.semb, m.mod)) return 1;
 
     const int Bd = cfg ? 3 * B : B;
+    CrossImg ci;   // the cross-KV cache in the attention kernel's operand format: once per call, read by every step
+    if (pack_cross(st, k_ref, v_ref, k_text, v_text, Bd, R, P, core + ((denoise_core_bytes(Bd, N) + 255) & ~size_t(255)), ci)) return 1;
     // mask for 3B rows when cfg: caller passes mask with B rows; replicate by pointer arithmetic is impossible,
     // so the cfg path expects `mask` to already hold 3B rows (documented in the header).
     auto eval_velocity = [&](int step) -> int {
         if (!cfg)
             return denoise_core(st, s.xt, mask, m.mod, step, 0, k_ref, v_ref, ref_mask, k_text, v_text, ph_mask, nullptr,
-                                B, N, R, P, s.v, core);
+                                B, N, R, P, s.v, core, ci);
         for (int r = 0; r < 3; ++r)
             HIPC(hipMemcpyAsync(s.xt3 + r * e, s.xt, e * sizeof(float), hipMemcpyDeviceToDevice, st));
         if (denoise_core(st, s.xt3, mask, m.mod, step, 0, k_ref, v_ref, ref_mask, k_text, v_text, ph_mask, nullptr, Bd,
-                         N, R, P, s.v3, core))
+                         N, R, P, s.v3, core, ci))
             return 1;
         HIPC(launch_cfg_combine(s.v3, s.v, s_text, s_spk, e, st));
         return 0;

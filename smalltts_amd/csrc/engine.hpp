@@ -43,6 +43,8 @@ struct EncoderW {
 };
 struct DitBlockW {
     PW qkvg, out, ff13, ff2;
+    PW qkvgp;          // the same rows with every head padded 120 -> 128 (zero rows): [4 x 8 x 128][960], gemm3 EpiQKV's column layout
+    float* b_qkvgp;    // bias in that layout (pad and gate entries zero)
     float* b_qkvg;
     const float *b1, *b3, *b2, *qn, *kn;
 };
@@ -79,6 +81,8 @@ struct CodecSpecC {
     int hop() const { int h = 1; for (int i = 0; i < n_ratios; ++i) h *= ratios[i]; return h; }
 };
 
+static constexpr int kDefaultPrecision = PREC_F16;   // "f16 mixed" (DESIGN §2): one default for the C ABI and the Python host side
+
 class Engine {
   public:
     explicit Engine(int device);
@@ -104,7 +108,8 @@ class Engine {
                 SITE_CODEC_FFN = 4,   // codec block FFNs (fused kernels and the wide-stage GEMM pairs)
                 SITE_CODEC_CONV = 5,  // codec stem / resampling (ConvTranspose, strided conv) / encoder head GEMMs
                 SITE_CONVPOS = 6,     // the grouped conv k = 31 pos-embed of the DiT input embedding (split out of SITE_COND: 1.2 % of a batch's time)
-                SITE_COUNT = 7 };
+                SITE_ATTN = 7,        // attention operand images (q, k, V^T, sigmoid(gate), P) of the DiT blocks and the encoders
+                SITE_COUNT = 8 };
     // preset: 3 = split-bf16 everywhere (fp32-class), 1 = single-pass bf16 everywhere, 2 = "f16 mixed": single-pass fp16 on
     // the block / encoder / cross-KV / codec-FFN GEMMs, split-bf16 on SITE_COND and SITE_CODEC_CONV
     void set_precision(int preset) {
@@ -126,6 +131,9 @@ class Engine {
     int tuning() const { return tuning_; }
     void set_fused_ffn(bool on) { fused_ffn_ = on; }
     void set_attn_mfma(bool on) { attn_mfma_ = on; }
+    void set_attn_img(bool on) { attn_img_ = on; }
+    bool attn_img() const { return attn_img_; }
+    int site_precision(int site) const { return site >= 0 && site < SITE_COUNT ? prec_[site] : 0; }
     void set_attn_prep_fused(bool on) { attn_prep_fused_ = on ? 2 : 0; }   // (test hook: the kernel test wants the asked-for variant at any grid)
     bool attn_prep_fused() const { return attn_prep_fused_ != 0; }
     void reset_attn_prep_fused() { const char* s = getenv("SMTTS_ATTN_PREP"); attn_prep_fused_ = s ? atoi(s) : 0; }
@@ -138,7 +146,7 @@ class Engine {
                     const uint8_t* ph_mask, int B, int R, int P, float* k_ref, float* v_ref, uint8_t* ref_mask,
                     float* k_text, float* v_text, void* ws, size_t ws_bytes, float* ref_seq_out, float* mem_out);
 
-    size_t denoise_ws_bytes(int B, int N, int rows) const;
+    size_t denoise_ws_bytes(int B, int N, int R, int P, int rows) const;
     int denoise_step(hipStream_t st, const float* x_t, const uint8_t* mask, const float* t, const float* k_ref,
                      const float* v_ref, const uint8_t* ref_mask, const float* k_text, const float* v_text,
                      const uint8_t* ph_mask, const float* rope, int B, int N, int R, int P, float* velocity,
@@ -147,7 +155,7 @@ class Engine {
     // mode 0: DMD re-noising loop (infer/onnx.py:98-125); mode 1: teacher ODE (build-defined).
     // cfg != 0: caches/masks hold 3B rows [cond; no-text; no-speaker], x has B rows.
     // noise: mode 0 -> (n_steps, B, N, 64); mode 1 -> (B, N, 64); null -> Philox(seed).
-    size_t sample_ws_bytes(int B, int N, int n_steps, int cfg) const;
+    size_t sample_ws_bytes(int B, int N, int R, int P, int n_steps, int cfg) const;
     int sample(hipStream_t st, int mode, int n_steps, int cfg, float s_text, float s_spk, const uint8_t* mask,
                const float* k_ref, const float* v_ref, const uint8_t* ref_mask, const float* k_text,
                const float* v_text, const uint8_t* ph_mask, int B, int N, int R, int P, const float* noise,
@@ -191,10 +199,15 @@ class Engine {
     int modulation(hipStream_t st, const float* t_dev, int rows, float* sinb, float* t1, float* temb, float* e1,
                    float* semb, float* mod);
     struct DenoiseWs;
+    // cross-KV cache of all layers in the attention kernel's operand format (attention_img.hip), built once per sampler call
+    struct CrossImg { bf16_t *kc = nullptr, *kc_lo = nullptr, *vtc = nullptr, *vtc_lo = nullptr; int Rp = 0, Cp = 0; };
+    size_t cross_img_bytes(int B, int R, int P) const;
+    int pack_cross(hipStream_t st, const float* k_ref, const float* v_ref, const float* k_text, const float* v_text, int B, int R,
+                   int P, char* ws, CrossImg& ci);
     int denoise_core(hipStream_t st, const float* x_t, const uint8_t* mask, const float* mod, int mod_row0,
                      int mod_rstride, const float* k_ref, const float* v_ref, const uint8_t* ref_mask,
                      const float* k_text, const float* v_text, const uint8_t* ph_mask, const float* rope, int B,
-                     int N, int R, int P, float* velocity, char* ws);
+                     int N, int R, int P, float* velocity, char* ws, const CrossImg& ci);
     size_t denoise_core_bytes(int B, int N) const;
     // runs one block; the result lives in *x on return (the fused mixer ping-pongs *x <-> *xalt)
     int codec_block(hipStream_t st, const CodecBlockW& w, float** x, float** xalt, float* nbuf, bf16_t* n2hi, bf16_t* n2lo,
@@ -211,8 +224,8 @@ class Engine {
     bool packing_ = false;
     int tuning_ = TUNE_LATENCY;
     bool dual_stream_latency_ = true;  // the dual-stream setting that TUNE_LATENCY restores
-    int preset_ = PREC_BF16X3;
-    int prec_[SITE_COUNT] = {3, 3, 3, 3, 3, 3, 3};
+    int preset_ = kDefaultPrecision;   // set_precision(kDefaultPrecision) in the constructor fills prec_
+    int prec_[SITE_COUNT] = {3, 3, 3, 3, 3, 3, 3, 3};
     bool fused_ffn_ = true;  // test hook: smtts_test_set_fused_ffn
     bool block_wave_ = true;  // codec stages with C = 32 / 64: mixer + FFN in one kernel (SMTTS_BLOCK_WAVE=0: mixer_fused + codec_ffn_wave)
     int up_g3_mink_ = 2048;  // codec ConvTranspose-as-GEMM: gemm3 on a converted copy of the image from this K up (SMTTS_UP_G3_MINK; below: fp32-A kernel)
@@ -232,6 +245,8 @@ class Engine {
     bool convpos_by_group_ = true;  // grouped conv pos-embed as one product per group over the batch's rows (false: per (utterance, group))
     bool attn_fuse_prep(const struct AttnArgs& a) const;
     bool attn_mfma_ = true;  // matrix-core attention (attention_mfma.hip); false = fp32 VALU kernel (attention.hip)
+    bool attn_img_ = true;   // attention on producer-written operand images (attention_img.hip: DMA + MFMA only); false = the round-2 kernels above
+    bool attn_epi_ = true;   // ... written by the QKVG GEMM's own epilogue (gemm3 EpiQKV); false (SMTTS_ATTN_EPI=0): fp32 projection + qkv_pack kernel
     Profiler prof_;
     bool prof_on_ = false;
     bool finalized_ = false;

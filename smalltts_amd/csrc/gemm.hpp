@@ -203,6 +203,7 @@ template <int ACT>
 struct EpiStore {
     static constexpr bool PAIRED = false;
     static constexpr bool STAGE16 = true;
+    static constexpr bool TILE = false;
     float* out;
     RowMap omap;
     long o_z;
@@ -277,6 +278,7 @@ struct EpiStore {
 struct EpiSwiGLU {
     static constexpr bool PAIRED = true;
     static constexpr bool STAGE16 = true;
+    static constexpr bool TILE = false;
     float* out;
     long ldo;
     const float* b1;  // may be null
@@ -341,6 +343,7 @@ template <int GATE>
 struct EpiResid {
     static constexpr bool PAIRED = false;
     static constexpr bool STAGE16 = false;
+    static constexpr bool TILE = false;
     float* x;
     RowMap xmap;
     const float* bias;       // may be null
@@ -386,6 +389,7 @@ struct EpiResid {
 struct EpiKV {
     static constexpr bool PAIRED = false;
     static constexpr bool STAGE16 = false;
+    static constexpr bool TILE = false;
     float* kdst;
     float* vdst;
     const float* bias;  // [n]
@@ -424,6 +428,7 @@ template <int FINAL>
 struct EpiConvPos {
     static constexpr bool PAIRED = false;
     static constexpr bool STAGE16 = false;
+    static constexpr bool TILE = false;
     float* out;
     const float* h;       // FINAL only
     const float* bias;    // [G*cpg]
@@ -467,6 +472,94 @@ struct EpiConvPos {
         }
     }
     __device__ __forceinline__ void colpair(int, int, const RowCtx&, const floatx16&, const floatx16&) const {}
+};
+
+// ------------------------------------------------------------------------------------------
+// QKVG projection -> attention operand images (gemm3 only; attention_img.hip describes the consumer).
+// Columns of the packed weight: n = (part * H + h) * HW + d, part = 0 q | 1 k | 2 v | 3 gate, every head padded from dh to HW
+// (64 / 128) columns with zero weight rows, so that a 128-column tile holds whole heads of ONE part.  The whole workgroup
+// passes its accumulators (+ bias) through an fp32 LDS tile and then works row-wise:
+//   q / k : RMSNorm over the head (sum of squares across the wave), * norm weight, RoPE on (2i, 2i + 1), q * 1/sqrt(dh)
+//           -> Q / K images [B][H][Nseq][HW]                              (dit.py:95-108, style.py:21-25,52-55)
+//   v     : transposed -> V^T image [B][H][HW][Np] (lane = row: 64 consecutive keys per store instruction)
+//   gate  : sigmoid -> [M][H * dh]
+// all in the 16-bit operand format `prec`.  Same arithmetic, in the same order, as qkv_pack_kernel (attention_img.hip), which
+// tests/test_kernels_gpu.py holds it to bit for bit.
+// ------------------------------------------------------------------------------------------
+struct EpiQKV {
+    static constexpr bool PAIRED = false;
+    static constexpr bool STAGE16 = false;
+    static constexpr bool TILE = true;
+    static constexpr int TP = 129;   // fp32 LDS tile pitch (floats): odd, so that lane = row reads of the V part spread over the banks
+    const float* bias;               // [4 * H * HW], padded like the weight rows (null: none)
+    const float *qw, *kw;            // [H][dh]
+    const float *rope_cos, *rope_sin;
+    float eps, q_scale;
+    int rot_dim, prec;
+    bf16_t *q, *q_lo, *k, *k_lo, *vt, *vt_lo, *g, *g_lo;
+    int Nseq, H, dh, HW, Np;
+    // (the generic column protocol is not used by this epilogue)
+    __device__ __forceinline__ void rows(int, int, int, RowCtx&) const {}
+    __device__ __forceinline__ void col(int, int, const RowCtx&, const floatx16&) const {}
+    __device__ __forceinline__ void colpair(int, int, const RowCtx&, const floatx16&, const floatx16&) const {}
+
+    // BN == 128; the workgroup's NW waves are laid out WM x WN with TM x TN 32x32 tiles each; `tile` = >= 64 * TP * 4 bytes of LDS
+    template <int BM, int TM, int TN, int WN, int NW>
+    __device__ __forceinline__ void tile_epilogue(floatx16 (&acc)[TM][TN], int M, int m0, int n0, int wave, int lane, float* tile) const {
+        const int wm = wave / WN, wn = wave % WN;
+        const int fr = lane & 31, fh = lane >> 5;
+        const int part = n0 / (H * HW), h0 = (n0 % (H * HW)) / HW;   // (uniform)
+#pragma unroll
+        for (int rh = 0; rh < BM / 64; ++rh) {     // 64 rows of the tile at a time
+            __syncthreads();                       // the ring (first pass) / the previous half (second pass) is no longer read
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int r32 = (wm * TM + i) * 32 - rh * 64;   // first row of this 32-row block inside the half
+                if (r32 < 0 || r32 >= 64) continue;              // (uniform)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const int c = (wn * TN + j) * 32 + fr;
+                    const float bv = bias ? bias[n0 + c] : 0.f;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        tile[(r32 + 4 * fh + (r & 3) + 8 * (r >> 2)) * TP + c] = acc[i][j][r] + bv;
+                }
+            }
+            __syncthreads();
+            const int mh = m0 + rh * 64;           // first row of this half
+            if (part == 2) {
+                // V^T: lane = row (key), the wave walks its share of the columns (dims)
+                const int m = mh + lane;
+                if (m < M) {
+                    const int b = m / Nseq, n = m - b * Nseq;
+#pragma unroll 4
+                    for (int c = wave; c < 128; c += NW) {
+                        const int h = h0 + c / HW, d = c % HW;
+                        store_img1(vt, vt_lo, prec, (((long)b * H + h) * HW + d) * Np + n, tile[lane * TP + c]);
+                    }
+                }
+            } else {
+                const int c0 = 2 * lane, h = h0 + c0 / HW, d = c0 % HW;
+                for (int r = wave; r < 64; r += NW) {
+                    const int m = mh + r;
+                    if (m >= M) break;             // (uniform)
+                    const int b = m / Nseq, n = m - b * Nseq;
+                    float x0 = tile[r * TP + c0], x1 = tile[r * TP + c0 + 1];
+                    if (part == 3) {
+                        if (d < dh) store_img2(g, g_lo, prec, (long)m * ((long)H * dh) + h * dh + d, sigmoid_f(x0), sigmoid_f(x1));
+                    } else {
+                        float ss = fmaf(x1, x1, x0 * x0);
+                        ss = HW == 64 ? group_sum<32>(ss) : wave_sum(ss);
+                        const QkPrep pp{part ? kw : qw, rope_cos, rope_sin, rot_dim, dh, eps, part ? 1.0f : q_scale};
+                        pp.apply(x0, x1, ss, h, d, n);
+                        const long off = (((long)b * H + h) * Nseq + n) * HW + d;
+                        if (part) store_img2(k, k_lo, prec, off, x0, x1);
+                        else store_img2(q, q_lo, prec, off, x0, x1);
+                    }
+                }
+            }
+        }
+    }
 };
 
 // C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)

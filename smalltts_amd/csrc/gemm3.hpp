@@ -228,6 +228,12 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm3_kernel(Gemm3Operands g, Epi
                 }
         }
     }
+    if constexpr (Epi::TILE) {   // whole-workgroup epilogue through an fp32 LDS tile in the finished ring (EpiQKV)
+        static_assert(BN == 128 && (BM == 64 || BM == 128), "tile epilogue: 128-column tiles of 64 / 128 rows");
+        static_assert(64 * Epi::TP * 4 <= S * STAGE_LD, "tile epilogue: the fp32 tile must fit the finished ring");
+        epi.template tile_epilogue<BM, TM, TN, WN, NW>(acc, g.M, m0, n0, wave, lane, reinterpret_cast<float*>(smem));
+        return;
+    }
     if constexpr (Epi::STAGE16) {
         constexpr int W = Epi::PAIRED ? 32 : TN * 32;
         constexpr int STG = 32 * (2 * W + 16);   // bytes of one wave's staging tile

@@ -13,7 +13,7 @@ hipError_t gemm3_convpos(const Gemm3Operands& g, bool final, const EpiConvPos<0>
     ProfScope ps(st, gemm3_prof_name(g, false, G3_64x64, split, final ? "convpos_final" : "convpos"), gemm3_flops(g, Z),
                  gemm3_bytes(g, Z, split, 4.0, true), gemm_bytes8d(g.N, g.K, (g.ksplit_tiles ? 1 : Z), true));
     if (final) {
-        EpiConvPos<1> q{p.out, p.h, p.bias, p.mask, p.G, p.cpg, p.T, p.pad, p.gstride, nullptr, nullptr};
+        EpiConvPos<1> q{p.out, p.h, p.bias, p.mask, p.G, p.cpg, p.T, p.pad, p.gstride, nullptr, nullptr, p.by_group};
         return gemm3_launch(g, q, Z, split, st, G3_64x64);
     }
     return gemm3_launch(g, p, Z, split, st, G3_64x64);

@@ -14,7 +14,7 @@ hipError_t gemm_convpos(const GemmOperands& g, bool final, const EpiConvPos<0>& 
     ProfScope ps(st, gemm_prof_name(g, false, CFG_64x64, split, final ? "convpos_final" : "convpos"),
                  gemm_flops(g, Z), gemm_bytes(g, Z, split, 1.0, true), gemm_bytes8d(g.N, g.K, Z, true));
     if (final) {
-        EpiConvPos<1> q{p.out, p.h, p.bias, p.mask, p.G, p.cpg, p.T, p.pad, p.gstride, nullptr, nullptr};
+        EpiConvPos<1> q{p.out, p.h, p.bias, p.mask, p.G, p.cpg, p.T, p.pad, p.gstride, nullptr, nullptr, p.by_group};
         return gemm_launch(g, q, Z, split, st, CFG_64x64);
     }
     return gemm_launch(g, p, Z, split, st, CFG_64x64);

@@ -34,7 +34,13 @@ hipError_t gemm_convpos(const GemmOperands& g, bool final, const EpiConvPos<0>& 
 static inline std::string gemm3_prof_name(const Gemm3Operands& g, bool paired, int cfg, int split, const char* epi) {
     if (cfg < 0) cfg = gemm3_pick_cfg(g.M, g.N, paired, split != PREC_BF16X3);
     static const char* tiles[] = {"64x128", "128x128", "64x64", "128x64", "128x32", "160x128", "128x128w4"};
-    return std::string("gemm3<") + tiles[cfg] + ",s" + std::to_string(split) + "," + epi + ">";
+    std::string n = std::string("gemm3<") + tiles[cfg] + ",s" + std::to_string(split) + "," + epi + ">";
+    extern thread_local int g_prof_shapes;   // profile mode 3: the product's shape behind the class name ("... 600x3840x960[/k3]")
+    if (g_prof_shapes) {
+        n += " " + std::to_string(g.M) + "x" + std::to_string(g.N) + "x" + std::to_string(g.K);
+        if (g.ksplit_tiles) n += "/k" + std::to_string((g.K / 64 + g.ksplit_tiles - 1) / g.ksplit_tiles);
+    }
+    return n;
 }
 // split-K launches (ksplit_tiles > 0) use blockIdx.z for K slices of ONE product: the work is counted once
 static inline double gemm3_flops(const Gemm3Operands& g, int Z) {
@@ -53,3 +59,5 @@ hipError_t gemm3_swiglu(const Gemm3Operands& g, const EpiSwiGLU& p, int split, h
 hipError_t gemm3_resid(const Gemm3Operands& g, int gate_mode, const EpiResid<0>& p, int split, hipStream_t st, int cfg = -1);
 hipError_t gemm3_kv(const Gemm3Operands& g, const EpiKV& p, int split, hipStream_t st);
 hipError_t gemm3_convpos(const Gemm3Operands& g, bool final, const EpiConvPos<0>& p, int Z, int split, hipStream_t st);
+// QKVG projection -> attention operand images (EpiQKV): columns n = (part * H + h) * HW + d, N = 4 * H * HW
+hipError_t gemm3_qkv(const Gemm3Operands& g, const EpiQKV& p, int split, hipStream_t st);

@@ -41,6 +41,7 @@ struct AttnArgs {
     float* out; long obs, ors;  // out (b, n, h*dh + d)
     bf16_t* out_hi; bf16_t* out_lo;  // when out_hi != null the result is written as a split bf16 pair instead
     int B, N, H, dh;
+    int dbg_lds_bytes;  // (r03 debug builds only)
 };
 hipError_t launch_attention(const AttnArgs& a, hipStream_t st);
 // Matrix-core variant (attention_mfma.hip): same arguments, needs prenormed = 1.
@@ -52,6 +53,45 @@ extern int g_attn_resident;
 // In place on the packed projection buffer: q <- RoPE(RMSNorm_head(q) * qw), k <- RoPE(RMSNorm_head(k) * kw)
 // (dit.py:95-108); one wave per (row, head, q|k).  Uses the q/k/bs/rs/qw/kw/eps/rope/rot_dim/B/N/H/dh fields.
 hipError_t launch_qk_prep(const AttnArgs& a, hipStream_t st);
+
+// ---- attention on producer-written operand images (attention_img.hip) -----------------------------------------------------------
+// Every array is a 16-bit GEMM-operand array in format `prec` (PREC_F16 / PREC_BF16: `*_lo` unused; PREC_BF16X3: hi + lo pair).
+static inline int pad8(int n) { return (n + 7) & ~7; }
+struct AttnImg {
+    int prec;
+    const bf16_t *q, *q_lo;      // [B][H][N][DHP]   RMSNorm_head * w, RoPE, x 1/sqrt(dh)   (DHP = 64 / 128, pad dims zero)
+    const bf16_t *k, *k_lo;      // [B][H][N][DHP]   self keys, normalised + rotated
+    const bf16_t *vt, *vt_lo;    // [B][H][DHP][Np]  self values transposed, Np = pad8(N), columns >= N zero
+    const bf16_t *g, *g_lo;      // [B*N][H*dh]      sigmoid(gate)
+    const bf16_t *kc, *kc_lo;    // [B][H][Cp][DHP]  cross keys of this layer (null: self-attention only), pad rows zero
+    const bf16_t *vtc, *vtc_lo;  // [B][H][DHP][Cp]  cross values transposed; Cp = Rp + pad8(P), Rp = pad8(R)
+    const uint8_t *mask_self, *mask_ref, *mask_text;   // [B][N], [B][R], [B][P] key validity (null = all valid)
+    bf16_t *out_hi, *out_lo;     // o[(b*N + n)*ors + h*dh + d] in the format store_split4 derives from out_lo
+    long ors;
+    int B, N, H, dh, Np, R, P, Rp, Cp;
+};
+hipError_t launch_attention_img(const AttnImg& a, hipStream_t st);
+// fp32 projection rows [B*N][4*H*dh] = [q | k | v | gate] (bias included) -> the self part of AttnImg (dit.py:95-108; the arithmetic
+// the gemm3 EpiQKV epilogue performs on its accumulators, as a stand-alone kernel: test hook + reference for the epilogue)
+struct QkvPackArgs {
+    const float* qkvg;
+    const float *qw, *kw;        // [H][dh]
+    float eps, q_scale;
+    const float *rope_cos, *rope_sin;   // [pos][rot_dim]
+    int rot_dim, prec;
+    bf16_t *q, *q_lo, *k, *k_lo, *vt, *vt_lo, *g, *g_lo;
+    int B, N, H, dh, dhp, Np;
+};
+hipError_t launch_qkv_pack(const QkvPackArgs& p, hipStream_t st);
+// fp32 cross-KV caches [L][B][H][R|P][dh] (the C ABI's rank-5 tensors) -> Kc [L][B][H][Cp][dhp], Vc^T [L][B][H][dhp][Cp]
+struct CrossPackArgs {
+    const float *k_ref, *v_ref, *k_text, *v_text;
+    bf16_t *kc, *kc_lo, *vtc, *vtc_lo;
+    int prec, L, B, H, dh, dhp, R, P, Rp, Cp;
+};
+hipError_t launch_cross_pack(const CrossPackArgs& p, hipStream_t st);
+// out[i] = hi[i] + lo[i]  (a split bf16 pair back to fp32: test hooks)
+hipError_t launch_split_to_f32(const bf16_t* hi, const bf16_t* lo, float* out, long n, hipStream_t st);
 
 // out[m][:] = table[ids[m]][:]  (phonemes.py:201)
 hipError_t launch_embedding(const int64_t* ids, const float* table, float* out, int M, int C, int vocab, hipStream_t st);

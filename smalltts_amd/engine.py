@@ -18,7 +18,7 @@ from .weights import (DEFAULT_CODEC, CodecSpec, codec_decoder_param_specs, codec
 N_LAYERS, N_HEADS, HEAD_DIM, LATENT = 12, 8, 120, 64
 ACT = {"none": 0, "silu": 1, "gelu": 2, "mish": 3}
 PRECISION = {"bf16x3": 3, "f16": 2, "bf16": 1}   # presets of smtts_set_precision (include/smalltts_hip.h)
-SITES = {"dit_block": 0, "encoder": 1, "cross_kv": 2, "cond": 3, "codec_ffn": 4, "codec_conv": 5, "convpos": 6}
+SITES = {"dit_block": 0, "encoder": 1, "cross_kv": 2, "cond": 3, "codec_ffn": 4, "codec_conv": 5, "convpos": 6, "attn": 7}
 DEFAULT_PRECISION = "f16"
 
 
@@ -210,7 +210,7 @@ class HipEngine:
         B, N, _ = x_t.shape
         R, P = cache["k_ref"].shape[3], cache["k_text"].shape[3]
         v = torch.empty_like(x_t)
-        ws = self._workspace(self.lib.smtts_denoise_workspace_bytes(self.h, B, N))
+        ws = self._workspace(self.lib.smtts_denoise_workspace_bytes(self.h, B, N, R, P))
         self._ck(self.lib.smtts_denoise_step(self.h, self._stream(), _p(x_t), _p(mask), _p(t), _p(cache["k_ref"]),
                                              _p(cache["v_ref"]), _p(cache["ref_mask"]), _p(cache["k_text"]),
                                              _p(cache["v_text"]), _p(cache["ph_mask"]), _p(rope), B, N, R, P, _p(v),
@@ -236,7 +236,7 @@ class HipEngine:
             assert tuple(noise.shape) == want, f"noise shape {tuple(noise.shape)} != {want}"
         x = torch.empty(B, N, LATENT, device=self.device)
         steps = torch.empty(num_steps, B, N, LATENT, device=self.device) if return_steps else None
-        ws = self._workspace(self.lib.smtts_sample_workspace_bytes(self.h, B, N, num_steps, int(cfg)))
+        ws = self._workspace(self.lib.smtts_sample_workspace_bytes(self.h, B, N, R, P, num_steps, int(cfg)))
         self._ck(self.lib.smtts_sample(self.h, self._stream(), {"dmd": 0, "ode": 1}[mode], num_steps, int(cfg), s_text,
                                        s_spk, _p(mask_in), _p(cache["k_ref"]), _p(cache["v_ref"]),
                                        _p(cache["ref_mask"]), _p(cache["k_text"]), _p(cache["v_text"]),
@@ -314,13 +314,14 @@ class HipEngine:
         self._ck(self.lib.smtts_pcm16(self.h, self._stream(), _p(x), x.numel(), _p(y)), "pcm16")
         return y
 
-    def profile(self, on, tagged: bool = False):
-        """on: False/True; tagged=True prefixes kernel names with the pipeline phase (enc, mod, dit, dec.s<i> ...)."""
+    def profile(self, on, tagged: bool = False, shapes: bool = False):
+        """on: False/True; tagged=True prefixes kernel names with the pipeline phase (enc, mod, dit, dec.s<i> ...); shapes=True
+        (implies tagged) also appends each GEMM product's shape to its class name ("gemm3<...> 600x3840x960")."""
         if on and getattr(self, "tuning", "latency") == "throughput":
             raise RuntimeError("per-kernel profiling pairs HIP events around every launch and assumes ONE call at a time: "
                                "leave throughput tuning / batches in flight first")
         self._profiling = bool(on)
-        self._ck(self.lib.smtts_profile_enable(self.h, (2 if tagged else 1) if on else 0), "profile_enable")
+        self._ck(self.lib.smtts_profile_enable(self.h, (3 if shapes else 2 if tagged else 1) if on else 0), "profile_enable")
 
     def profile_report(self):
         import json
@@ -378,13 +379,22 @@ class HipEngine:
         P = 0 if k_text is None else k_text.shape[2]
         out = torch.empty(B, N, H * dh, device=self.device)
         fn = self.lib.smtts_test_attention_mfma if mfma else self.lib.smtts_test_attention
-        if mfma:   # True / "fused": q / k prep inside the attention kernel (the engine default); "prep": separate qk_prep launch;
-            # a "+stream" suffix keeps the streaming form where the resident-K/V form would apply
-            mode = (2 if str(mfma).startswith("prep") else 1) + (4 if str(mfma).endswith("+stream") else 0)
+        if mfma:
+            # "img" / "img:f16" / "img:bf16x3": the DMA + MFMA kernel on producer-written operand images (the engine default) at
+            # that operand precision.  Round-2 kernels: True / "fused": q / k prep inside the matrix-core kernel; "prep": separate
+            # qk_prep launch; a "+stream" suffix keeps their streaming form where the resident-K/V form would apply
+            s = str(mfma)
+            if s.startswith("img"):
+                mode = 3
+                self._ck(self.lib.smtts_set_site_precision(self.h, SITES["attn"], PRECISION[s.split(":")[1] if ":" in s else "bf16x3"]),
+                         "set_site_precision")
+            else:
+                mode = 8 + (2 if s.startswith("prep") else 1) + (4 if s.endswith("+stream") else 0)
             self._ck(self.lib.smtts_test_set_attention_mfma(self.h, mode), "set_attention_mfma")
         self._ck(fn(self.h, self._stream(), _p(qkvg), _p(qw), _p(kw), eps, _p(rope), rot_dim,
                                                _p(k_ref), _p(v_ref), R, _p(k_text), _p(v_text), P, _p(mask_self),
                                                _p(mask_ref), _p(mask_text), B, N, H, dh, _p(out)), "test_attention")
         if mfma:
             self._ck(self.lib.smtts_test_set_attention_mfma(self.h, 3), "set_attention_mfma")
+            self.set_precision(self.precision)
         return out

@@ -67,9 +67,13 @@ class ShardContext:
     benchmark contract asks for, and the waveform gather.  world == 1 needs no process group and every method degenerates."""
 
     def __init__(self, world: int = 1, rank: int = 0, local_rank: int = 0, backend: Optional[str] = None, group=None,
-                 owns_group: bool = False):
+                 owns_group: bool = False, collective: Optional[bool] = None):
         self.world, self.rank, self.local_rank = int(world), int(rank), int(local_rank)
         self.backend, self.group, self._owns = backend, group, owns_group
+        # collectives are issued when there is more than one rank — or when a process group was FORCED at world 1
+        # (SMTTS_DIST_FORCE=1): the RCCL path (init with device_id, device-side all_gather_into_tensor, barrier, all_reduce,
+        # destroy) can then be executed and tested on a single GPU, so an 8-GPU run does not meet it for the first time
+        self.collective = (self.world > 1) if collective is None else bool(collective)
         self.on_gpu = torch.cuda.is_available()
         n_dev = torch.cuda.device_count() if self.on_gpu else 0
         # gloo runs (tests, several ranks sharing one GPU) wrap the local rank; an nccl job has one GPU per rank
@@ -86,19 +90,25 @@ class ShardContext:
         world = int(os.environ.get("WORLD_SIZE", "1"))
         rank = int(os.environ.get("RANK", "0"))
         local = int(os.environ.get("LOCAL_RANK", "0"))
-        if world <= 1:
+        force = os.environ.get("SMTTS_DIST_FORCE", "") == "1"   # a process group even at world 1 (tests / the nccl smoke run)
+        if world <= 1 and not force:
             return cls(1, 0, local)
         backend = backend or os.environ.get("SMTTS_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC (RCCL needs it on this driver)
         owns = False
         if not dist.is_initialized():
+            if world <= 1:   # forced single-rank group outside a launcher: supply the rendezvous ourselves
+                os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+                os.environ.setdefault("MASTER_PORT", "29517")
+                os.environ.setdefault("WORLD_SIZE", "1")
+                os.environ.setdefault("RANK", "0")
             if backend == "nccl":
                 torch.cuda.set_device(local)
                 dist.init_process_group("nccl", device_id=torch.device("cuda", local))
             else:
                 dist.init_process_group(backend)
             owns = True
-        ctx = cls(world, rank, local, backend, None, owns)
+        ctx = cls(max(world, 1), rank, local, backend, None, owns, collective=True)
         if ctx.on_gpu:
             torch.cuda.set_device(ctx.device_index)
         return ctx
@@ -115,13 +125,13 @@ class ShardContext:
     def barrier(self) -> None:
         if self.on_gpu:
             torch.cuda.synchronize()
-        if self.world > 1:
+        if self.collective:
             dist.barrier(group=self.group)
             if self.on_gpu:
                 torch.cuda.synchronize()
 
     def max_over_ranks(self, seconds: float) -> float:
-        if self.world <= 1:
+        if not self.collective:
             return float(seconds)
         t = torch.tensor([seconds], device=self.comm_device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
@@ -132,21 +142,21 @@ class ShardContext:
         return shard_range(n_items, self.world, self.rank)
 
     def gather_buffer(self, n_total: int, samples: int, dtype=torch.float32) -> Optional[torch.Tensor]:
-        """Pre-allocated output of gather_waveforms for a steady-state loop with equal shards (None when world == 1)."""
-        if self.world <= 1:
+        """Pre-allocated output of gather_waveforms for a steady-state loop with equal shards (None without collectives)."""
+        if not self.collective:
             return None
         return torch.empty(n_total, 1, samples, dtype=dtype, device=self.comm_device)
 
     def gather_waveforms(self, local: torch.Tensor, n_total: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
         """(n_local, 1, S) of this rank -> (n_total, 1, S) on every rank; the only collective of the path."""
-        if self.world <= 1:
+        if not self.collective:
             return local
         if local.device != self.comm_device:
             local = local.to(self.comm_device)
         return all_gather_waveforms(local, n_total, self.group, out)
 
     def close(self) -> None:
-        if self.world > 1 and self._owns and dist.is_initialized():
+        if self.collective and self._owns and dist.is_initialized():
             dist.barrier(group=self.group)
             dist.destroy_process_group()
 

@@ -33,6 +33,18 @@ def test_loader_sets_signatures_and_host_only_calls_work():
     assert abs(a.value - 7.853981515e-6) < 1e-11 and s.value == 1.0
 
 
+def test_one_precision_default_for_the_c_abi_and_the_python_host_side():
+    """A handle from smtts_create starts at the same preset the Python engine asks for ("f16 mixed" = 2), and the header says so."""
+    _need_lib()
+    from smalltts_amd import engine as weights
+    lib = _lib.load()
+    assert lib.smtts_default_precision() == 2
+    assert weights.PRECISION[weights.DEFAULT_PRECISION] == 2
+    with open(_lib.HEADER_PATH) as f:
+        txt = f.read()
+    assert "THE DEFAULT of a new handle" in txt and "single-stream" not in txt
+
+
 def test_schedule_matches_reference_kat():
     """smtts_alpha_sigma (host float64 math in C++) vs the reference's numpy values."""
     _need_lib()
@@ -60,7 +72,7 @@ def test_null_handle_is_an_error_not_a_crash():
     for smtts_last_error(NULL); none of them touches HIP before the check, so this runs without a GPU."""
     _need_lib()
     lib = _lib.load()
-    skip = {"smtts_create", "smtts_destroy", "smtts_last_error", "smtts_version", "smtts_alpha_sigma"}
+    skip = {"smtts_create", "smtts_destroy", "smtts_last_error", "smtts_version", "smtts_alpha_sigma", "smtts_default_precision"}
     for name, (res, args) in _lib.SIGNATURES.items():
         if name in skip:
             continue

@@ -284,3 +284,22 @@ def test_gelu_q5_constants_in_the_kernel_header_meet_their_error_bound():
     c = np.array([float(v) for v in re.findall(r"Q\d = (-?[0-9.e-]+)f", body)], np.float32)
     assert c.size == 6 and c[-1] < 0            # negative leading coefficient: |x| -> inf extrapolates to max(x, 0)
     assert fp32_error(c) < 2.2e-6
+
+
+def test_optional_codec_tensor_switched_off_by_the_spec_is_an_error_not_a_silent_drop():
+    """_validated() filters a source down to the inventory of the CodecSpec in force; a final-norm weight or a bias
+    that the spec says is absent would have vanished without a word although the engine applies such tensors when present."""
+    import numpy as np
+    import pytest
+    from smalltts_amd.api import _validated
+    from smalltts_amd.weights import CodecSpec, all_param_specs
+    on = CodecSpec(final_norm=True)
+    off = CodecSpec(final_norm=False, ffn_bias=False)
+    tensors = {k: np.zeros(s, np.float32) for k, s in all_param_specs(on) if k.startswith("codec.decoder.")}
+    assert len(_validated(tensors, "t", on)) == len(tensors)
+    with pytest.raises(ValueError, match="optional codec parameter"):
+        _validated(tensors, "t", off)
+    kept = {k: v for k, v in tensors.items() if k in dict(all_param_specs(off))}
+    assert 0 < len(_validated(kept, "t", off)) == len(kept) < len(tensors)
+    extra = dict(kept, **{"optimizer.state.step": np.zeros(1, np.float32)})      # unrelated keys are still just ignored
+    assert len(_validated(extra, "t", off)) == len(kept)

@@ -172,7 +172,7 @@ def _attn_ref(qkvg, qw, kw, eps, rope, rot, H, dh, kr, vr, kt, vt, ms, mr, mt):
 @pytest.mark.parametrize("B,N,H,dh,rot,R,P", [(2, 75, 8, 120, 64, 15, 30), (3, 21, 8, 64, 64, 0, 0),
                                              (2, 40, 4, 128, 128, 0, 0), (2, 130, 8, 120, 64, 70, 90),
                                              (1, 5, 8, 120, 64, 3, 2), (16, 75, 8, 120, 64, 15, 30)])   # last: resident-K/V form
-@pytest.mark.parametrize("mfma", [False, "fused", "prep"])
+@pytest.mark.parametrize("mfma", [False, "img:bf16x3", "img:f16", "img:bf16", "fused", "prep"])
 def test_attention(eng, B, N, H, dh, rot, R, P, mfma):
     D = H * dh
     qkvg = _rand(B, N, 4 * D, seed=20)
@@ -190,7 +190,8 @@ def test_attention(eng, B, N, H, dh, rot, R, P, mfma):
     ref = _attn_ref(qkvg, qw, kw, 1e-6, rope, rot, H, dh, kr, vr, kt, vt, ms, mr, mt)
     got = eng.test_attention(qkvg, qw, kw, 1e-6, rope, rot, H, dh, kr, vr, kt, vt, ms, mr, mt, mfma=mfma).cpu()
     err = rel_l2(got.numpy(), ref.numpy())
-    assert err < (3e-5 if mfma else 1e-5), f"attention (mfma={mfma}): {err:.3e}"
+    tol = {"img:f16": 1.5e-3, "img:bf16": 1.2e-2}.get(mfma, 3e-5 if mfma else 1e-5)   # single-pass operand formats: 2^-11 / 2^-8 rounding
+    assert err < tol, f"attention (mfma={mfma}): {err:.3e}"
 
 
 def test_attention_resident_form_is_bit_identical_to_the_streaming_form(eng):
@@ -219,7 +220,7 @@ def test_attention_all_keys_masked_gives_zero(eng):
     w = torch.ones(H, dh)
     rope = torch.zeros(N, dh)
     ms = torch.ones(B, N, dtype=torch.bool); ms[1] = False
-    for mfma in (False, "fused", "prep"):
+    for mfma in (False, "img:bf16x3", "img:f16", "fused", "prep"):
         got = eng.test_attention(qkvg, w, w, 1e-5, rope, dh, H, dh, mask_self=ms, mfma=mfma).cpu()
         assert torch.isfinite(got).all() and float(got[1].abs().max()) == 0.0 and float(got[0].abs().max()) > 0
 
@@ -258,3 +259,33 @@ def test_device_pcm16_is_bit_exact_with_the_wav_writer(eng, tmp_path):
     host = np.frombuffer(open(tmp_path / "a.wav", "rb").read()[44:], "<i2")
     dev = eng.pcm16(x).cpu().numpy()
     assert dev.dtype == np.int16 and np.array_equal(dev, host)
+
+
+@pytest.mark.parametrize("prec", ["f16", "bf16x3"])
+def test_qkvg_epilogue_writes_the_images_the_pack_kernel_writes_bit_for_bit(prec, monkeypatch):
+    """gemm3 EpiQKV (head RMSNorm + RoPE + operand formatting on the GEMM's accumulators, through an LDS tile) against the
+    stand-alone qkv_pack kernel on the fp32 projection of the same GEMM: the same arithmetic in the same order, so the whole
+    chain behind them — encoders (dh 64 / 128, unpadded heads), DiT blocks (dh 120 padded to 128 columns), ragged masks,
+    cross keys — must agree bit for bit.  Also at M = 1800 rows (the teacher's 128x128 tiles)."""
+    from smalltts_amd.engine import HipEngine
+    engs = {}
+    for epi in ("1", "0"):
+        monkeypatch.setenv("SMTTS_ATTN_EPI", epi)
+        e = HipEngine(0, prec); e.load_synthetic(7, parts=("dit",)); e.finalize()
+        engs[epi] = e
+    for (B, N, R, P) in [(3, 75, 15, 30), (2, 33, 9, 70), (24, 75, 15, 30)]:
+        g = torch.Generator().manual_seed(B * 100 + N)
+        ref = torch.randn(B, R, 64, generator=g); ids = torch.randint(1, 198, (B, P), generator=g)
+        rl = torch.full((B,), R); rl[-1] = max(1, R // 2)
+        pm = torch.ones(B, P, dtype=torch.bool); pm[0, P // 3:] = False
+        mask = torch.ones(B, N, dtype=torch.bool); mask[-1, N - 5:] = False
+        xt = torch.randn(B, N, 64, generator=g); t = torch.full((B,), 0.6)
+        outs = {}
+        for epi, e in engs.items():
+            c = e.cond_encode(ref, rl, ids, pm, debug=True)
+            v = e.denoise_step(xt, mask, t, c)
+            outs[epi] = {k: x.clone() for k, x in c.items() if torch.is_tensor(x)} | {"velocity": v.clone()}
+        for k in outs["1"]:
+            assert torch.equal(outs["1"][k], outs["0"][k]), f"{prec} B={B} N={N}: {k} differs, max {float((outs['1'][k].float() - outs['0'][k].float()).abs().max()):.3e}"
+    for e in engs.values():
+        e.close()

@@ -98,3 +98,36 @@ def test_error_paths_match_the_reference_handler(srv):
     assert _req(port, "POST", "/synthesize?duration=1", b"x" * 10, "text/plain")[0] == 400
     big, ct = _multipart({"audio": (b"\0" * (S.BODY_LIMIT + 1), "r.wav"), "text": (b"hi", None)})
     assert _req(port, "POST", "/synthesize?duration=1", big, ct)[0] == 413                  # RequestBodyLimitLayer 2 MiB
+
+
+def test_bad_duration_or_token_count_is_a_400_for_the_offender_alone(srv):
+    """limits are checked before a request may join a shared batch — nan / inf / huge durations and empty or
+    over-long token lists never reach the batcher (where they would have failed every request of the batch with a 500)."""
+    port, b = srv
+    ref = S.encode_wav(np.zeros(4800), 24000)
+    body, ct = _multipart({"audio": (ref, "r.wav"), "text": (b"hi", None)})
+    for d in ("nan", "inf", "-inf", "-1", "0", "1e9", "600"):
+        st, _, msg = _req(port, "POST", f"/synthesize?duration={d}", body, ct)
+        assert st == 400 and msg.startswith(b"invalid `duration`"), (d, st, msg)
+    body, ct = _multipart({"audio": (ref, "r.wav"), "tokens": (str(list(range(1, 4098))).encode(), None)})
+    st, _, msg = _req(port, "POST", "/synthesize?duration=1", body, ct)
+    assert st == 400 and msg.startswith(b"invalid text: 4097 tokens")
+    body, ct = _multipart({"audio": (ref, "r.wav"), "tokens": (b"[]", None)})
+    assert _req(port, "POST", "/synthesize?duration=1", body, ct)[0] == 400
+    assert b.seen == []                                                  # none of them was submitted
+    assert S.validate_request(546.0, [1]) == S.MAX_FRAMES - 1 and S.validate_request(0.01, [1] * 4096) == 1
+
+
+def test_dispatcher_packs_a_deep_queue_but_never_waits_beyond_max_batch():
+    """Batcher._gather: up to max_batch inside the window, then whatever is ALREADY queued up to max_pack."""
+    import queue
+    g = S.Batcher.__new__(S.Batcher)
+    g.q, g.max_batch, g.max_pack, g.window = queue.Queue(), 8, 24, 0.002
+    for i in range(30):
+        g.q.put(i)
+    assert g._gather() == list(range(24)) and g._gather() == list(range(24, 30))
+    for i in range(3):
+        g.q.put(i)
+    assert g._gather() == [0, 1, 2]
+    g.q.put(7); g.q.put(None)
+    assert g._gather() == [7] and g._gather() is None
