@@ -167,15 +167,14 @@ int smtts_test_attention(smtts_handle h, void* stream, const float* qkvg, const 
                          const float* k_text, const float* v_text, int P, const uint8_t* mask_self,
                          const uint8_t* mask_ref, const uint8_t* mask_text, int B, int N, int H, int dh, float* out);
 
-/* matrix-core attention (qk_prep + attention_mfma kernel), same contract as smtts_test_attention */
+/* the product's attention path in isolation: stand-alone producers (qkv_pack + cross_pack) write the operand images, then the DMA + MFMA
+ * kernel (attention_img.hip) at the site-7 operand precision; same contract as smtts_test_attention (the fp32 VALU reference) */
 int smtts_test_attention_mfma(smtts_handle h, void* stream, const float* qkvg, const float* qw, const float* kw, float eps,
                               const float* rope, int rot_dim, const float* k_ref, const float* v_ref, int R,
                               const float* k_text, const float* v_text, int P, const uint8_t* mask_self,
                               const uint8_t* mask_ref, const uint8_t* mask_text, int B, int N, int H, int dh, float* out);
-/* engine-wide switch: 1 (default) = matrix-core attention, 0 = fp32 VALU attention kernel */
-/* default (bit 3 clear): the DMA + MFMA kernel on producer-written operand images (attention_img.hip).  + 8: the round-2 kernels,
- * selected by the low bits — 0: fp32 VALU attention; 1: matrix cores, q / k head-norm + RoPE fused into the staging; 2: matrix cores
- * after a separate in-place qk_prep launch; 3: matrix cores, prep placement as the engine defaults; + 4: never their resident-K/V form */
+/* engine-wide A/B switch: non-zero (default) = operand images written by the QKVG GEMM epilogue + the DMA / MFMA attention kernel;
+ * 0 = fp32 projection + in-place qk_prep + the fp32 VALU reference kernel */
 int smtts_test_set_attention_mfma(smtts_handle h, int mode);
 
 #ifdef __cplusplus

@@ -261,21 +261,31 @@ __global__ __launch_bounds__(256) void attention_img_kernel(AttnImg a, int nslot
     };
 
     // ---- normalise, gate, store: lane = query fr, rows = dims 32 w + (r & 3) + 8 (r >> 2) + 4 fh -----------------------------
+    // sigmoid(gate) of this lane's output elements: requested at the top of a tile, together with the DMAs, so that the
+    // epilogue does not start with a dependent memory round trip
+    float4 g4[4];
+    auto load_gate = [&](int q0) {
+        const int n = q0 + fr;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int d0 = 32 * w + 8 * q + 4 * fh;
+            g4[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (w < NDT && n < N && d0 < a.dh)
+                g4[q] = load_act4(a.g, a.g_lo, ((long)b * N + n) * ((long)a.H * a.dh) + h * a.dh + d0);
+        }
+    };
     auto finish = [&](int q0) {
         const int n = q0 + fr;
         if (w < NDT && n < N) {
             const float inv = l_run > 0.f ? 1.0f / l_run : 0.f;
-            const long gbase = ((long)b * N + n) * ((long)a.H * a.dh) + h * a.dh;
             const long obase = ((long)b * N + n) * a.ors + h * a.dh;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int d0 = 32 * w + 8 * q + 4 * fh;
-                if (d0 < a.dh) {   // dh % 4 == 0: a group of four dims is entirely inside or outside the head
-                    const float4 g4 = load_act4(a.g, a.g_lo, gbase + d0);
+                if (d0 < a.dh)   // dh % 4 == 0: a group of four dims is entirely inside or outside the head
                     store_split4(a.out_hi, a.out_lo, obase + d0,
-                                 make_float4(oacc[4 * q + 0] * inv * g4.x, oacc[4 * q + 1] * inv * g4.y,
-                                             oacc[4 * q + 2] * inv * g4.z, oacc[4 * q + 3] * inv * g4.w));
-                }
+                                 make_float4(oacc[4 * q + 0] * inv * g4[q].x, oacc[4 * q + 1] * inv * g4[q].y,
+                                             oacc[4 * q + 2] * inv * g4[q].z, oacc[4 * q + 3] * inv * g4[q].w));
             }
         }
     };
@@ -306,6 +316,7 @@ __global__ __launch_bounds__(256) void attention_img_kernel(AttnImg a, int nslot
             issue_chunk(0, 0);
         }
         reset();
+        load_gate(qt * QT);
 #pragma unroll 1
         for (int c = 0; c < nch; ++c) {
             const unsigned long long vmask = nch <= 4 ? (c == 0 ? vm0 : c == 1 ? vm1 : c == 2 ? vm2 : vm3) : chunk_mask(c * KC);
@@ -360,7 +371,7 @@ hipError_t launch_attention_img(const AttnImg& a, hipStream_t st) {
     const double kt = a.N + (a.kc ? a.R + a.P : 0);
     const double bhd = (double)a.B * a.H * a.dh;
     const double eb = a.prec == PREC_BF16X3 ? 4.0 : 2.0;   // bytes per operand element
-    ProfScope ps(st, a.dh == 120 ? "attention_img<120>" : a.dh == 64 ? "attention_img<64>" : "attention_img<128>",
+    ProfScope ps(st, a.dh <= 64 ? "attention_img<64>" : "attention_img<128>",   // (padded head dim: the kernel's template argument)
                  4.0 * bhd * a.N * kt, eb * bhd * (4.0 * a.N + 2.0 * (kt - a.N)));
     const int dhp = a.dh <= 64 ? 64 : 128;
     if (a.dh > 128) return hipErrorInvalidValue;

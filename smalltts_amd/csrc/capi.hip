@@ -157,12 +157,8 @@ int smtts_test_gemm3(smtts_handle h, void* stream, const float* A, const float* 
     return E.test_gemm3(ST(stream), A, W, bias, M, N, K, act, split, cfg, C);
 }
 int smtts_test_set_fused_ffn(smtts_handle h, int on) { NULLCHK; E.set_fused_ffn(on != 0); return 0; }
-int smtts_test_set_attention_mfma(smtts_handle h, int mode) { NULLCHK;   // 0: fp32 VALU kernel, 1: matrix cores with q / k prep fused (default), 2: matrix cores after a separate qk_prep launch
-    E.set_attn_mfma((mode & 3) != 0);
-    if ((mode & 3) == 3) E.reset_attn_prep_fused();   // 3: matrix cores, prep placement back to the engine default
-    else E.set_attn_prep_fused((mode & 3) != 2);
-    g_attn_resident = (mode & 4) ? 0 : 1;   // + 4: streaming form only (process-wide switch; the resident-K/V form is the default where it applies)
-    E.set_attn_img((mode & 8) == 0);        // + 8: the round-2 kernels selected by the low bits; without it (default) the DMA + MFMA kernel on producer-written images
+int smtts_test_set_attention_mfma(smtts_handle h, int mode) { NULLCHK;   // 0: fp32 projection + qk_prep + the fp32 VALU reference kernel; else (default): producer-written operand images + the DMA / MFMA kernel
+    E.set_attn_img(mode != 0);
     return 0;
 }
 
@@ -205,7 +201,7 @@ int smtts_test_attention_mfma(smtts_handle h, void* stream, const float* qkvg, c
                               const float* rope, int rot_dim, const float* k_ref, const float* v_ref, int R,
                               const float* k_text, const float* v_text, int P, const uint8_t* mask_self,
                               const uint8_t* mask_ref, const uint8_t* mask_text, int B, int N, int H, int dh, float* out) { NULLCHK;
-    if (E.attn_img()) {
+    {
         // round-3 path: stand-alone producer (qkv_pack + cross_pack, L = 1) then the DMA + MFMA kernel, at the SITE_ATTN precision
         const int D = H * dh, dhp = dh <= 64 ? 64 : 128, Np = pad8(N), Rp = pad8(R > 0 ? R : 0), Cp = Rp + pad8(P > 0 ? P : 0);
         const int pa = E.site_precision(Engine::SITE_ATTN);
@@ -247,32 +243,6 @@ int smtts_test_attention_mfma(smtts_handle h, void* stream, const float* qkvg, c
         (void)hipFree(img); (void)hipFree(rc); (void)hipFree(rs); (void)hipFree(ob);
         return e == hipSuccess ? 0 : E.fail_hip(e, "attention_img");
     }
-    AttnArgs a{};
-    const int D = H * dh;
-    float *tmp = nullptr, *rc = nullptr, *rs = nullptr;
-    const size_t nq = (size_t)B * N * 4 * D;
-    const int nr = N * rot_dim;
-    if (hipMalloc(&tmp, nq * 4) != hipSuccess || hipMalloc(&rc, (size_t)nr * 4) != hipSuccess ||
-        hipMalloc(&rs, (size_t)nr * 4) != hipSuccess)
-        return E.fail("test_attention_mfma: alloc failed");
-    (void)hipMemcpyAsync(tmp, qkvg, nq * 4, hipMemcpyDeviceToDevice, ST(stream));  // qk_prep works in place
-    (void)launch_rope_cossin(rope, rc, rs, nr, ST(stream));
-    const bool fused = E.attn_prep_fused();   // fused prep reads the caller's buffer as it is
-    const float* src = fused ? qkvg : tmp;
-    a.q = src; a.k = src + D; a.v = src + 2 * D; a.gate = src + 3 * D;
-    a.bs = (long)N * 4 * D; a.rs = 4 * D;
-    a.qw = qw; a.kw = kw; a.eps = eps; a.rope_cos = rc; a.rope_sin = rs; a.rot_dim = rot_dim;
-    a.k_ref = R > 0 ? k_ref : nullptr; a.v_ref = v_ref; a.R = R;
-    a.k_text = P > 0 ? k_text : nullptr; a.v_text = v_text; a.P = P;
-    a.mask_self = mask_self; a.mask_ref = mask_ref; a.mask_text = mask_text;
-    a.out = out; a.obs = (long)N * D; a.ors = D;
-    a.B = B; a.N = N; a.H = H; a.dh = dh;
-    a.prenormed = fused ? 0 : 1;
-    hipError_t e = fused ? hipSuccess : launch_qk_prep(a, ST(stream));
-    if (e == hipSuccess) e = launch_attention_mfma(a, ST(stream));
-    (void)hipStreamSynchronize(ST(stream));
-    (void)hipFree(tmp); (void)hipFree(rc); (void)hipFree(rs);
-    return e == hipSuccess ? 0 : E.fail_hip(e, "attention_mfma");
 }
 
 }  // extern "C"

@@ -249,18 +249,31 @@ struct QkPrep {
     const float *rope_cos, *rope_sin;
     int rot_dim, dh;
     float eps, scale;      // scale: 1/sqrt(dh) for q, 1 for k
-    __device__ __forceinline__ void apply(float& x0, float& x1, float ss, int h, int d, int n) const {
-        const float rstd = __builtin_amdgcn_rsqf(fmaf(ss, 1.0f / (float)dh, eps));
+    // the loads of one pair, separated from the arithmetic so that a caller can issue them for all its rows first
+    __device__ __forceinline__ void weights(int h, int d, float& w0, float& w1) const {
         const bool in = d < dh;
-        const float w0 = in ? w[h * dh + d] : 0.f, w1 = in ? w[h * dh + d + 1] : 0.f;
+        w0 = in ? w[h * dh + d] : 0.f;
+        w1 = in ? w[h * dh + d + 1] : 0.f;
+    }
+    __device__ __forceinline__ void rope(int d, int n, float& c, float& s) const {
+        c = 1.f; s = 0.f;
+        if (d < rot_dim) { c = rope_cos[(long)n * rot_dim + d]; s = rope_sin[(long)n * rot_dim + d]; }
+    }
+    __device__ __forceinline__ void math(float& x0, float& x1, float ss, float w0, float w1, float c, float s, int d) const {
+        const float rstd = __builtin_amdgcn_rsqf(fmaf(ss, 1.0f / (float)dh, eps));
         x0 = (x0 * rstd) * w0;
         x1 = (x1 * rstd) * w1;
         if (d < rot_dim) {
-            const float c = rope_cos[(long)n * rot_dim + d], s = rope_sin[(long)n * rot_dim + d];
             const float a0 = fmaf(x0, c, -(x1 * s)), a1 = fmaf(x1, c, x0 * s);
             x0 = a0; x1 = a1;
         }
         x0 *= scale; x1 *= scale;
+    }
+    __device__ __forceinline__ void apply(float& x0, float& x1, float ss, int h, int d, int n) const {
+        float w0, w1, c, s;
+        weights(h, d, w0, w1);
+        rope(d, n, c, s);
+        math(x0, x1, ss, w0, w1, c, s, d);
     }
 };
 

@@ -28,8 +28,10 @@ inline std::string sidx(const std::string& a, int i, const std::string& b) { ret
 }  // namespace
 
 int g_gemm3_t160 = 1;   // gemm3 160x128 tiles for M = 600 x wide N (SMTTS_GEMM_T160=0: off)
-int g_gemm3_deep = 1;   // gemm3 ring depth for single-array operand formats: 1 = deep (latency tuning), 0 = shallow (throughput tuning)
-int g_gemm3_w4_minm = 2048;  // gemm3: 4-wave 128x128 tiles (wave 64x64) for single-array products with M >= this and N >= 2048 (SMTTS_GEMM_W4_MINM; 0 = off)
+thread_local int g_gemm3_deep = 1;   // gemm3 ring depth for single-array operand formats: 1 = deep (latency tuning), 0 = shallow (throughput tuning);
+                                      // thread-local, installed from the calling Engine for the duration of each operator call (DeepScope)
+namespace { struct DeepScope { int prev; explicit DeepScope(int v) : prev(g_gemm3_deep) { g_gemm3_deep = v; } ~DeepScope() { g_gemm3_deep = prev; } }; }
+int g_gemm3_w4_minm = 0;  // gemm3: 4-wave 128x128 tiles (wave 64x64) for single-array products with M >= this and N >= 2048 (SMTTS_GEMM_W4_MINM; 0 = off)
 int g_gemm3_stage16 = 1;  // gemm3: 16-bit outputs through the LDS-staged epilogue (SMTTS_GEMM_STAGE16=0: scalar stores)
 int g_gemm3_nfast = 1;  // gemm3 tile order: N fastest when M > N (SMTTS_GEMM_NFAST=0 restores M fastest everywhere)
 thread_local Profiler* g_prof = nullptr;
@@ -40,7 +42,7 @@ static int g_small_m_splitk = 1;   // SMTTS_SMALLM_SPLITK=0: A/B switch for the 
 Engine::Engine(int device) : device_(device) {
     set_precision(kDefaultPrecision);
     if (const char* nf = getenv("SMTTS_GEMM_NFAST")) g_gemm3_nfast = atoi(nf);
-    if (const char* dp = getenv("SMTTS_GEMM_DEEP")) g_gemm3_deep = atoi(dp);
+    if (const char* dp = getenv("SMTTS_GEMM_DEEP")) gemm_deep_ = atoi(dp);
     if (const char* s16 = getenv("SMTTS_GEMM_STAGE16")) g_gemm3_stage16 = atoi(s16);
     if (const char* w4 = getenv("SMTTS_GEMM_W4_MINM")) g_gemm3_w4_minm = atoi(w4);
     if (const char* t1 = getenv("SMTTS_GEMM_T160")) g_gemm3_t160 = atoi(t1);
@@ -48,11 +50,9 @@ Engine::Engine(int device) : device_(device) {
     if (s && *s == '1') dual_stream_ = false;
     if ((s = getenv("SMTTS_BLOCK_WAVE"))) block_wave_ = atoi(s) != 0;
     if ((s = getenv("SMTTS_SMALLM_SPLITK"))) g_small_m_splitk = atoi(s);
-    if ((s = getenv("SMTTS_ATTN_RES"))) g_attn_resident = atoi(s);
     if ((s = getenv("SMTTS_CONVPOS_BY_GROUP"))) convpos_by_group_ = atoi(s) != 0;
     if ((s = getenv("SMTTS_ATTN_EPI"))) attn_epi_ = atoi(s) != 0;
     if ((s = getenv("SMTTS_ATTN_IMG"))) attn_img_ = atoi(s) != 0;
-    if ((s = getenv("SMTTS_ATTN_PREP"))) attn_prep_fused_ = atoi(s);   // 0: separate qk_prep launch, 1: fused up to one workgroup per CU, 2: always fused
     if ((s = getenv("SMTTS_UP_G3_MINK")) && atoi(s) >= 64) up_g3_mink_ = atoi(s);
     if ((s = getenv("SMTTS_KSPLIT_OUT")) && atoi(s) >= 1 && atoi(s) <= kSplitK) ksplit_out_ = atoi(s);
     if ((s = getenv("SMTTS_KSPLIT_ENC")) && atoi(s) >= 1 && atoi(s) <= kSplitK) ksplit_enc_ = atoi(s);
@@ -62,16 +62,15 @@ Engine::Engine(int device) : device_(device) {
 }
 
 void Engine::set_tuning(int mode) {
-    extern int g_gemm3_deep;
     if (mode == TUNE_THROUGHPUT) {
         if (tuning_ != TUNE_THROUGHPUT) dual_stream_latency_ = dual_stream_;
         tuning_ = TUNE_THROUGHPUT;
         dual_stream_ = false;
-        g_gemm3_deep = 0;
+        gemm_deep_ = 0;
     } else {
         if (tuning_ == TUNE_THROUGHPUT) dual_stream_ = dual_stream_latency_;
         tuning_ = TUNE_LATENCY;
-        g_gemm3_deep = getenv("SMTTS_GEMM_DEEP") ? atoi(getenv("SMTTS_GEMM_DEEP")) : 1;
+        gemm_deep_ = getenv("SMTTS_GEMM_DEEP") ? atoi(getenv("SMTTS_GEMM_DEEP")) : 1;
     }
 }
 
@@ -821,13 +820,9 @@ int Engine::run_encoder(hipStream_t st, const EncoderW& e, void* wsv, int B, int
             ai.B = B; ai.N = S; ai.H = e.heads; ai.dh = e.dh; ai.Np = Sp;
             HIPC(launch_attention_img(ai, st));
         } else {
-        a.prenormed = !attn_fuse_prep(a);   // fused: the matrix-core kernel normalises + rotates q / k while staging
-        if (a.prenormed) HIPC(launch_qk_prep(a, st));
-        static char* dbg_dump = getenv("SMTTS_DBG_ATTN_PTR") ? reinterpret_cast<char*>(strtoull(getenv("SMTTS_DBG_ATTN_PTR"), nullptr, 0)) : nullptr;
-        char* dd = dbg_dump && &e == &style_ ? dbg_dump + l * ((size_t)M * 4 * D * 4 + (size_t)M * D * 2) : nullptr;
-        if (dd) HIPC(hipMemcpyAsync(dd, w.qkvg, (size_t)M * 4 * D * 4, hipMemcpyDeviceToDevice, st));   // r03 debug: attention inputs as the kernel sees them
-        HIPC(attn_mfma_ ? launch_attention_mfma(a, st) : launch_attention(a, st));
-        if (dd) HIPC(hipMemcpyAsync(dd + (size_t)M * 4 * D * 4, o.hi, (size_t)M * D * 2, hipMemcpyDeviceToDevice, st));   // ... and its output
+            a.prenormed = 1;
+            HIPC(launch_qk_prep(a, st));
+            HIPC(launch_attention(a, st));
         }
         EpiResid<0> r1{w.x, rd, nullptr, nullptr, 0, 0, 0, 1, nullptr};
         NextLN n1{b.mn, nullptr, y.hi, y.lo, true, e.eps};
@@ -875,6 +870,7 @@ int Engine::ensure_aux() {
 int Engine::cond_encode(hipStream_t st, const float* ref, const int64_t* ref_len, const int64_t* ids,
                         const uint8_t* ph_mask, int B, int R, int P, float* k_ref, float* v_ref, uint8_t* ref_mask,
                         float* k_text, float* v_text, void* ws, size_t ws_bytes, float* ref_seq_out, float* mem_out) {
+    DeepScope deep_scope(gemm_deep_);
     ProfTag ptag("enc");
     if (!dit_ready_) return fail("cond_encode: DiT weights not finalized");
     if (R > kMaxPos || P > kMaxPos) return fail("cond_encode: sequence longer than the rope table (4096)");
@@ -995,16 +991,6 @@ struct CoreWs {
     }
 };
 }  // namespace
-
-// q / k prep inside attention_mfma pays while the attention grid is at most one workgroup per CU (B = 8: 192 workgroups, 26.5 ->
-// 21.0 us per block); the fused kernel holds 322 VGPRs, so a grid of several rounds (the teacher's 3B-row CFG batches: 576
-// workgroups) loses the second resident workgroup per CU and the separate qk_prep launch wins (128-step teacher 257 vs 269 ms)
-bool Engine::attn_fuse_prep(const AttnArgs& a) const {
-    if (!attn_mfma_ || !attn_prep_fused_) return false;
-    if (attention_mfma_resident(a)) return true;   // keys are prepared once per (batch, head) there: no redundancy to weigh
-    const long wgs = (long)((a.N + 31) / 32) * a.H * a.B;
-    return attn_prep_fused_ > 1 || wgs <= num_cus_;
-}
 
 size_t Engine::denoise_core_bytes(int B, int N) const {
     Bump b(nullptr);
@@ -1130,9 +1116,9 @@ int Engine::denoise_core(hipStream_t st, const float* x_t, const uint8_t* mask, 
             ai.B = B; ai.N = N; ai.H = kHeads; ai.dh = kDh; ai.Np = Np; ai.R = R; ai.P = P; ai.Rp = ci.Rp; ai.Cp = ci.Cp;
             HIPC(launch_attention_img(ai, st));
         } else {
-            a.prenormed = !attn_fuse_prep(a);   // fused: the matrix-core kernel normalises + rotates q / k while staging
-            if (a.prenormed) HIPC(launch_qk_prep(a, st));
-            HIPC(attn_mfma_ ? launch_attention_mfma(a, st) : launch_attention(a, st));
+            a.prenormed = 1;
+            HIPC(launch_qk_prep(a, st));
+            HIPC(launch_attention(a, st));
         }
         // to_out + mask + gated residual (dit.py:117-118,198), then the MLP AdaLN (dit.py:199)
         EpiResid<0> r1{w.x, rh, nullptr, m + 2 * kHidden, kModLd, mod_row0, mod_rstride, N, mask};
@@ -1206,6 +1192,7 @@ int Engine::denoise_step(hipStream_t st, const float* x_t, const uint8_t* mask, 
                          const float* v_ref, const uint8_t* ref_mask, const float* k_text, const float* v_text,
                          const uint8_t* ph_mask, const float* rope, int B, int N, int R, int P, float* velocity,
                          void* ws, size_t ws_bytes) {
+    DeepScope deep_scope(gemm_deep_);
     if (!dit_ready_) return fail("denoise_step: DiT weights not finalized");
     if (N > kMaxPos) return fail("denoise_step: sequence longer than the rope table (4096)");
     if (ws_bytes < denoise_ws_bytes(B, N, R, P, B)) return fail("denoise_step: workspace too small");
@@ -1273,6 +1260,7 @@ int Engine::sample(hipStream_t st, int mode, int n_steps, int cfg, float s_text,
                    const float* k_ref, const float* v_ref, const uint8_t* ref_mask, const float* k_text,
                    const float* v_text, const uint8_t* ph_mask, int B, int N, int R, int P, const float* noise,
                    uint64_t seed, float* x_out, float* steps_out, void* ws, size_t ws_bytes) {
+    DeepScope deep_scope(gemm_deep_);
     if (!dit_ready_) return fail("sample: DiT weights not finalized");
     if (n_steps < 1) return fail("sample: n_steps must be >= 1");
     if (N > kMaxPos) return fail("sample: sequence longer than the rope table (4096)");
@@ -1481,6 +1469,7 @@ size_t Engine::decode_ws_bytes(int B, int T) const {
 }
 
 int Engine::codec_decode(hipStream_t st, const float* latents, int B, int T, float* audio, void* ws, size_t ws_bytes) {
+    DeepScope deep_scope(gemm_deep_);
     if (!dec_.ready) return fail("codec_decode: decoder weights not finalized");
     if (ws_bytes < decode_ws_bytes(B, T)) return fail("codec_decode: workspace too small");
     HIPC(hipSetDevice(device_));
@@ -1580,6 +1569,7 @@ size_t Engine::encode_ws_bytes(int B, int S_) const {
 }
 
 int Engine::codec_encode(hipStream_t st, const float* audio, int B, int S_, float* latents, void* ws, size_t ws_bytes) {
+    DeepScope deep_scope(gemm_deep_);
     if (!enc_.ready) return fail("codec_encode: encoder weights not finalized");
     if (ws_bytes < encode_ws_bytes(B, S_)) return fail("codec_encode: workspace too small");
     HIPC(hipSetDevice(device_));
@@ -1666,6 +1656,7 @@ int Engine::codec_encode(hipStream_t st, const float* audio, int B, int S_, floa
 // ---------------------------------------------------------------------------------------------
 int Engine::test_gemm(hipStream_t st, const float* A, int lda, const float* W, const float* bias, int M, int N, int K,
                       int act, int split, int cfg, float* C, int ldc) {
+    DeepScope deep_scope(gemm_deep_);
     HIPC(hipSetDevice(device_));
     bf16_t *hi = nullptr, *lo = nullptr;
     HIPC(hipMalloc(&hi, (size_t)N * K * 2));
@@ -1682,6 +1673,7 @@ int Engine::test_gemm(hipStream_t st, const float* A, int lda, const float* W, c
 
 int Engine::test_gemm3(hipStream_t st, const float* A, const float* W, const float* bias, int M, int N, int K, int act,
                        int split, int cfg, float* C) {
+    DeepScope deep_scope(gemm_deep_);
     HIPC(hipSetDevice(device_));
     bf16_t *hi = nullptr, *lo = nullptr, *ahi = nullptr, *alo = nullptr;
     HIPC(hipMalloc(&hi, (size_t)N * K * 2));
@@ -1702,6 +1694,7 @@ int Engine::test_gemm3(hipStream_t st, const float* A, const float* W, const flo
 
 int Engine::test_swiglu(hipStream_t st, const float* A, const float* W1, const float* W3, const float* b1,
                         const float* b3, int M, int F, int K, int split, float* out) {
+    DeepScope deep_scope(gemm_deep_);
     HIPC(hipSetDevice(device_));
     if (F % 32) return fail("test_swiglu: F must be a multiple of 32");
     float* cat = nullptr;
@@ -1727,6 +1720,7 @@ int Engine::test_swiglu(hipStream_t st, const float* A, const float* W1, const f
 
 // epi: 0 store, 1 store+gelu, 2 swiglu (N = packed 2F), 3 resid tanh-gate
 int Engine::bench_gemm(int M, int N, int K, int epi, int split, int cfg, int iters, int ver, float* avg_us) {
+    DeepScope deep_scope(gemm_deep_);
     HIPC(hipSetDevice(device_));
     float *A = nullptr, *Wf = nullptr, *C = nullptr, *bias = nullptr, *gate = nullptr;
     bf16_t *hi = nullptr, *lo = nullptr, *ahi = nullptr, *alo = nullptr;
@@ -1756,6 +1750,11 @@ int Engine::bench_gemm(int M, int N, int K, int epi, int split, int cfg, int ite
                 case 0: return gemm3_store(g3, ACT_NONE, store_to(C, rowmap_plain(N), bias), 1, split, 0, cfg);
                 case 1: return gemm3_store(g3, ACT_GELU, store_to(C, rowmap_plain(N), bias), 1, split, 0, cfg);
                 case 2: { EpiSwiGLU sw{C, N / 2, bias, bias, nullptr, nullptr}; return gemm3_swiglu(g3, sw, split, 0); }
+                case 4: {   // GELU hidden written as ONE 16-bit operand array (the codec's first FFN product): C is reused as that array
+                    EpiStore<ACT_NONE> e{nullptr, rowmap_plain(N), 0, bias, 0, 1.f, nullptr, reinterpret_cast<bf16_t*>(C), sm_lo_for(split == PREC_BF16X3 ? PREC_F16 : split, nullptr)};
+                    return gemm3_store(g3, ACT_GELU, e, 1, split, 0, cfg);
+                }
+                case 5: { EpiResid<0> r{C, rowmap_plain(N), bias, gate, 0, 0, 0, M, nullptr}; return gemm3_resid(g3, 2, r, split, 0, cfg); }   // LayerScale residual (codec FF2)
                 default: { EpiResid<0> r{C, rowmap_plain(N), bias, gate, 0, 0, 0, M, nullptr}; return gemm3_resid(g3, 1, r, split, 0, cfg); }
             }
         }

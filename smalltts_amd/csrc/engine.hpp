@@ -130,13 +130,9 @@ class Engine {
     void set_tuning(int mode);
     int tuning() const { return tuning_; }
     void set_fused_ffn(bool on) { fused_ffn_ = on; }
-    void set_attn_mfma(bool on) { attn_mfma_ = on; }
     void set_attn_img(bool on) { attn_img_ = on; }
     bool attn_img() const { return attn_img_; }
     int site_precision(int site) const { return site >= 0 && site < SITE_COUNT ? prec_[site] : 0; }
-    void set_attn_prep_fused(bool on) { attn_prep_fused_ = on ? 2 : 0; }   // (test hook: the kernel test wants the asked-for variant at any grid)
-    bool attn_prep_fused() const { return attn_prep_fused_ != 0; }
-    void reset_attn_prep_fused() { const char* s = getenv("SMTTS_ATTN_PREP"); attn_prep_fused_ = s ? atoi(s) : 0; }
     void set_dual_stream(bool on) { dual_stream_ = on; }
     int precision() const { return preset_; }
 
@@ -223,6 +219,7 @@ class Engine {
     std::vector<void*> pack_allocs_;  // everything finalize() builds: freed and rebuilt by the next finalize()
     bool packing_ = false;
     int tuning_ = TUNE_LATENCY;
+    int gemm_deep_ = 1;   // gemm3 ring depth of this engine's launches (1 deep: latency tuning, 0 shallow: throughput); installed per operator call (DeepScope)
     bool dual_stream_latency_ = true;  // the dual-stream setting that TUNE_LATENCY restores
     int preset_ = kDefaultPrecision;   // set_precision(kDefaultPrecision) in the constructor fills prec_
     int prec_[SITE_COUNT] = {3, 3, 3, 3, 3, 3, 3, 3};
@@ -235,17 +232,9 @@ class Engine {
     hipStream_t aux_ = nullptr;
     hipEvent_t ev_fork_ = nullptr, ev_join_ = nullptr;
     int ensure_aux();
-    // q / k head-norm + RoPE inside attention_mfma's staging: 1 = when the grid is <= one workgroup per CU, 2 = always, 0 = separate
-    // qk_prep launch (in place).  DEFAULT 0: the fused kernels are faster (26.5 -> 21.0 us per DiT block) and bit-exact alone, but
-    // with other HIP streams active (dual-stream encoders, batches in flight) their results stopped repeating bit for bit —
-    // whole utterances off by ~5e-2 in the style encoder, 23 of 24 in-flight rounds different (tools/stress_determinism.py,
-    // profiles/r02bl_*).  Neither the kernel alone nor two of them side by side reproduce it; the separate launch never showed it.
-    int attn_prep_fused_ = 0;
     int num_cus_ = 256;
     bool convpos_by_group_ = true;  // grouped conv pos-embed as one product per group over the batch's rows (false: per (utterance, group))
-    bool attn_fuse_prep(const struct AttnArgs& a) const;
-    bool attn_mfma_ = true;  // matrix-core attention (attention_mfma.hip); false = fp32 VALU kernel (attention.hip)
-    bool attn_img_ = true;   // attention on producer-written operand images (attention_img.hip: DMA + MFMA only); false = the round-2 kernels above
+    bool attn_img_ = true;   // attention on producer-written operand images (attention_img.hip: DMA + MFMA only); false (SMTTS_ATTN_IMG=0, test hook) = fp32 projection + qk_prep + the fp32 VALU reference kernel (attention.hip)
     bool attn_epi_ = true;   // ... written by the QKVG GEMM's own epilogue (gemm3 EpiQKV); false (SMTTS_ATTN_EPI=0): fp32 projection + qkv_pack kernel
     Profiler prof_;
     bool prof_on_ = false;

@@ -539,22 +539,49 @@ struct EpiQKV {
                     }
                 }
             } else {
+                // the wave's 64 / NW rows as independent chains: every load (LDS tile, rope table) is issued before the first
+                // reduction, the reductions interleave, then the stores — not one global round trip per row
+                constexpr int RPW = 64 / NW;
                 const int c0 = 2 * lane, h = h0 + c0 / HW, d = c0 % HW;
-                for (int r = wave; r < 64; r += NW) {
-                    const int m = mh + r;
-                    if (m >= M) break;             // (uniform)
+                float x0[RPW], x1[RPW], cs[RPW], sn[RPW];
+                long mrow[RPW], nrow[RPW];
+                const QkPrep pp{part ? kw : qw, rope_cos, rope_sin, rot_dim, dh, eps, part ? 1.0f : q_scale};
+                float w0 = 0.f, w1 = 0.f;
+                if (part < 2) pp.weights(h, d, w0, w1);
+#pragma unroll
+                for (int i = 0; i < RPW; ++i) {
+                    const int r = wave + i * NW;
+                    int m = mh + r;
+                    m = m < M ? m : M - 1;         // rows past the end: computed on a valid row, not stored
                     const int b = m / Nseq, n = m - b * Nseq;
-                    float x0 = tile[r * TP + c0], x1 = tile[r * TP + c0 + 1];
-                    if (part == 3) {
-                        if (d < dh) store_img2(g, g_lo, prec, (long)m * ((long)H * dh) + h * dh + d, sigmoid_f(x0), sigmoid_f(x1));
-                    } else {
-                        float ss = fmaf(x1, x1, x0 * x0);
-                        ss = HW == 64 ? group_sum<32>(ss) : wave_sum(ss);
-                        const QkPrep pp{part ? kw : qw, rope_cos, rope_sin, rot_dim, dh, eps, part ? 1.0f : q_scale};
-                        pp.apply(x0, x1, ss, h, d, n);
-                        const long off = (((long)b * H + h) * Nseq + n) * HW + d;
-                        if (part) store_img2(k, k_lo, prec, off, x0, x1);
-                        else store_img2(q, q_lo, prec, off, x0, x1);
+                    mrow[i] = m;
+                    nrow[i] = ((long)b * H + h) * Nseq + n;
+                    x0[i] = tile[r * TP + c0]; x1[i] = tile[r * TP + c0 + 1];
+                    cs[i] = 1.f; sn[i] = 0.f;
+                    if (part < 2) pp.rope(d, n, cs[i], sn[i]);
+                }
+                if (part == 3) {
+#pragma unroll
+                    for (int i = 0; i < RPW; ++i)
+                        if (mh + wave + i * NW < M && d < dh)
+                            store_img2(g, g_lo, prec, mrow[i] * ((long)H * dh) + h * dh + d, sigmoid_f(x0[i]), sigmoid_f(x1[i]));
+                } else {
+                    float ss[RPW];
+#pragma unroll
+                    for (int i = 0; i < RPW; ++i) ss[i] = fmaf(x1[i], x1[i], x0[i] * x0[i]);
+#pragma unroll
+                    for (int o = 32; o > 0; o >>= 1) {   // (HW == 64: two heads per wave, the sum stays inside 32 lanes)
+                        if (HW == 64 && o == 32) continue;
+#pragma unroll
+                        for (int i = 0; i < RPW; ++i) ss[i] += __shfl_xor(ss[i], o, 64);
+                    }
+#pragma unroll
+                    for (int i = 0; i < RPW; ++i) {
+                        pp.math(x0[i], x1[i], ss[i], w0, w1, cs[i], sn[i], d);
+                        if (mh + wave + i * NW < M) {
+                            if (part) store_img2(k, k_lo, prec, nrow[i] * HW + d, x0[i], x1[i]);
+                            else store_img2(q, q_lo, prec, nrow[i] * HW + d, x0[i], x1[i]);
+                        }
                     }
                 }
             }

@@ -277,9 +277,12 @@ enum Gemm3Cfg {
 
 static inline int gemm3_pick_cfg(int M, int N, bool paired, bool single = false /* one array per operand (fp16 / bf16) */) {
     extern int g_gemm3_w4_minm;   // single-array formats: 128x128 with four 64x64 waves from this M up (0 = never); split-bf16 falls back
-    // measured (profiles/r02k_ab_keepx_w4.txt): the wide, short-K first FFN product of the codec's GEMM stages gains (24000 x 2048 x 512:
-    // 122 -> 98 us, 4800 x 4096 x 1024: 86 -> 72 us), the narrow long-K second product loses (94 -> 102, 64 -> 81 us) -> wide N only
+    // round 2 (profiles/r02k_ab_keepx_w4.txt) took the 4-wave tile for the wide, short-K first FFN product of the codec's GEMM stages
+    // (24000 x 2048 x 512: 122 -> 98 us); with the LDS-staged 16-bit epilogue the 8-wave 128x128 tile now beats it on those very
+    // shapes (round 3, profiles/r03j_gemm_codec_tile_sweep.txt: 101 vs 90 us, 4800 x 4096 x 1024: 69 vs 62 us) -> off by default
+    // (SMTTS_GEMM_W4_MINM=<M> switches it back on); 256x256 and 256x128 tiles were measured there too and bought nothing.
     if (g_gemm3_w4_minm > 0 && M >= g_gemm3_w4_minm && N >= 2048) return G3_128x128_W4;
+    if (single && !paired && M >= 2048 && N >= 2048) return G3_128x128;
     if (paired) {
         // the SwiGLU pair epilogue needs 32x64 wave tiles: 128x128 or 160x128.  Single-array formats run two such workgroups per
         // CU, so 512 tiles are one round: the teacher's 1800 x 4800 FF1 is 570 tiles of 128x128 (two rounds) but 456 of 160x128
@@ -331,7 +334,7 @@ static inline bool gemm3_ok(const Gemm3Operands& g) {
 // it waits on memory keeps the other streams' kernels off its CU.  Hence a run-time choice: g_gemm3_deep (Engine tuning mode).
 template <int SPLIT, class Epi>
 static inline hipError_t gemm3_launch_split(const Gemm3Operands& g, const Epi& epi, int Z, int cfg, hipStream_t st) {
-    extern int g_gemm3_deep;
+    extern thread_local int g_gemm3_deep;
     if constexpr (SPLIT != 3) {
         // deep rings pay when the whole grid is resident at once (one latency-bound round); a grid of several rounds at the deep
         // ring's occupancy runs faster shallow with more workgroups per CU (teacher QKVG, 450 tiles of 128x128: 35.1 us deep — two

@@ -1,4 +1,6 @@
 // QKVG projection with the attention-operand epilogue (gemm.hpp EpiQKV): 128-column tiles = whole (padded) heads.
+#include <cstdlib>
+
 #include "gemm_ops.hpp"
 #include "prof.hpp"
 
@@ -17,10 +19,12 @@ hipError_t gemm3_qkv(const Gemm3Operands& g_in, const EpiQKV& p, int split, hipS
     if (!gemm3_ok(g_in) || g_in.N != 4 * p.H * p.HW || (p.HW != 64 && p.HW != 128) || (p.dh & 1) || p.dh > p.HW || (p.rot_dim & 1) ||
         p.rot_dim > p.dh || (g_in.N % 128))
         return hipErrorInvalidValue;
-    extern int g_gemm3_deep, g_gemm3_nfast;
+    extern thread_local int g_gemm3_deep;
+    extern int g_gemm3_nfast;
     Gemm3Operands g = g_in;
     g.nfast = g_gemm3_nfast && (long)g.M > (long)g.N;
-    const bool big = g.M > 640;
+    static const int big_minm = getenv("SMTTS_QKV_BIG_MINM") ? atoi(getenv("SMTTS_QKV_BIG_MINM")) : 641;   // A/B: 128x128 tiles from this many rows up
+    const bool big = g.M >= big_minm;
     const long tiles = (long)((g.M + (big ? 127 : 63)) / (big ? 128 : 64)) * (g.N / 128);
     const bool deep = g_gemm3_deep && split != PREC_BF16X3 && tiles <= 256;   // deep rings only while the grid is one resident round (gemm3_launch_split)
     ProfScope ps(st, gemm3_prof_name(g, false, big ? G3_128x128 : G3_64x128, split, "qkv_img"), 2.0 * g.M * (double)g.N * g.K,

@@ -37,19 +37,13 @@ struct AttnArgs {
     const uint8_t* mask_self;  // [B][N]  key validity (may be null = all valid)
     const uint8_t* mask_ref;   // [B][R]
     const uint8_t* mask_text;  // [B][P]
-    int prenormed;      // 1: q and k were already RMS-normalised + rotated in place by launch_qk_prep
+    int prenormed;      // 1: q and k were already RMS-normalised + rotated in place by launch_qk_prep (0: the kernel does it on the fly)
     float* out; long obs, ors;  // out (b, n, h*dh + d)
     bf16_t* out_hi; bf16_t* out_lo;  // when out_hi != null the result is written as a split bf16 pair instead
     int B, N, H, dh;
-    int dbg_lds_bytes;  // (r03 debug builds only)
 };
+// fp32 VALU attention (attention.hip): the A/B reference of the DMA + MFMA kernel below (test hook, SMTTS_ATTN_IMG=0)
 hipError_t launch_attention(const AttnArgs& a, hipStream_t st);
-// Matrix-core variant (attention_mfma.hip): same arguments, needs prenormed = 1.
-hipError_t launch_attention_mfma(const AttnArgs& a, hipStream_t st);
-// true when launch_attention_mfma will take its resident-K/V form for these arguments (one workgroup per (batch, head), every key
-// staged and prepared once): the q / k prep is then always worth fusing
-bool attention_mfma_resident(const AttnArgs& a);
-extern int g_attn_resident;
 // In place on the packed projection buffer: q <- RoPE(RMSNorm_head(q) * qw), k <- RoPE(RMSNorm_head(k) * kw)
 // (dit.py:95-108); one wave per (row, head, q|k).  Uses the q/k/bs/rs/qw/kw/eps/rope/rot_dim/B/N/H/dh fields.
 hipError_t launch_qk_prep(const AttnArgs& a, hipStream_t st);

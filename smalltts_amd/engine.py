@@ -379,22 +379,13 @@ class HipEngine:
         P = 0 if k_text is None else k_text.shape[2]
         out = torch.empty(B, N, H * dh, device=self.device)
         fn = self.lib.smtts_test_attention_mfma if mfma else self.lib.smtts_test_attention
-        if mfma:
-            # "img" / "img:f16" / "img:bf16x3": the DMA + MFMA kernel on producer-written operand images (the engine default) at
-            # that operand precision.  Round-2 kernels: True / "fused": q / k prep inside the matrix-core kernel; "prep": separate
-            # qk_prep launch; a "+stream" suffix keeps their streaming form where the resident-K/V form would apply
+        if mfma:   # "img" / "img:f16" / "img:bf16x3" / "img:bf16": the product's DMA + MFMA kernel on operand images at that precision
             s = str(mfma)
-            if s.startswith("img"):
-                mode = 3
-                self._ck(self.lib.smtts_set_site_precision(self.h, SITES["attn"], PRECISION[s.split(":")[1] if ":" in s else "bf16x3"]),
-                         "set_site_precision")
-            else:
-                mode = 8 + (2 if s.startswith("prep") else 1) + (4 if s.endswith("+stream") else 0)
-            self._ck(self.lib.smtts_test_set_attention_mfma(self.h, mode), "set_attention_mfma")
+            self._ck(self.lib.smtts_set_site_precision(self.h, SITES["attn"], PRECISION[s.split(":")[1] if ":" in s else "bf16x3"]),
+                     "set_site_precision")
         self._ck(fn(self.h, self._stream(), _p(qkvg), _p(qw), _p(kw), eps, _p(rope), rot_dim,
                                                _p(k_ref), _p(v_ref), R, _p(k_text), _p(v_text), P, _p(mask_self),
                                                _p(mask_ref), _p(mask_text), B, N, H, dh, _p(out)), "test_attention")
         if mfma:
-            self._ck(self.lib.smtts_test_set_attention_mfma(self.h, 3), "set_attention_mfma")
             self.set_precision(self.precision)
         return out

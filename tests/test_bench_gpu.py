@@ -33,7 +33,11 @@ def test_bench_single_gpu_line_has_the_contract_fields_and_rooflines():
     assert r["unit"] == "audio-seconds/sec" and r["value"] > 100 and r["value_sequential"] > 100 and r["vs_baseline"] is None
     assert abs(r["value"] - 80.0 / (r["ms_per_step"] * 1e-3)) / r["value"] < 1e-3        # 8 x 10 s per step
     assert r["config"]["workload"].startswith("cond-encode + 4-step DMD sampler + codec decode") and "model" not in r["config"]
+    # the K-step region is repeated until >= 2 s have been timed; value / ms_per_step are the median repeat
+    assert r["timed_seconds"] >= 2.0 and r["repeats"] >= 2 and r["ms_per_step_min"] <= r["ms_per_step"] <= r["ms_per_step_max"]
+    assert r["dist"] == {"backend": None, "collective": False, "world": 1}
     rf = r["roofline"]
+    assert 1 <= len(rf["by_shape"]) <= 3 and all(t["avg_us"] > 0 and 0 < t["mfma_frac"] < 1 and "x" in t["MxNxK"] for t in rf["by_shape"])
     assert rf["bound"] in ("hbm", "mfma") and 0 < rf["frac"] < 1 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-4
     assert rf["unit"] in ("GB/s", "TFLOP/s") and "traffic" in rf and len(rf["kernel_src_sha"]) == 16
     for ph in ("dit_sampler", "cond_encoders", "codec_decode"):

@@ -90,3 +90,18 @@ def test_torchrun_two_ranks_walk_the_bench_protocol(mode):
     res = json.loads(line)
     assert res["ok"] and res["world"] == 2 and res["backend"] == "gloo"
     assert res["max_s"] >= 0.01   # rank 1 reported 10 ms more than rank 0: the MAX over ranks was taken
+
+
+def test_forced_world_one_group_runs_every_collective_over_gloo():
+    """SMTTS_DIST_FORCE=1: the helper the GPU suite runs over nccl / RCCL (tests/helpers/rccl_world1.py), here over gloo on the
+    CPU — a process group at world size 1, gather into a pre-allocated buffer (fp32 and PCM16 as bytes), barrier, all_reduce."""
+    import json, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SMTTS_DIST_BACKEND="gloo", SMTTS_DIST_FORCE="1", MASTER_PORT=str(_free_port()))
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(root, "tests", "helpers", "rccl_world1.py")], capture_output=True, text=True,
+                       timeout=300, cwd=root, env=env)
+    assert p.returncode == 0, p.stderr[-2000:]
+    r = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    assert r["backend"] == "gloo" and r["f32"] and r["pcm16"] and r["ragged"] and r["max"] == 1.25 and r["destroyed"]

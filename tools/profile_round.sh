@@ -8,7 +8,7 @@ TAG=${1:-r02}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 mkdir -p gpurun_out
 SHA=$(python -c 'import bench; print(bench.kernel_source_hash())')
-CMD="python bench.py --steps 5 --warmup 2 --no-cpu-baseline"
+CMD="python bench.py --steps 5 --warmup 2 --min-seconds 0 --no-cpu-baseline"
 $CMD > gpurun_out/${TAG}_plain_bench.json 2>/dev/null
 rocprofv3 --kernel-trace --stats -d gpurun_out/${TAG}_trace -o t -- $CMD > gpurun_out/${TAG}_trace_bench.json 2> gpurun_out/${TAG}_trace.err
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d gpurun_out/${TAG}_fetch -o f --output-format csv -- $CMD --no-roofline > /dev/null 2> gpurun_out/${TAG}_fetch.err

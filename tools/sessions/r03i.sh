@@ -1,0 +1,7 @@
+#!/bin/bash
+cd "$GRAFT_REPO_ROOT"; export TMPDIR=/tmp
+O=gpurun_out/r03i.txt; : > $O
+timeout 900 python -m pytest tests/test_kernels_gpu.py -x -q -k "attention or qkvg" 2>&1 | tail -5 >> $O
+timeout 900 python -m pytest tests/test_dit_gpu.py tests/test_precision_gpu.py -x -q 2>&1 | tail -5 >> $O
+timeout 300 python tools/phase_breakdown.py --reps 4 2>/dev/null | head -34 >> $O
+for i in 1 2; do timeout 600 python bench.py --steps 24 --warmup 4 --min-seconds 1.0 --no-cpu-baseline --no-roofline 2>/dev/null | python -c 'import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d["ms_per_step"], "ms in flight (", d["ms_per_step_min"], "..", d["ms_per_step_max"], "),", d.get("sequential_ms_per_step"), "one at a time")' >> $O; done
