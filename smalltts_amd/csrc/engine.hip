@@ -1020,8 +1020,14 @@ int Engine::denoise_core(hipStream_t st, const float* x_t, const uint8_t* mask, 
     HIPC(gemm_store(ops(x_t, rowmap_plain(kLatent), inproj_, M), ACT_NONE,
                     store_to(w.h, rh, rawp("dit.input_embed.proj.bias")), 1, pc, st));
     HIPC(launch_convpos_pack(w.h, mask, gm1.hi, gm1.lo, B, N, kConvG, kConvCpg, kConvPad, kConvGs, st));
-    HIPC(hipMemsetAsync(w.gm2.hi, 0, w.gm_elems * 2, st));
-    HIPC(hipMemsetAsync(w.gm2.lo, 0, w.gm_elems * 2, st));
+    // zero regions that no kernel of this function writes (pad frames of the conv image, pad columns of the FF hidden, pad key
+    // columns of V^T): once per workspace use — the sampler's later steps find them as the first step left them
+    const bool init_ws = !ws_ready_;
+    ws_ready_ = ws_keep_;
+    if (init_ws) {
+        HIPC(hipMemsetAsync(w.gm2.hi, 0, w.gm_elems * 2, st));
+        if (pcp == PREC_BF16X3) HIPC(hipMemsetAsync(w.gm2.lo, 0, w.gm_elems * 2, st));
+    }
     {
         // grouped conv k=31 as B*G small GEMMs: z = b*G + g, rows = frames, K = 31 taps x 64 (padded) channels
         // one product per GROUP over the rows of the whole batch (z = g, row m = (b, frame)): B * N rows fill their 64-row tiles
@@ -1045,8 +1051,10 @@ int Engine::denoise_core(hipStream_t st, const float* x_t, const uint8_t* mask, 
         HIPC(gemm3_convpos(g, true, e2, nz, pcp, st));
     }
     // zero the padded tail columns [2400, 2432) of the FF hidden once per call
-    HIPC(hipMemsetAsync(w.ffh.hi, 0, (size_t)M * kFFp * 2, st));
-    HIPC(hipMemsetAsync(w.ffh.lo, 0, (size_t)M * kFFp * 2, st));
+    if (init_ws) {
+        HIPC(hipMemsetAsync(w.ffh.hi, 0, (size_t)M * kFFp * 2, st));
+        if (pb == PREC_BF16X3) HIPC(hipMemsetAsync(w.ffh.lo, 0, (size_t)M * kFFp * 2, st));
+    }
     const float* rc = rope_dit_cos_;
     const float* rs = rope_dit_sin_;
     if (rope) {  // caller-supplied angle table (reference operator input, infer/onnx.py:42-47,122)
@@ -1056,6 +1064,10 @@ int Engine::denoise_core(hipStream_t st, const float* x_t, const uint8_t* mask, 
     }
     // The AdaLN in front of each GEMM is fused into the kernel that produced the residual stream it normalises
     // (split-K reduction + gated residual + LayerNorm-modulate in one pass); only the very first one runs alone.
+    if (join_pending_) {   // the modulation table is being computed on the side stream (sample)
+        HIPC(hipStreamWaitEvent(st, ev_join_, 0));
+        join_pending_ = false;
+    }
     HIPC(launch_ln_modulate(w.x, nullptr, yb.hi, yb.lo, M, kHidden, 1e-6f, mod + 0 * kHidden, mod + 1 * kHidden, kModLd,
                             mod_row0, mod_rstride, N, st));
     // split-K exists to fill the chip at M = 600 (150 tiles of 64x64 for N = 960); the 3B-row CFG batches of the teacher
@@ -1091,7 +1103,7 @@ int Engine::denoise_core(hipStream_t st, const float* x_t, const uint8_t* mask, 
             pk.q = w.qi.hi; pk.q_lo = w.qi.lo; pk.k = w.ki.hi; pk.k_lo = w.ki.lo; pk.vt = w.vti.hi; pk.vt_lo = w.vti.lo;
             pk.g = w.gi.hi; pk.g_lo = w.gi.lo;
             pk.B = B; pk.N = N; pk.H = kHeads; pk.dh = kDh; pk.dhp = 128; pk.Np = Np;
-            if (l == 0 && Np != N) {   // pad key columns of V^T: zero once per call (the producer only writes n < N)
+            if (l == 0 && Np != N && init_ws) {   // pad key columns of V^T (the producer only writes n < N)
                 HIPC(hipMemsetAsync(w.vti.hi, 0, w.vt_elems * 2, st));
                 if (pa == PREC_BF16X3) HIPC(hipMemsetAsync(w.vti.lo, 0, w.vt_elems * 2, st));
             }
@@ -1284,9 +1296,22 @@ int Engine::sample(hipStream_t st, int mode, int n_steps, int cfg, float s_text,
     // first DiT block of every batch (~0.1-0.5 ms of idle time in the rocprof timeline)
     HIPC(launch_linspace10(s.ts, n_steps, st));
     // t is shared by the whole batch -> every AdaLN vector of every step in one pass (SURVEY §7 hard part 3)
-    if (modulation(st, s.ts, n_steps, m.sinb, m.t1, m.temb, m.e1, m.semb, m.mod)) return 1;
+    // The table does not depend on the batch's data, only the first AdaLN needs it: in latency tuning it is computed on the
+    // engine's side stream while the main stream packs the cross-KV images and embeds the first step's input (0.2 ms of tiny-M
+    // GEMMs that fill a fraction of the chip); the main stream joins right before its first ln_modulate (denoise_core).
+    if (dual_stream_ && !prof_on_) {
+        if (ensure_aux()) return 1;
+        HIPC(hipEventRecord(ev_fork_, st));
+        HIPC(hipStreamWaitEvent(aux_, ev_fork_, 0));
+        if (modulation(aux_, s.ts, n_steps, m.sinb, m.t1, m.temb, m.e1, m.semb, m.mod)) return 1;
+        HIPC(hipEventRecord(ev_join_, aux_));
+        join_pending_ = true;
+    } else if (modulation(st, s.ts, n_steps, m.sinb, m.t1, m.temb, m.e1, m.semb, m.mod)) {
+        return 1;
+    }
 
     const int Bd = cfg ? 3 * B : B;
+    struct KeepWs { Engine* e; explicit KeepWs(Engine* e_) : e(e_) { e->ws_ready_ = false; e->ws_keep_ = true; } ~KeepWs() { e->ws_ready_ = e->ws_keep_ = false; } } keep_ws(this);
     CrossImg ci;   // the cross-KV cache in the attention kernel's operand format: once per call, read by every step
     if (pack_cross(st, k_ref, v_ref, k_text, v_text, Bd, R, P, core + ((denoise_core_bytes(Bd, N) + 255) & ~size_t(255)), ci)) return 1;
     // mask for 3B rows when cfg: caller passes mask with B rows; replicate by pointer arithmetic is impossible,
@@ -1755,6 +1780,7 @@ int Engine::bench_gemm(int M, int N, int K, int epi, int split, int cfg, int ite
                     return gemm3_store(g3, ACT_GELU, e, 1, split, 0, cfg);
                 }
                 case 5: { EpiResid<0> r{C, rowmap_plain(N), bias, gate, 0, 0, 0, M, nullptr}; return gemm3_resid(g3, 2, r, split, 0, cfg); }   // LayerScale residual (codec FF2)
+                case 6: return gemm3_store(g3, ACT_NONE, store_to(C, rowmap_plain(N), nullptr), 1, split, 0, cfg);   // no bias: what a split-K slice stores
                 default: { EpiResid<0> r{C, rowmap_plain(N), bias, gate, 0, 0, 0, M, nullptr}; return gemm3_resid(g3, 1, r, split, 0, cfg); }
             }
         }

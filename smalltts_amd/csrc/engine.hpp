@@ -232,6 +232,8 @@ class Engine {
     hipStream_t aux_ = nullptr;
     hipEvent_t ev_fork_ = nullptr, ev_join_ = nullptr;
     int ensure_aux();
+    bool ws_ready_ = false, ws_keep_ = false;   // sample(): the denoiser workspace's never-written regions were zeroed by an earlier step of this call
+    bool join_pending_ = false;   // sample(): the side stream's modulation table must be joined before the first AdaLN
     int num_cus_ = 256;
     bool convpos_by_group_ = true;  // grouped conv pos-embed as one product per group over the batch's rows (false: per (utterance, group))
     bool attn_img_ = true;   // attention on producer-written operand images (attention_img.hip: DMA + MFMA only); false (SMTTS_ATTN_IMG=0, test hook) = fp32 projection + qk_prep + the fp32 VALU reference kernel (attention.hip)

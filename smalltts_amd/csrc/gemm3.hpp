@@ -28,6 +28,15 @@ struct Gemm3Operands {
     int ksplit_tiles;  // > 0: blockIdx.z is a split-K index; this launch slice covers k-tiles [z*ksplit_tiles, +ksplit_tiles)
 };
 
+#ifdef G3_TIMELINE   // debug build (tools/gemm3_timeline.py): wave 0 of every workgroup stamps the shader clock around each k-tile's wait / barrier / MFMAs
+static __device__ unsigned long long g3_tl_buf[1024 * 160];   // (one copy per translation unit: read through gemm3_store.hip's)
+#define G3_STAMP(i) do { if (tid == 0 && blockIdx.x < 1024 && (i) < 160) g3_tl_buf[blockIdx.x * 160 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define G3_STAMPR(i) do { if (tid == 0 && blockIdx.x < 1024) g3_tl_buf[blockIdx.x * 160 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)   // constant 100 MHz: calibrates the shader clock
+#else
+#define G3_STAMPR(i) do { } while (0)
+#define G3_STAMP(i) do { } while (0)
+#endif
+
 template <int BM, int BN, int WM, int WN, int SPLIT, int S, class Epi>
 __global__ __launch_bounds__(WM* WN * 64) void gemm3_kernel(Gemm3Operands g, Epi epi) {
     constexpr int BK = 64;
@@ -190,9 +199,12 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm3_kernel(Gemm3Operands g, Epi
             w_off[j][kk] = NARR * A_ARR + r * 128 + (((kk * 2 + fh) ^ ((r >> 1) & 7)) << 4);
     }
 
+    G3_STAMPR(152);
+    G3_STAMP(0);
 #pragma unroll
     for (int s = 0; s < S - 1; ++s)
         if (s < nk) issue(s);
+    G3_STAMP(1);
 
     for (int kt = 0; kt < nk; ++kt) {
         // younger than stage kt's DMA: its own touch loads + (S-2) full later stages
@@ -200,38 +212,89 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm3_kernel(Gemm3Operands g, Epi
             wait_vmcnt<(S - 2) * OPS + PFN>();
         else
             wait_vmcnt<0>();
+        G3_STAMP(2 + 4 * kt);          // own DMA pieces of k-tile kt landed
         __builtin_amdgcn_s_barrier();
-        if (kt + S - 1 < nk) issue(kt + S - 1);
+        G3_STAMP(3 + 4 * kt);          // everybody's did
         const char* st = smem + (kt % S) * STAGE_LD;
+        // Small latency-bound tiles (64x64: the DiT's N = 960 projections) issue every fragment read of the k-tile first, THEN the
+        // next stage's DMAs (4 wave-instructions of ~60 cycles each, M0 dance included), then the MFMAs: the LDS latency of the
+        // reads hides under the DMA issue instead of following it — per-k-tile timeline (tools/gemm3_timeline.py,
+        // profiles/r03n_*, r03o_*): wait 31 % / barrier 9 % / DMA issue 20 % / reads + MFMA 40 % of 0.77 us before, -7 % after.
+        // The larger tiles keep the interleaved order: with 8 - 32 MFMAs per k-tile the compiler already hides the reads under
+        // them, and holding all fragments delays the first MFMA (24000 x 512 x 2048: 74 -> 87 us when forced, r03o).
+#ifndef G3_LATE_64
+#define G3_LATE_64 1   // (A/B: -DG3_LATE_64=0 restores the interleaved order everywhere)
+#endif
+        constexpr bool LATE = G3_LATE_64 && BM == 64 && BN == 64;
+        if constexpr (LATE) {
+            bf16x8 ah[4][TM], al[4][SPLIT == 3 ? TM : 1], bh[4][TN], bl[4][SPLIT == 3 ? TN : 1];
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-            bf16x8 ah[TM], al[TM], bh[TN], bl[TN];
+            for (int kk = 0; kk < 4; ++kk) {
 #pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                ah[i] = *reinterpret_cast<const bf16x8*>(st + a_off[i][kk]);
-                if (SPLIT == 3) al[i] = *reinterpret_cast<const bf16x8*>(st + a_off[i][kk] + A_ARR);
-            }
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                bh[j] = *reinterpret_cast<const bf16x8*>(st + w_off[j][kk]);
-                if (SPLIT == 3) bl[j] = *reinterpret_cast<const bf16x8*>(st + w_off[j][kk] + W_ARR);
-            }
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
+                for (int i = 0; i < TM; ++i) {
+                    ah[kk][i] = *reinterpret_cast<const bf16x8*>(st + a_off[i][kk]);
+                    if (SPLIT == 3) al[kk][i] = *reinterpret_cast<const bf16x8*>(st + a_off[i][kk] + A_ARR);
+                }
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
-                    if (SPLIT == 3) {
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
-                    }
-                    acc[i][j] = mfma16<SPLIT>(ah[i], bh[j], acc[i][j]);
+                    bh[kk][j] = *reinterpret_cast<const bf16x8*>(st + w_off[j][kk]);
+                    if (SPLIT == 3) bl[kk][j] = *reinterpret_cast<const bf16x8*>(st + w_off[j][kk] + W_ARR);
                 }
+            }
+            if (kt + S - 1 < nk) issue(kt + S - 1);
+            G3_STAMP(4 + 4 * kt);          // fragment reads + next stage's DMAs issued
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        if (SPLIT == 3) {
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[kk][i], bh[kk][j], acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[kk][i], bl[kk][j], acc[i][j], 0, 0, 0);
+                        }
+                        acc[i][j] = mfma16<SPLIT>(ah[kk][i], bh[kk][j], acc[i][j]);
+                    }
+        } else {
+            if (kt + S - 1 < nk) issue(kt + S - 1);
+            G3_STAMP(4 + 4 * kt);          // next stage's DMAs issued
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                bf16x8 ah[TM], al[TM], bh[TN], bl[TN];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    ah[i] = *reinterpret_cast<const bf16x8*>(st + a_off[i][kk]);
+                    if (SPLIT == 3) al[i] = *reinterpret_cast<const bf16x8*>(st + a_off[i][kk] + A_ARR);
+                }
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    bh[j] = *reinterpret_cast<const bf16x8*>(st + w_off[j][kk]);
+                    if (SPLIT == 3) bl[j] = *reinterpret_cast<const bf16x8*>(st + w_off[j][kk] + W_ARR);
+                }
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        if (SPLIT == 3) {
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+                        }
+                        acc[i][j] = mfma16<SPLIT>(ah[i], bh[j], acc[i][j]);
+                    }
+            }
         }
+#ifdef G3_TIMELINE
+        asm volatile("s_nop 0" :: "v"(acc[0][0][0]));   // (the stamp must not move above the MFMAs' issue)
+#endif
+        G3_STAMP(5 + 4 * kt);          // fragment reads + MFMAs of k-tile kt issued
     }
+    G3_STAMP(150);
     if constexpr (Epi::TILE) {   // whole-workgroup epilogue through an fp32 LDS tile in the finished ring (EpiQKV)
         static_assert(BN == 128 && (BM == 64 || BM == 128), "tile epilogue: 128-column tiles of 64 / 128 rows");
         static_assert(64 * Epi::TP * 4 <= S * STAGE_LD, "tile epilogue: the fp32 tile must fit the finished ring");
         epi.template tile_epilogue<BM, TM, TN, WN, NW>(acc, g.M, m0, n0, wave, lane, reinterpret_cast<float*>(smem));
+        G3_STAMP(151);
+        G3_STAMPR(153);
         return;
     }
     if constexpr (Epi::STAGE16) {
@@ -241,10 +304,14 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm3_kernel(Gemm3Operands g, Epi
         if (g.stage16 && epi.stage16_ok() && ((Epi::PAIRED ? g.N / 2 : g.N) % 8) == 0) {   // wave-uniform: kernel arguments only
             __syncthreads();   // every wave has read its last fragments: the ring is free
             gemm_epilogue_staged16<TM, TN, Epi>(epi, acc, g.M, g.N, m0 + wm * TM * 32, n0 + wn * TN * 32, z, lane, smem + wave * STG);
+            G3_STAMP(151);
+            G3_STAMPR(153);
             return;
         }
     }
     gemm_epilogue<TM, TN, Epi>(epi, acc, g.M, g.N, m0 + wm * TM * 32, n0 + wn * TN * 32, z, lane);
+    G3_STAMP(151);
+    G3_STAMPR(153);
 }
 
 template <int BM, int BN, int WM, int WN, int SPLIT, int S, class Epi>

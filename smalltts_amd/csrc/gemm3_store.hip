@@ -14,3 +14,14 @@ hipError_t gemm3_store(const Gemm3Operands& g, int act, const EpiStore<ACT_NONE>
     }
     return hipErrorInvalidValue;
 }
+
+#ifdef G3_TIMELINE   // debug build only (tools/gemm3_timeline.py): the k-tile stamps of this translation unit's gemm3 instantiations
+extern "C" int smtts_debug_read_timeline(unsigned long long* host, int n) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g3_tl_buf), (size_t)n * 8);
+}
+extern "C" int smtts_debug_clear_timeline(void) {
+    void* p = nullptr;
+    if (hipGetSymbolAddress(&p, HIP_SYMBOL(g3_tl_buf)) != hipSuccess) return 1;
+    return (int)hipMemset(p, 0, sizeof(unsigned long long) * 1024 * 160);
+}
+#endif
