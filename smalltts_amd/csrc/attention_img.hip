@@ -280,6 +280,10 @@ __global__ __launch_bounds__(256) void attention_img_kernel(AttnImg a, int nslot
             const float inv = l_run > 0.f ? 1.0f / l_run : 0.f;
             const long obase = ((long)b * N + n) * a.ors + h * a.dh;
 #pragma unroll
+            for (int q = 0; q < 4; ++q) {   // the (conditional) gate loads are complete before the first store (gemm.hpp epi_settle)
+                asm volatile("" : "+v"(g4[q].x), "+v"(g4[q].y), "+v"(g4[q].z), "+v"(g4[q].w));
+            }
+#pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int d0 = 32 * w + 8 * q + 4 * fh;
                 if (d0 < a.dh)   // dh % 4 == 0: a group of four dims is entirely inside or outside the head

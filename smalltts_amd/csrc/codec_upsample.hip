@@ -127,6 +127,8 @@ __global__ __launch_bounds__(512) void codec_upsample_wave_kernel(UpsampleArgs a
                 acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, bh, acc[nt], 0, 0, 0);
             }
         }
+        // (tried: settling the ring's prefetched steps before these stores, so that the next tile does not start with an s_waitcnt
+        // vmcnt(0) behind them — 151 -> 175 us at K = 128: waiting for the prefetch here costs more than the drain there, r03r)
         if (m_cur < a.M) {
             float* orow = a.out + a.omap.at(m_cur);
 #pragma unroll

@@ -196,6 +196,13 @@ struct RowCtx {
     int aux[16];
     unsigned valid;  // bit r: row in range (and not masked out, where the epilogue skips masked rows)
 };
+// Every value an epilogue LOADED must be complete, as far as the compiler's wait-count pass can tell, before its first STORE is
+// issued: loads and stores share vmcnt on gfx9 and complete out of order with respect to each other, so a load that is still
+// (or only "possibly": a skipped branch arm) pending once stores are in flight costs an `s_waitcnt vmcnt(0)` in front of EVERY
+// later element — sixteen serialised store round trips, 3.4 of the 12 us a 64 x 64 tile's workgroup lived (per-k-tile timeline,
+// profiles/r03p_*).  Passing the register through an empty asm makes it a plain definition: the wait lands here, once.
+__device__ __forceinline__ void epi_settle(float& v) { asm volatile("" : "+v"(v)); }
+__device__ __forceinline__ void epi_settle(int& v) { asm volatile("" : "+v"(v)); }
 __device__ __forceinline__ int epi_row(int mb, int r) { return mb + (r & 3) + 8 * (r >> 2); }
 
 // out[omap(m) + n] = mask(m) * act((acc + bias[n]) * scale)
@@ -223,20 +230,27 @@ struct EpiStore {
             rc.aux[r] = (ok && rowmask) ? rowmask[m] : 1;
             rc.valid |= (ok ? 1u : 0u) << r;
         }
+        if (rowmask)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) epi_settle(rc.aux[r]);
     }
     __device__ __forceinline__ void col(int z, int n, const RowCtx& rc, const floatx16& acc) const {
-        const float b = bias ? bias[(long)z * bias_z + n] : 0.f;
+        float b = bias ? bias[(long)z * bias_z + n] : 0.f;
+        epi_settle(b);
+        float v[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            if (rc.valid >> r & 1) {
-                float v = apply_act<ACT>((acc[r] + b) * scale);
-                v = rc.aux[r] ? v : 0.f;
-                if (ohi) {
-                    store_act1(ohi, olo, rc.off[r] + n, v);
-                } else {
-                    out[rc.off[r] + n] = v;
-                }
-            }
+            v[r] = apply_act<ACT>((acc[r] + b) * scale);
+            v[r] = rc.aux[r] ? v[r] : 0.f;
+        }
+        if (ohi) {   // (one decision per column, not per element)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                if (rc.valid >> r & 1) store_act1(ohi, olo, rc.off[r] + n, v[r]);
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                if (rc.valid >> r & 1) out[rc.off[r] + n] = v[r];
         }
     }
     __device__ __forceinline__ void colpair(int, int, const RowCtx&, const floatx16&, const floatx16&) const {}
@@ -296,7 +310,8 @@ struct EpiSwiGLU {
     }
     __device__ __forceinline__ void col(int, int, const RowCtx&, const floatx16&) const {}
     __device__ __forceinline__ void colpair(int, int nh, const RowCtx& rc, const floatx16& a, const floatx16& b) const {
-        const float v1 = b1 ? b1[nh] : 0.f, v3 = b1 ? b3[nh] : 0.f;
+        float v1 = b1 ? b1[nh] : 0.f, v3 = b1 ? b3[nh] : 0.f;
+        epi_settle(v1); epi_settle(v3);
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             if (rc.valid >> r & 1) {
@@ -354,18 +369,23 @@ struct EpiResid {
     const uint8_t* rowmask;  // may be null: masked rows are left untouched
     __device__ __forceinline__ void rows(int, int mb, int M, RowCtx& rc) const {
         rc.valid = 0;
+        int mk[16];   // all sixteen mask bytes are requested before the first is looked at (one round trip, not sixteen dependent ones)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int m = epi_row(mb, r);
-            bool ok = m < M;
-            if (ok && rowmask) ok = rowmask[m] != 0;
+            mk[r] = rowmask ? (int)rowmask[m < M ? m : 0] : 1;
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = epi_row(mb, r);
+            const bool ok = m < M && mk[r] != 0;
             rc.off[r] = xmap.at(ok ? m : 0);
             rc.aux[r] = GATE == 1 ? grow0 + ((ok ? m : 0) / rows_per_batch) * grstride : 0;
             rc.valid |= (ok ? 1u : 0u) << r;
         }
     }
     __device__ __forceinline__ void col(int, int n, const RowCtx& rc, const floatx16& acc) const {
-        const float b = bias ? bias[n] : 0.f;
+        float b = bias ? bias[n] : 0.f;
         float gv[16], xv[16];
         const float g2 = GATE == 2 ? gate[n] : 1.f;
 #pragma unroll
@@ -374,6 +394,8 @@ struct EpiResid {
             gv[r] = (GATE == 1 && ok) ? gate[(long)rc.aux[r] * gld + n] : g2;
             xv[r] = ok ? x[rc.off[r] + n] : 0.f;
         }
+        epi_settle(b);   // (gv / xv are consumed in order by the store loop: settling all 32 costs registers — 115 -> 130 VGPRs on the
+                         // 128 x 128 tile, one workgroup per CU less — for nothing, the first store needs them anyway)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             if (rc.valid >> r & 1) {
@@ -406,7 +428,8 @@ struct EpiKV {
         }
     }
     __device__ __forceinline__ void col(int, int n, const RowCtx& rc, const floatx16& acc) const {
-        const float bv = bias[n];
+        float bv = bias[n];
+        epi_settle(bv);
         int d = n % dh, t = n / dh;
         const int h = t % H;
         t /= H;
@@ -450,13 +473,19 @@ struct EpiConvPos {
             rc.off[r] = FINAL ? ((long)b * T + t) * (G * cpg) : (zz * (T + 2 * pad) + pad + t) * gstride;
             rc.valid |= (ok ? 1u : 0u) << r;
         }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) epi_settle(rc.aux[r]);
     }
     __device__ __forceinline__ void col(int z, int n, const RowCtx& rc, const floatx16& acc) const {
         const int ch = (by_group ? z : z % G) * cpg + n;
-        const float bv = bias[ch];
+        float bv = bias[ch];
         float hv[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) hv[r] = (FINAL && (rc.valid >> r & 1)) ? h[rc.off[r] + ch] : 0.f;
+        epi_settle(bv);
+        if (FINAL)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) epi_settle(hv[r]);
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             if (rc.valid >> r & 1) {
@@ -559,6 +588,11 @@ struct EpiQKV {
                     x0[i] = tile[r * TP + c0]; x1[i] = tile[r * TP + c0 + 1];
                     cs[i] = 1.f; sn[i] = 0.f;
                     if (part < 2) pp.rope(d, n, cs[i], sn[i]);
+                }
+                if (part < 2) {   // (conditional loads: complete before the first store, see epi_settle)
+                    epi_settle(w0); epi_settle(w1);
+#pragma unroll
+                    for (int i = 0; i < RPW; ++i) { epi_settle(cs[i]); epi_settle(sn[i]); }
                 }
                 if (part == 3) {
 #pragma unroll

@@ -49,6 +49,11 @@ __global__ __launch_bounds__(256) void ln_modulate_kernel(const float* __restric
     }
     const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)C + eps);
 #pragma unroll
+    for (int i = 0; i < NV4; ++i) {   // (complete before the first store: see rmsnorm_kernel)
+        asm volatile("" : "+v"(sh[i].x), "+v"(sh[i].y), "+v"(sh[i].z), "+v"(sh[i].w));
+        asm volatile("" : "+v"(sc[i].x), "+v"(sc[i].y), "+v"(sc[i].z), "+v"(sc[i].w));
+    }
+#pragma unroll
     for (int i = 0; i < NV4; ++i) {
         const int c = lane + 64 * i;
         if (c < C4) {
@@ -87,24 +92,29 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(const float* __restrict__ 
     const bool live = row < M;
     const int c4n = C >> 2;
     const float4* xr = reinterpret_cast<const float4*>(x + xmap.at(live ? row : 0));
-    float4 v[NV4];
-    float ss = 0.f;
+    float4 v[NV4], gw[NV4];   // the weights are requested with the row: a load inside the store loop below would cost one
+    float ss = 0.f;           // s_waitcnt vmcnt(0) — a drained store queue — per channel group (loads and stores share the counter)
+    const float4* w4 = reinterpret_cast<const float4*>(w);
 #pragma unroll
     for (int i = 0; i < NV4; ++i) {
         int c = sub + LPR * i;
         v[i] = (live && c < c4n) ? xr[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+        gw[i] = (live && c < c4n) ? w4[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int i = 0; i < NV4; ++i) {
+        asm volatile("" : "+v"(gw[i].x), "+v"(gw[i].y), "+v"(gw[i].z), "+v"(gw[i].w));
         ss += v[i].x * v[i].x + v[i].y * v[i].y + v[i].z * v[i].z + v[i].w * v[i].w;
     }
     ss = group_sum<LPR>(ss);
     const float rstd = 1.0f / sqrtf(ss / (float)C + eps);
     if (!live) return;
     const long yo = ymap.at(row);
-    const float4* w4 = reinterpret_cast<const float4*>(w);
 #pragma unroll
     for (int i = 0; i < NV4; ++i) {
         int c = sub + LPR * i;
         if (c < c4n) {
-            float4 g = w4[c];
+            float4 g = gw[i];
             const float4 o = make_float4(v[i].x * rstd * g.x, v[i].y * rstd * g.y, v[i].z * rstd * g.z, v[i].w * rstd * g.w);
             if (yhi) store_split4(yhi, ylo, yo + c * 4, o);
             else reinterpret_cast<float4*>(y + yo)[c] = o;
@@ -469,10 +479,25 @@ __global__ __launch_bounds__(256) void dwconv_resid_rms_kernel(float* __restrict
             const float4 g = reinterpret_cast<const float4*>(gamma)[c];
             float4 xv = xr[c];
             xv.x += g.x * acc.x; xv.y += g.y * acc.y; xv.z += g.z * acc.z; xv.w += g.w * acc.w;
-            xr[c] = xv;
             v[i] = xv;
         }
         ss += v[i].x * v[i].x + v[i].y * v[i].y + v[i].z * v[i].z + v[i].w * v[i].w;
+    }
+    // the updated rows are stored after ALL channel groups' loads: a store between two groups' loads makes the second group's first
+    // use an s_waitcnt vmcnt(0) (loads and stores share the counter), i.e. one full memory round trip per group instead of one per row
+    const float4* nw4 = reinterpret_cast<const float4*>(nw);
+    float4 gw[NV4];
+#pragma unroll
+    for (int i = 0; i < NV4; ++i) {
+        const int c = sub + LPR * i;
+        gw[i] = (live && c < C4) ? nw4[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int i = 0; i < NV4; ++i) asm volatile("" : "+v"(gw[i].x), "+v"(gw[i].y), "+v"(gw[i].z), "+v"(gw[i].w));
+#pragma unroll
+    for (int i = 0; i < NV4; ++i) {
+        const int c = sub + LPR * i;
+        if (live && c < C4) xr[c] = v[i];
     }
     if (LPR == 64) {
         ss = group_sum<64>(ss);
@@ -485,12 +510,11 @@ __global__ __launch_bounds__(256) void dwconv_resid_rms_kernel(float* __restrict
     const float rstd = 1.0f / sqrtf(ss / (float)(C4 * 4) + eps);
     if (!live) return;
     const long yo = ymap.at((int)row);
-    const float4* nw4 = reinterpret_cast<const float4*>(nw);
 #pragma unroll
     for (int i = 0; i < NV4; ++i) {
         const int c = sub + LPR * i;
         if (c < C4) {
-            const float4 g = nw4[c];
+            const float4 g = gw[i];
             store_split4(yhi, ylo, yo + c * 4, make_float4(v[i].x * rstd * g.x, v[i].y * rstd * g.y, v[i].z * rstd * g.z, v[i].w * rstd * g.w));
         }
     }
@@ -773,6 +797,13 @@ __global__ __launch_bounds__(256) void splitk_resid_ln_kernel(const float* __res
         g[i] = gate ? reinterpret_cast<const float4*>(gate + mrow)[cc] : make_float4(1.f, 1.f, 1.f, 1.f);
     }
     const bool live = mk != 0;
+    // every loaded value is complete before the first store: loads and stores share vmcnt and complete out of order with respect to
+    // each other, so the AdaLN rows (first used after the x stores) would otherwise cost an s_waitcnt vmcnt(0) that drains those stores
+#pragma unroll
+    for (int i = 0; i < NV4; ++i) {
+        asm volatile("" : "+v"(sh[i].x), "+v"(sh[i].y), "+v"(sh[i].z), "+v"(sh[i].w));
+        asm volatile("" : "+v"(sc[i].x), "+v"(sc[i].y), "+v"(sc[i].z), "+v"(sc[i].w));
+    }
 #pragma unroll
     for (int i = 0; i < NV4; ++i) {
         const int c = lane + 64 * i;

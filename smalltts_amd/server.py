@@ -365,7 +365,9 @@ def serve(host: str = "0.0.0.0", port: int = 3000, weights: Optional[str] = None
     tts = SmallTTS(**kw)
     enc = Encoder(**kw)
     batcher = Batcher(tts, enc, max_batch, window_ms, in_flight, tts.num_steps, max_pack)
-    httpd = ThreadingHTTPServer((host, port), make_handler(batcher, tokenizer))
+    class _Server(ThreadingHTTPServer):
+        request_queue_size = 256   # listen backlog: bursts of concurrent clients (the default of 5 resets connections)
+    httpd = _Server((host, port), make_handler(batcher, tokenizer))
     httpd.daemon_threads = True
     httpd.batcher = batcher
     if ready is not None:

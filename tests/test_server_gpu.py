@@ -47,7 +47,10 @@ def test_concurrent_requests_get_their_own_audio(n_req, max_pack):
     tts, enc = SmallTTS(engine=eng, seed=0), Encoder(engine=eng)
     batcher = S.Batcher(tts, enc, max_batch=8, window_ms=30.0, in_flight=3, num_steps=4, max_pack=max_pack)
     from http.server import ThreadingHTTPServer
-    httpd = ThreadingHTTPServer(("127.0.0.1", 0), S.make_handler(batcher, tokenizer="chars"))
+
+    class Srv(ThreadingHTTPServer):
+        request_queue_size = 256          # 48 clients connect at once: the default backlog of 5 resets some of them
+    httpd = Srv(("127.0.0.1", 0), S.make_handler(batcher, tokenizer="chars"))
     httpd.daemon_threads = True
     th = threading.Thread(target=httpd.serve_forever, kwargs={"poll_interval": 0.02}, daemon=True)
     th.start()
