@@ -72,7 +72,9 @@ int smtts_get_precision(smtts_handle h);   /* the preset in force (1 / 2 / 3) */
 int smtts_default_precision(void);         /* host-only: the preset smtts_create starts with */
 /* one GEMM site group at a time: site 0 DiT blocks, 1 encoders, 2 cross-KV, 3 conditioning / in / out projections,
  * 4 codec FFNs, 5 codec stem / resampling convs, 6 conv pos-embed, 7 attention operands (q, k, v, gate, probabilities);
- * prec 1 bf16, 2 fp16, 3 split-bf16 (call after smtts_set_precision) */
+ * prec 1 bf16, 2 fp16, 3 split-bf16 (call after smtts_set_precision); site 5 (codec resampling convs) also takes
+ * 4 = "fp16 x 2": fp16 activations against fp16 hi + lo weights, two passes instead of split-bf16's three, on the decoder's
+ * ConvTranspose stages with 512 <= K <= 1024 (the other stages stay split-bf16) */
 int smtts_set_site_precision(smtts_handle h, int site, int prec);
 int smtts_has_part(smtts_handle h, int part); /* 0 dit, 1 codec decoder, 2 codec encoder */
 

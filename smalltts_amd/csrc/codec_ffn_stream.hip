@@ -139,6 +139,13 @@ __global__ __launch_bounds__(NW * 64) void codec_ffn_stream_kernel(FfnStreamArgs
         }
     };
 
+#ifdef FS_PHASE_TICKS   // (A/B builds: with two 4-wave workgroups per CU, hold the second half of the grid back by this many 10-ns ticks so
+                        // that the two workgroups of a CU do their tile I/O at different times)
+    if (blockIdx.x >= gridDim.x / 2) {
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+        while (__builtin_amdgcn_s_memrealtime() - t0 < (unsigned long long)(FS_PHASE_TICKS)) __builtin_amdgcn_s_sleep(32);
+    }
+#endif
     const int npass_total = (a.M + NW * 32 - 1) / (NW * 32);
     const int my_passes = blockIdx.x < npass_total ? (npass_total - blockIdx.x + gridDim.x - 1) / gridDim.x : 0;
     const int total = my_passes * NSTEP;  // ring slots this workgroup will consume
@@ -172,6 +179,31 @@ __global__ __launch_bounds__(NW * 64) void codec_ffn_stream_kernel(FfnStreamArgs
 #endif
         }
     };
+    // x I/O of a pass used to cost three exposed memory round trips (tile read at the top; residual re-read, then the drain of
+    // its stores at the bottom — elimination builds, profiles/r02x_*: 120 of 313 us at C = 128).  Two of them are hidden now:
+    //  FS_XNEXT     the NEXT pass's tile is requested right behind this pass's stores (the accumulators and the re-read tile
+    //               are dead by then, so it costs no registers) and arrives under the one drain both need anyway;
+    //  FS_XO_EARLY  the residual re-read is issued two ring steps before the end of the pass, into the registers the
+    //               normalised input fragments and the first-product accumulators have just left; the counted waits of those
+    //               two steps allow for the XL younger loads.
+    // Measured (profiles/r03u_*, us per launch, old / early re-read / next-tile request / both): C = 128: 304.6 / 290.3 / 302.8 /
+    // 300.4; C = 256: 238.8 / 237.0 / 232.0 / 238.1 — far less than the 120 us the elimination builds promised: what a pass
+    // waits for is not the latency of its own requests but the BURST — every workgroup of the launch reaches its write-back
+    // within the same few microseconds (32 MB of stores, then 32 MB of reads, per round of passes), and nothing computes while
+    // HBM serves it.  Each width keeps the variant that helps it (-DFS_XNEXT=0/1 -DFS_XO_EARLY=0/1 force one for A/B builds).
+#ifdef FS_XNEXT
+    constexpr bool XNEXT = FS_XNEXT;
+#else
+    constexpr bool XNEXT = C == 256;
+#endif
+#ifdef FS_XO_EARLY
+    constexpr bool XO_EARLY = FS_XO_EARLY;
+#else
+    constexpr bool XO_EARLY = C == 128;
+#endif
+    constexpr int XL = XO_EARLY ? 4 * NOT : 0;   // loads of the early re-read (per lane)
+    static_assert((S - 2) * PW + XL <= 63, "vmcnt immediate");
+    if (XNEXT && my_passes > 0) load_x(0);
 #pragma unroll 1
     for (int p = 0; p < my_passes; ++p) {
         const int pass = blockIdx.x + p * gridDim.x;
@@ -179,7 +211,7 @@ __global__ __launch_bounds__(NW * 64) void codec_ffn_stream_kernel(FfnStreamArgs
         // ---- x -> RMSNorm -> split bf16 B fragments (lane = frame, channels 16 kk + 8 fh + e) -------------------
         bf16x8 nh[KK1], nl[KK1];
         {
-            load_x(p);
+            if (!XNEXT) load_x(p);
             float ss = 0.f;
 #pragma unroll
             for (int kk = 0; kk < KK1; ++kk)
@@ -216,11 +248,12 @@ __global__ __launch_bounds__(NW * 64) void codec_ffn_stream_kernel(FfnStreamArgs
         Frags F0, F1;
 
         // one ring step; ti = hidden tile of the first product (step index), do_* select what the step contains
-        auto step = [&](auto do_p1, auto do_g, auto do_p2, int ti, floatx16& hw, const floatx16& hr, Frags& fw, const Frags& fr_) {
+        auto step = [&](auto do_p1, auto do_g, auto do_p2, int ti, floatx16& hw, const floatx16& hr, Frags& fw, const Frags& fr_, auto younger) {
             constexpr bool P1 = decltype(do_p1)::value, G = decltype(do_g)::value, P2 = decltype(do_p2)::value;
+            constexpr int YL = decltype(younger)::value;   // loads issued by this wave AFTER the DMA pieces of this step's slot (early re-read)
             // ---- ring hand-over (one barrier per step) ----
             if (it + S - 1 <= total)
-                wait_vmcnt<(S - 2) * PW>();
+                wait_vmcnt<(S - 2) * PW + YL>();
             else
                 wait_vmcnt<0>();
 #ifndef FS_NOBARRIER   // (timing experiment only: without the barrier the ring hand-over is a data race)
@@ -398,32 +431,38 @@ __global__ __launch_bounds__(NW * 64) void codec_ffn_stream_kernel(FfnStreamArgs
         using T_ = std::true_type;
         using F_ = std::false_type;
         // step i: P1 -> H[i & 1]; GELU: H[(i+1) & 1] -> Fr[(i+1) & 1]; P2 reads Fr[i & 1]
-        step(T_{}, F_{}, F_{}, 0, H0, H0, F1, F0);  // (no GELU / second product yet: hr, fr_ unused)
-        step(T_{}, T_{}, F_{}, 1, H1, H0, F0, F1);
+        using Y0 = std::integral_constant<int, 0>;
+        step(T_{}, F_{}, F_{}, 0, H0, H0, F1, F0, Y0{});  // (no GELU / second product yet: hr, fr_ unused)
+        step(T_{}, T_{}, F_{}, 1, H1, H0, F0, F1, Y0{});
 #pragma unroll 1
         for (int i = 2; i < NT1; i += 2) {
-            step(T_{}, T_{}, T_{}, i, H0, H1, F1, F0);
-            step(T_{}, T_{}, T_{}, i + 1, H1, H0, F0, F1);
+            step(T_{}, T_{}, T_{}, i, H0, H1, F1, F0, Y0{});
+            step(T_{}, T_{}, T_{}, i + 1, H1, H0, F0, F1, Y0{});
         }
-        step(F_{}, T_{}, T_{}, NT1, H0, H1, F1, F0);
-        step(F_{}, F_{}, T_{}, NT1 + 1, H1, H0, F0, F1);
-
-        // ---- epilogue: x[frame][c] += gamma[c] (out + b2[c]); channel(r) = 32 ot + (r & 3) + 8 (r >> 2) + 4 fh ----------
-#ifdef FS_ELIM_XOUT   // (timing experiment: the residual read-modify-write never happens, but the compiler cannot know)
-        if (m_cur < a.M && a.eps < 0.f) {
-#else
-        if (m_cur < a.M) {
-#endif
-            float* xr = a.x + a.img.at(m_cur);
-            // every re-read of the tile is issued before the first store: one memory round trip per pass instead of one per
-            // channel tile (the hidden-tile registers are dead here, so the C / 2 extra registers are free)
-            float4 xo[NOT][4];
+        // the residual re-read, in the accumulator layout (clamped row: every lane issues the same number of loads)
+        float* const xr = a.x + a.img.at(m_cur < a.M ? m_cur : a.M - 1);
+        float4 xo[NOT][4];
+        auto load_xo = [&]() {
 #pragma unroll
             for (int ot = 0; ot < NOT; ++ot)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) xo[ot][q] = *reinterpret_cast<const float4*>(xr + 32 * ot + 8 * q + 4 * fh);
+        };
+        if (XO_EARLY) load_xo();
+        // step NT1's slot and the two behind it were issued before the re-read; with a two-slot ring step NT1 + 1's slot is issued
+        // inside step NT1, i.e. AFTER it, and must be waited for without the allowance
+        step(F_{}, T_{}, T_{}, NT1, H0, H1, F1, F0, std::integral_constant<int, XL>{});
+        step(F_{}, F_{}, T_{}, NT1 + 1, H1, H0, F0, F1, std::integral_constant<int, (S > 2 ? XL : 0)>{});
+
+        // ---- epilogue: x[frame][c] += gamma[c] (out + b2[c]); channel(r) = 32 ot + (r & 3) + 8 (r >> 2) + 4 fh ----------
+        if (!XO_EARLY) load_xo();   // every re-read of the tile is issued before the first store: one round trip, not one per channel tile
 #ifndef FS_EPI_NOFENCE
-            __builtin_amdgcn_sched_barrier(0);   // (keeps hipcc from sinking the loads back next to their stores)
+        __builtin_amdgcn_sched_barrier(0);   // (keeps hipcc from sinking the loads back next to their stores)
+#endif
+#ifdef FS_ELIM_XOUT   // (timing experiment: the residual read-modify-write never happens, but the compiler cannot know)
+        if (m_cur < a.M && a.eps < 0.f) {
+#else
+        if (m_cur < a.M) {
 #endif
 #pragma unroll
             for (int ot = 0; ot < NOT; ++ot) {
@@ -441,9 +480,14 @@ __global__ __launch_bounds__(NW * 64) void codec_ffn_stream_kernel(FfnStreamArgs
                 }
             }
         }
-        // the counted waits of the step loop assume only DMA pieces are outstanding: drain this pass's loads / stores
-        // (tried: requesting the NEXT pass's tile before this write-back and leaving the stores in flight — the 64 extra live
+        // the counted waits of the step loop assume only DMA pieces are outstanding (stores complete out of order with loads):
+        // drain this pass's stores — and with them the next pass's tile, requested behind them
+        // (tried in round 2: requesting it BEFORE this write-back and leaving the stores in flight — the 64 extra live
         // registers spill, 300 -> 321 us, profiles/r02x_*)
+        __builtin_amdgcn_sched_barrier(0);   // (the request stays BEHIND the stores: hoisted above them it would be live next to the accumulators)
+        // (unconditional — behind the last pass it re-reads a clamped row: a conditional request would keep the OLD tile's 64-128
+        // registers live through the whole pass on the not-taken path, and spills)
+        if (XNEXT) load_x(p + 1);
         wait_vmcnt<0>();
     }
 }

@@ -144,7 +144,9 @@ __device__ __forceinline__ float apply_act(float x) {
 // Activation buffers are written by their producer in the format of the CONSUMING GEMM.  The format travels with the
 // (hi, lo) pointer pair every producer already takes: lo == null -> bf16 single, lo == SM_F16_TAG -> fp16 single (16-bit
 // storage is shared: an fp16 array is addressed through the same bf16_t* type), anything else -> split pair.
-enum { PREC_BF16 = 1, PREC_F16 = 2, PREC_BF16X3 = 3 };
+//   PREC_F16X2   (SITE_CODEC_CONV's ConvTranspose products only) A as one fp16 array, W as an fp16 hi + lo pair:
+//                acc += A W_lo + A W_hi (2 MFMAs): the weights exact to ~22 bits, the activations rounded to 11
+enum { PREC_BF16 = 1, PREC_F16 = 2, PREC_BF16X3 = 3, PREC_F16X2 = 4 };
 typedef _Float16 half_t;
 typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
 typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
@@ -154,7 +156,7 @@ typedef float f32x2_t __attribute__((ext_vector_type(2)));
 __host__ __device__ __forceinline__ bool sm_is_f16(const bf16_t* lo) { return lo == SM_F16_TAG; }
 __host__ __device__ __forceinline__ bool sm_is_split(const bf16_t* lo) { return lo != nullptr && lo != SM_F16_TAG; }
 // lo pointer that tells a producer which format to write for a consumer of precision `prec`
-static inline bf16_t* sm_lo_for(int prec, bf16_t* lo) { return prec == PREC_BF16X3 ? lo : prec == PREC_F16 ? SM_F16_TAG : nullptr; }
+static inline bf16_t* sm_lo_for(int prec, bf16_t* lo) { return prec == PREC_BF16X3 ? lo : (prec == PREC_F16 || prec == PREC_F16X2) ? SM_F16_TAG : nullptr; }
 
 // (a, b) -> packed fp16 pair, round to nearest even, saturating at +-65504 (v_cvt_pk_f16_f32 + v_pk_min/max_f16)
 __device__ __forceinline__ unsigned cvt_pk_f16_sat(float a, float b) {
@@ -211,7 +213,7 @@ __device__ __forceinline__ void store_split4(bf16_t* hi, bf16_t* lo, long off, c
 // one 32x32x16 MFMA on 16-bit fragments held as bf16x8 registers: fp16 when SPLIT == PREC_F16, bf16 otherwise
 template <int SPLIT>
 __device__ __forceinline__ floatx16 mfma16(const bf16x8& a, const bf16x8& b, const floatx16& c) {
-    if constexpr (SPLIT == PREC_F16)
+    if constexpr (SPLIT == PREC_F16 || SPLIT == PREC_F16X2)
         return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8_t, a), __builtin_bit_cast(half8_t, b), c, 0, 0, 0);
     else
         return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);

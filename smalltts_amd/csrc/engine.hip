@@ -33,6 +33,8 @@ thread_local int g_gemm3_deep = 1;   // gemm3 ring depth for single-array operan
 namespace { struct DeepScope { int prev; explicit DeepScope(int v) : prev(g_gemm3_deep) { g_gemm3_deep = v; } ~DeepScope() { g_gemm3_deep = prev; } }; }
 int g_gemm3_w4_minm = 0;  // gemm3: 4-wave 128x128 tiles (wave 64x64) for single-array products with M >= this and N >= 2048 (SMTTS_GEMM_W4_MINM; 0 = off)
 int g_gemm3_stage16 = 1;  // gemm3: 16-bit outputs through the LDS-staged epilogue (SMTTS_GEMM_STAGE16=0: scalar stores)
+int g_gemm_xcd = 1;     // fp32-A GEMM: XCD-aware tile order for unbatched launches (SMTTS_GEMM_XCD=0: plain blockIdx mapping)
+int g_gemm3_group = 4;  // gemm3 tile order when neither operand fits an XCD's L2: bands of this many row tiles (SMTTS_GEMM_GROUP=1: plain N fastest)
 int g_gemm3_nfast = 1;  // gemm3 tile order: N fastest when M > N (SMTTS_GEMM_NFAST=0 restores M fastest everywhere)
 thread_local Profiler* g_prof = nullptr;
 thread_local const char* g_prof_tag = nullptr;
@@ -42,6 +44,8 @@ static int g_small_m_splitk = 1;   // SMTTS_SMALLM_SPLITK=0: A/B switch for the 
 Engine::Engine(int device) : device_(device) {
     set_precision(kDefaultPrecision);
     if (const char* nf = getenv("SMTTS_GEMM_NFAST")) g_gemm3_nfast = atoi(nf);
+    if (const char* gg = getenv("SMTTS_GEMM_GROUP")) g_gemm3_group = atoi(gg);
+    if (const char* gx = getenv("SMTTS_GEMM_XCD")) g_gemm_xcd = atoi(gx);
     if (const char* dp = getenv("SMTTS_GEMM_DEEP")) gemm_deep_ = atoi(dp);
     if (const char* s16 = getenv("SMTTS_GEMM_STAGE16")) g_gemm3_stage16 = atoi(s16);
     if (const char* w4 = getenv("SMTTS_GEMM_W4_MINM")) g_gemm3_w4_minm = atoi(w4);
@@ -54,6 +58,8 @@ Engine::Engine(int device) : device_(device) {
     if ((s = getenv("SMTTS_ATTN_EPI"))) attn_epi_ = atoi(s) != 0;
     if ((s = getenv("SMTTS_ATTN_IMG"))) attn_img_ = atoi(s) != 0;
     if ((s = getenv("SMTTS_UP_G3_MINK")) && atoi(s) >= 64) up_g3_mink_ = atoi(s);
+    if ((s = getenv("SMTTS_X2_MINK")) && atoi(s) >= 64) x2_mink_ = atoi(s);
+    if ((s = getenv("SMTTS_X2_MAXK")) && atoi(s) >= 64) x2_maxk_ = atoi(s);
     if ((s = getenv("SMTTS_KSPLIT_OUT")) && atoi(s) >= 1 && atoi(s) <= kSplitK) ksplit_out_ = atoi(s);
     if ((s = getenv("SMTTS_KSPLIT_ENC")) && atoi(s) >= 1 && atoi(s) <= kSplitK) ksplit_enc_ = atoi(s);
     if ((s = getenv("SMTTS_KSPLIT_FF2")) && atoi(s) >= 1 && atoi(s) <= kSplitK) ksplit_ff2_ = atoi(s);
@@ -492,7 +498,7 @@ int Engine::finalize_codec(bool decoder) {
         *out = d;
         return 0;
     };
-    auto gather_to_pw = [&](const float* src, int N, int K, GatherSpec g, PW& out, float** f32_out) -> int {
+    auto gather_to_pw = [&](const float* src, int N, int K, GatherSpec g, PW& out, float** f32_out, bool x2 = false) -> int {
         float* tmp = nullptr;
         if (f32_out) {
             tmp = static_cast<float*>(dalloc((size_t)N * K * 4));
@@ -503,6 +509,11 @@ int Engine::finalize_codec(bool decoder) {
         HIPC(launch_gather_pack(src, tmp, N, K, g, 0));
         if (f32_out) { *f32_out = tmp; return 0; }
         out = pack_from_f32(tmp, N, K);
+        if (x2 && out.N) {   // low half of the fp16 pair (PREC_F16X2)
+            out.l16 = static_cast<bf16_t*>(dalloc((size_t)N * K * 2));
+            if (!out.l16) return fail("codec pack alloc failed");
+            HIPC(launch_f16_residual(tmp, K, out.h16, out.l16, out.K, N, K, 0));
+        }
         HIPC(hipStreamSynchronize(0));
         HIPC(hipFree(tmp));
         return out.N ? 0 : fail("codec pack failed");
@@ -520,7 +531,7 @@ int Engine::finalize_codec(bool decoder) {
                 const RawTensor* w = raw(sidx(P + ".up.", i, ".weight"));
                 if (!w || w->numel != (long)Cin * C * 2 * r) return fail("missing/mis-shaped " + sidx(P + ".up.", i, ".weight"));
                 GatherSpec g{r, 1, 2L * r, -(long)r, (long)C * 2 * r, C, Cin, Cin};
-                if (gather_to_pw(w->d, r * C, 2 * Cin, g, st.resample, nullptr)) return 1;
+                if (gather_to_pw(w->d, r * C, 2 * Cin, g, st.resample, nullptr, true)) return 1;
                 const float* b = nullptr;
                 if (opt_vec(sidx(P + ".up.", i, ".bias"), C, 0.f, &b)) return 1;
                 GatherSpec gb{0, 0, 0, 0, 1, 1, C, C};
@@ -1501,7 +1512,7 @@ int Engine::codec_decode(hipStream_t st, const float* latents, int B, int T, flo
     const CodecSpecC& s = cspec_;
     const int S = s.n_ratios + 1, pad = kCodecPad, Kc = s.kernel, L = s.latent_dim;
     const int pcv = prec_[SITE_CODEC_CONV];
-    const int pcv3 = pcv == PREC_F16 ? PREC_BF16X3 : pcv;  // the fp32-A and streaming-upsample kernels have no fp16 variant
+    const int pcv3 = pcv == PREC_F16 || pcv == PREC_F16X2 ? PREC_BF16X3 : pcv;  // the fp32-A and streaming-upsample kernels have no fp16 variant
     // re-derive the plan
     size_t max_img = 0, max_hid = 0;
     {
@@ -1549,12 +1560,21 @@ int Engine::codec_decode(hipStream_t st, const float* latents, int B, int T, flo
             if (fused_ffn_ && codec_upsample_wave_ok(sg.resample.K, sg.resample.N) && sg.resample.K == 2 * C && sg.resample.N == r * Cn)
                 HIPC(launch_codec_upsample_wave(x, am, sg.resample.hi, sg.resample.lo, sg.resample.K, sg.resample_bias, xn, om,
                                                 B * Ti, sg.resample.K, sg.resample.N, pcv3, st));
-            else if (fused_ffn_ && sg.resample.K % 64 == 0 && sg.resample.K >= up_g3_mink_ && C % 8 == 0 && (size_t)B * (pad + Ti) * C <= max_img) {
+            else if (pcv == PREC_F16X2 && sg.resample.l16 && sg.resample.K % 64 == 0 && sg.resample.K >= x2_mink_ && sg.resample.K <= x2_maxk_ &&
+                     C % 8 == 0 && (size_t)B * (pad + Ti) * C <= max_img) {
+                // two-pass fp16 product: the image once as ONE fp16 array (pads included: the causal zeros), the weights as an fp16
+                // hi + lo pair — A W_lo + A W_hi on the DMA-ring GEMM instead of three split-bf16 passes on the fp32-A kernel
+                HIPC(launch_to_split(x, rowmap_plain(C), w.n2hi, SM_F16_TAG, rowmap_plain(C), B * (pad + Ti), C, st));
+                Gemm3Operands g3 = ops3(SplitBuf{w.n2hi, w.n2lo}, am, sg.resample, B * Ti, PREC_F16);
+                g3.Wlo = sg.resample.l16;
+                HIPC(gemm3_store_x2(g3, store_to(xn, om, sg.resample_bias), st));
+            } else if (fused_ffn_ && sg.resample.K % 64 == 0 && sg.resample.K >= up_g3_mink_ && C % 8 == 0 && (size_t)B * (pad + Ti) * C <= max_img) {
+                const int pg = pcv == PREC_F16X2 ? PREC_BF16X3 : pcv;   // (f16x2 outside its K range: split-bf16)
                 // widest stages (K >= 2048; measured: 215 -> 148 us and 216 -> 193 us, no gain at K <= 1024): split the image once (pads included: they are the causal zeros) and run the DMA-ring GEMM on
                 // the overlapping rows of the split pair (n2 is free between blocks)
                 SplitBuf xs{w.n2hi, w.n2lo};
-                HIPC(launch_to_split(x, rowmap_plain(C), xs.hi, xs.as(pcv).lo, rowmap_plain(C), B * (pad + Ti), C, st));
-                HIPC(gemm3_store(ops3(xs, am, sg.resample, B * Ti, pcv), ACT_NONE, store_to(xn, om, sg.resample_bias), 1, pcv, st));
+                HIPC(launch_to_split(x, rowmap_plain(C), xs.hi, xs.as(pg).lo, rowmap_plain(C), B * (pad + Ti), C, st));
+                HIPC(gemm3_store(ops3(xs, am, sg.resample, B * Ti, pg), ACT_NONE, store_to(xn, om, sg.resample_bias), 1, pg, st));
             } else
                 HIPC(gemm_store(ops(x, am, sg.resample, B * Ti), ACT_NONE, store_to(xn, om, sg.resample_bias), 1, pcv3, st));
             float* t = x; x = xn; xn = t;
@@ -1600,7 +1620,7 @@ int Engine::codec_encode(hipStream_t st, const float* audio, int B, int S_, floa
     HIPC(hipSetDevice(device_));
     const CodecSpecC& s = cspec_;
     const int S = s.n_ratios + 1, pad = kCodecPad, Kc = s.kernel;
-    const int pcv3 = prec_[SITE_CODEC_CONV] == PREC_F16 ? PREC_BF16X3 : prec_[SITE_CODEC_CONV];
+    const int pcv3 = prec_[SITE_CODEC_CONV] == PREC_F16 || prec_[SITE_CODEC_CONV] == PREC_F16X2 ? PREC_BF16X3 : prec_[SITE_CODEC_CONV];
     size_t max_img = 0, max_hid = 0;
     {
         long Ti = S_;

@@ -26,6 +26,7 @@ struct PW {  // packed GEMM weight [N][K]: bf16 hi + lo (PREC_BF16X3 / PREC_BF16
     bf16_t* hi = nullptr;
     bf16_t* lo = nullptr;
     bf16_t* h16 = nullptr;
+    bf16_t* l16 = nullptr;   // fp16(w - float(h16)): only where PREC_F16X2 can run (the codec decoder's ConvTranspose weights)
     int N = 0, K = 0;  // K = row stride = GEMM K (may be zero-padded beyond the source width)
 };
 
@@ -118,7 +119,10 @@ class Engine {
         if (preset_ == PREC_F16) prec_[SITE_COND] = prec_[SITE_CODEC_CONV] = prec_[SITE_CONVPOS] = PREC_BF16X3;
     }
     int set_site_precision(int site, int prec) {
-        if (site < 0 || site >= SITE_COUNT || prec < 1 || prec > 3) return fail("set_site_precision: bad site / precision");
+        // PREC_F16X2 exists for the codec decoder's ConvTranspose products only (the stages x2_mink_ <= K <= x2_maxk_; the others,
+        // the stem and the encoder's strided convs run split-bf16 under it)
+        if (site < 0 || site >= SITE_COUNT || prec < 1 || prec > (site == SITE_CODEC_CONV ? PREC_F16X2 : 3))
+            return fail("set_site_precision: bad site / precision");
         prec_[site] = prec;
         return 0;
     }
@@ -225,6 +229,7 @@ class Engine {
     int prec_[SITE_COUNT] = {3, 3, 3, 3, 3, 3, 3, 3};
     bool fused_ffn_ = true;  // test hook: smtts_test_set_fused_ffn
     bool block_wave_ = true;  // codec stages with C = 32 / 64: mixer + FFN in one kernel (SMTTS_BLOCK_WAVE=0: mixer_fused + codec_ffn_wave)
+    int x2_mink_ = 512, x2_maxk_ = 1024;   // PREC_F16X2 on SITE_CODEC_CONV: the ConvTranspose stages with K in this range (SMTTS_X2_MINK / _MAXK)
     int up_g3_mink_ = 2048;  // codec ConvTranspose-as-GEMM: gemm3 on a converted copy of the image from this K up (SMTTS_UP_G3_MINK; below: fp32-A kernel)
     int ksplit_enc_ = 4;  // split-K of the encoders' residual projections (1 = fused-epilogue GEMM + separate RMSNorm)
     int ksplit_out_ = 3, ksplit_ff2_ = 3;  // (<= kSplitK; 150 tiles x 3 = 450 workgroups = one round at 2 per CU) split-K factors of the two N = 960 DiT projections (1 = fused epilogue)

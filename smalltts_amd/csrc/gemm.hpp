@@ -24,6 +24,7 @@ struct GemmOperands {
     int M, N, K;
     long a_z, w_z;  // per-blockIdx.z element strides
     int w_zmod;     // weights use (z % w_zmod) * w_z when non-zero (grouped conv: z = batch*G + group)
+    int xcd_order = 1;  // unbatched launches: XCD-aware tile order (set by gemm_launch from g_gemm_xcd; A/B switch)
 };
 
 __device__ __forceinline__ void split4(const float4& v, uint2& hi, uint2& lo) {
@@ -62,7 +63,18 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(GemmOperands g, Epi e
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
-    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN, z = blockIdx.z;
+    // Workgroups are dealt to the 8 XCDs round-robin in dispatch order (x fastest), and each XCD has its own L2: with the plain
+    // (x = column tile, y = row tile) mapping the column tiles of ONE row tile land on different XCDs and every one of them reads
+    // the A rows from HBM again (counters, the codec's ConvTranspose at C = 256 / 128: 1.13 GB per launch against 0.27 GB of
+    // operands + output).  Unbatched launches therefore give every XCD a contiguous run of tiles, column tile fastest.
+    int bx = blockIdx.x, by = blockIdx.y;
+    if (gridDim.z == 1 && g.xcd_order) {
+        const int Nt = gridDim.x, tot = Nt * (int)gridDim.y, p = bx + Nt * by;
+        const int q = tot / 8, r = tot % 8, xcd = p % 8, loc = p / 8;
+        const int vid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+        by = vid / Nt; bx = vid % Nt;
+    }
+    const int m0 = by * BM, n0 = bx * BN, z = blockIdx.z;
     const float* A = g.A + (long)z * g.a_z;
     const long wz = (long)(g.w_zmod ? z % g.w_zmod : z) * g.w_z;
     const bf16_t* Whi = g.Whi + wz;
@@ -768,9 +780,12 @@ static inline hipError_t gemm_launch_split(const GemmOperands& g, const Epi& epi
 // split: 1 = plain bf16, 3 = split-bf16 (fp32-class).  This fp32-A kernel serves the cold sites only and has no fp16
 // variant: PREC_F16 runs as split-bf16 here (its OUTPUT may still be written in any operand format, see store_act1).
 template <class Epi>
-static inline hipError_t gemm_launch(const GemmOperands& g, const Epi& epi, int Z, int split, hipStream_t st,
+static inline hipError_t gemm_launch(const GemmOperands& g_in, const Epi& epi, int Z, int split, hipStream_t st,
                                      int cfg = -1) {
-    if (g.M <= 0 || g.N <= 0) return hipSuccess;
+    if (g_in.M <= 0 || g_in.N <= 0) return hipSuccess;
+    extern int g_gemm_xcd;
+    GemmOperands g = g_in;
+    g.xcd_order = g_gemm_xcd;
     if (cfg < 0) cfg = gemm_pick_cfg(g.M, g.N, g.K, Epi::PAIRED);
     if (split != PREC_BF16) return gemm_launch_split<3, Epi>(g, epi, Z, cfg, st);
     return gemm_launch_split<1, Epi>(g, epi, Z, cfg, st);

@@ -23,7 +23,7 @@ struct Gemm3Operands {
     int M, N, K;
     long a_z, w_z;
     int w_zmod;
-    int nfast = 0;     // tile order inside an XCD's run: 0 = M fastest, 1 = N fastest (set by gemm3_launch)
+    int nfast = 0;     // tile order inside an XCD's run: 0 = M fastest, 1 = N fastest, G > 1 = bands of G row tiles (set by gemm3_launch)
     int stage16 = 1;   // 16-bit outputs through the LDS-staged epilogue (set by gemm3_launch from g_gemm3_stage16; A/B switch)
     int ksplit_tiles;  // > 0: blockIdx.z is a split-K index; this launch slice covers k-tiles [z*ksplit_tiles, +ksplit_tiles)
 };
@@ -42,10 +42,13 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm3_kernel(Gemm3Operands g, Epi
     constexpr int BK = 64;
     constexpr int NW = WM * WN;
     constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
-    constexpr int NARR = SPLIT == 3 ? 2 : 1;
+    // arrays per operand: split-bf16 (SPLIT 3) has hi + lo on both sides; PREC_F16X2 (SPLIT 4) one fp16 array of A against an
+    // fp16 hi + lo pair of W (two MFMAs per fragment pair: A W_lo + A W_hi); the single formats one each
+    constexpr int NARR_A = SPLIT == 3 ? 2 : 1, NARR_W = (SPLIT == 3 || SPLIT == PREC_F16X2) ? 2 : 1;
+    constexpr int NARR = NARR_A;
     constexpr int A_ARR = BM * 128, W_ARR = BN * 128;  // bytes per array per stage
-    constexpr int STAGE = NARR * (A_ARR + W_ARR);
-    constexpr int NA = NARR * (BM / 8), NWS = NARR * (BN / 8);  // DMA slots (8 rows each)
+    constexpr int STAGE = NARR_A * A_ARR + NARR_W * W_ARR;
+    constexpr int NA = NARR_A * (BM / 8), NWS = NARR_W * (BN / 8);  // DMA slots (8 rows each)
     constexpr int PW = (NA + NWS + NW - 1) / NW;                // slots per wave per stage
     constexpr bool DUMMY = PW * NW != NA + NWS;                 // odd wave counts (160-row tiles, 10 waves): the surplus slots DMA
     constexpr int STAGE_LD = STAGE + (DUMMY ? 1024 : 0);        // into a 1-KiB pad behind the stage so every wave counts the same vmcnt
@@ -55,7 +58,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm3_kernel(Gemm3Operands g, Epi
     // L2 hit.  Issued from every wave right after each stage's DMA so the vmcnt arithmetic stays uniform.
     // Measured on MI355X: no gain (dit.qkvg 36.5 -> 42 us), i.e. HBM-miss latency is not what binds -> disabled (PFD = 0).
     constexpr int PFD = 0;
-    constexpr int LINES = NARR * (BM + BN);
+    constexpr int LINES = NARR_A * BM + NARR_W * BN;
     constexpr int PFN = PFD ? (LINES + NW * 64 - 1) / (NW * 64) : 0;  // touch instructions per wave per k-tile
     constexpr int OPS = PW + PFN;                            // VMEM ops per wave per k-tile
     static_assert((S - 2) * PW + (S - 1) * PFN <= 63, "vmcnt immediate overflow");
@@ -78,8 +81,20 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm3_kernel(Gemm3Operands g, Epi
     // panel (right when W is the big operand: the small-M DiT products); N fastest keeps the A rows and re-streams the
     // (small, L2 / MALL resident) weights — right for the tall codec products, where M-fastest re-read all of A from HBM
     // once per N-tile (PMC: 896 MB per launch against 250 MB of operands at 24000 x 2048 x 512).
-    const bool nfast = g.nfast;
-    const int m0 = (nfast ? vid / Nt : vid % Mt) * BM, n0 = (nfast ? vid % Nt : vid / Mt) * BN, z = blockIdx.z;
+    // When BOTH operands are larger than an XCD's L2 (the codec's coarse ConvTranspose / FFN products) neither order is right:
+    // N fastest re-streams the whole of W once per row tile (counters, 4800 x 2560 x 2048 at split-bf16: 615 MB per launch
+    // against 110 MB of operands + output).  nfast = G > 1 walks bands of G row tiles, M fastest inside a band, so the ~32-64
+    // tiles an XCD runs at once cover G row tiles x several column tiles and every operand k-slice is shared while it is hot.
+    const int gm = g.nfast;
+    int mi, ni;
+    if (gm == 0) {
+        mi = vid % Mt; ni = vid / Mt;
+    } else {
+        const int per = gm * Nt, band = vid / per, first = band * gm, loc = vid - band * per;
+        const int rows = Mt - first < gm ? Mt - first : gm;
+        mi = first + loc % rows; ni = loc / rows;
+    }
+    const int m0 = mi * BM, n0 = ni * BN, z = blockIdx.z;
     const int zb = g.ksplit_tiles ? 0 : z;  // batch index (split-K launches are unbatched)
     const long wz = (long)(g.w_zmod ? zb % g.w_zmod : zb) * g.w_z;
 
@@ -111,7 +126,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm3_kernel(Gemm3Operands g, Epi
             int n = n0 + r;
             n = n < g.N ? n : g.N - 1;
             src[i] = (arr ? g.Wlo : g.Whi) + wz + (long)n * g.ldw + c * 8;
-            dst[i] = NARR * A_ARR + arr * W_ARR + rb * 1024;
+            dst[i] = NARR_A * A_ARR + arr * W_ARR + rb * 1024;
         }
     }
 
@@ -196,7 +211,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm3_kernel(Gemm3Operands g, Epi
         const int r = (wn * TN + j) * 32 + fr;
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk)
-            w_off[j][kk] = NARR * A_ARR + r * 128 + (((kk * 2 + fh) ^ ((r >> 1) & 7)) << 4);
+            w_off[j][kk] = NARR_A * A_ARR + r * 128 + (((kk * 2 + fh) ^ ((r >> 1) & 7)) << 4);
     }
 
     G3_STAMPR(152);
@@ -227,7 +242,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm3_kernel(Gemm3Operands g, Epi
 #endif
         constexpr bool LATE = G3_LATE_64 && BM == 64 && BN == 64;
         if constexpr (LATE) {
-            bf16x8 ah[4][TM], al[4][SPLIT == 3 ? TM : 1], bh[4][TN], bl[4][SPLIT == 3 ? TN : 1];
+            bf16x8 ah[4][TM], al[4][SPLIT == 3 ? TM : 1], bh[4][TN], bl[4][NARR_W == 2 ? TN : 1];
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) {
 #pragma unroll
@@ -238,7 +253,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm3_kernel(Gemm3Operands g, Epi
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
                     bh[kk][j] = *reinterpret_cast<const bf16x8*>(st + w_off[j][kk]);
-                    if (SPLIT == 3) bl[kk][j] = *reinterpret_cast<const bf16x8*>(st + w_off[j][kk] + W_ARR);
+                    if (NARR_W == 2) bl[kk][j] = *reinterpret_cast<const bf16x8*>(st + w_off[j][kk] + W_ARR);
                 }
             }
             if (kt + S - 1 < nk) issue(kt + S - 1);
@@ -253,6 +268,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm3_kernel(Gemm3Operands g, Epi
                             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[kk][i], bh[kk][j], acc[i][j], 0, 0, 0);
                             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[kk][i], bl[kk][j], acc[i][j], 0, 0, 0);
                         }
+                        if (SPLIT == PREC_F16X2) acc[i][j] = mfma16<SPLIT>(ah[kk][i], bl[kk][j], acc[i][j]);
                         acc[i][j] = mfma16<SPLIT>(ah[kk][i], bh[kk][j], acc[i][j]);
                     }
         } else {
@@ -269,7 +285,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm3_kernel(Gemm3Operands g, Epi
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
                     bh[j] = *reinterpret_cast<const bf16x8*>(st + w_off[j][kk]);
-                    if (SPLIT == 3) bl[j] = *reinterpret_cast<const bf16x8*>(st + w_off[j][kk] + W_ARR);
+                    if (NARR_W == 2) bl[j] = *reinterpret_cast<const bf16x8*>(st + w_off[j][kk] + W_ARR);
                 }
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
@@ -279,6 +295,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm3_kernel(Gemm3Operands g, Epi
                             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
                             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
                         }
+                        if (SPLIT == PREC_F16X2) acc[i][j] = mfma16<SPLIT>(ah[i], bl[j], acc[i][j]);
                         acc[i][j] = mfma16<SPLIT>(ah[i], bh[j], acc[i][j]);
                     }
             }
@@ -316,9 +333,9 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm3_kernel(Gemm3Operands g, Epi
 
 template <int BM, int BN, int WM, int WN, int SPLIT, int S, class Epi>
 static inline hipError_t gemm3_launch_cfg(const Gemm3Operands& g, const Epi& epi, int Z, hipStream_t st) {
-    constexpr int NARR = SPLIT == 3 ? 2 : 1;
-    constexpr bool DUMMY = (NARR * (BM / 8 + BN / 8)) % (WM * WN) != 0;
-    constexpr size_t lds = (size_t)S * (NARR * (BM + BN) * 128 + (DUMMY ? 1024 : 0)) + 256;  // ring (+ pads) + dummy slot of the prefetch touches
+    constexpr int NARR_A = SPLIT == 3 ? 2 : 1, NARR_W = (SPLIT == 3 || SPLIT == PREC_F16X2) ? 2 : 1;
+    constexpr bool DUMMY = (NARR_A * (BM / 8) + NARR_W * (BN / 8)) % (WM * WN) != 0;
+    constexpr size_t lds = (size_t)S * ((NARR_A * BM + NARR_W * BN) * 128 + (DUMMY ? 1024 : 0)) + 256;  // ring (+ pads) + dummy slot of the prefetch touches
     static_assert(lds <= 160 * 1024, "LDS ring exceeds 160 KiB");
     dim3 grid(((g.N + BN - 1) / BN) * ((g.M + BM - 1) / BM), 1, Z);  // 1-D tile index, remapped per XCD in-kernel
     auto kern = gemm3_kernel<BM, BN, WM, WN, SPLIT, S, Epi>;
@@ -402,7 +419,7 @@ static inline bool gemm3_ok(const Gemm3Operands& g) {
 template <int SPLIT, class Epi>
 static inline hipError_t gemm3_launch_split(const Gemm3Operands& g, const Epi& epi, int Z, int cfg, hipStream_t st) {
     extern thread_local int g_gemm3_deep;
-    if constexpr (SPLIT != 3) {
+    if constexpr (SPLIT == PREC_BF16 || SPLIT == PREC_F16) {
         // deep rings pay when the whole grid is resident at once (one latency-bound round); a grid of several rounds at the deep
         // ring's occupancy runs faster shallow with more workgroups per CU (teacher QKVG, 450 tiles of 128x128: 35.1 us deep — two
         // rounds at one workgroup per CU — against 27.5 shallow; B = 8 QKVG as 600 tiles of 64x64: 20.4 against 15.3)
@@ -444,7 +461,7 @@ static inline hipError_t gemm3_launch_split(const Gemm3Operands& g, const Epi& e
         case G3_160x128:   // (32x64 wave tiles: also valid for the paired SwiGLU epilogue)
             return gemm3_launch_cfg<160, 128, 5, 2, SPLIT, 2, Epi>(g, epi, Z, st);
         case G3_128x128_W4:
-            if constexpr (SPLIT != 3) return gemm3_launch_cfg<128, 128, 2, 2, SPLIT, 2, Epi>(g, epi, Z, st);
+            if constexpr (SPLIT == PREC_BF16 || SPLIT == PREC_F16) return gemm3_launch_cfg<128, 128, 2, 2, SPLIT, 2, Epi>(g, epi, Z, st);
             break;
     }
     return hipErrorInvalidValue;
@@ -461,8 +478,27 @@ static inline hipError_t gemm3_launch(const Gemm3Operands& g_in, const Epi& epi,
     Gemm3Operands g = g_in;
     extern int g_gemm3_stage16;
     g.stage16 = g_gemm3_stage16;
-    g.nfast = g_gemm3_nfast && (long)g.M > (long)g.N;  // the bigger operand streams, the smaller stays in L2
+    // the bigger operand streams, the smaller stays in L2 — unless the smaller one does not fit there either (> 3 MB): bands
+    extern int g_gemm3_group;
+    const double wbytes = (double)g.N * g.K * (split == PREC_BF16X3 ? 4.0 : 2.0);
+    g.nfast = g_gemm3_nfast && (long)g.M > (long)g.N ? (g_gemm3_group > 1 && wbytes > 3e6 && g.M >= 1024 ? g_gemm3_group : 1) : 0;
     if (split == PREC_BF16X3) return gemm3_launch_split<3, Epi>(g, epi, Z, cfg == G3_128x128_W4 ? G3_128x128 : cfg, st);
     if (split == PREC_F16) return gemm3_launch_split<2, Epi>(g, epi, Z, cfg, st);
     return gemm3_launch_split<1, Epi>(g, epi, Z, cfg, st);
+}
+
+// PREC_F16X2: one fp16 array of A (g.Ahi) against an fp16 hi + lo pair of W (g.Whi, g.Wlo) — two MFMA passes instead of the
+// three of split-bf16, A rounded to 11 bits, W exact to ~22.  Instantiated only where it is used (the codec's ConvTranspose
+// products, gemm3_store.hip): not part of gemm3_launch's run-time precision switch.
+template <class Epi>
+static inline hipError_t gemm3_launch_x2(const Gemm3Operands& g_in, const Epi& epi, int Z, hipStream_t st, int cfg = -1) {
+    if (g_in.M <= 0 || g_in.N <= 0) return hipSuccess;
+    if (!gemm3_ok(g_in) || !g_in.Wlo) return hipErrorInvalidValue;
+    if (cfg < 0) cfg = gemm3_pick_cfg(g_in.M, g_in.N, Epi::PAIRED, false);
+    extern int g_gemm3_nfast, g_gemm3_stage16, g_gemm3_group;
+    Gemm3Operands g = g_in;
+    g.stage16 = g_gemm3_stage16;
+    const double wbytes = (double)g.N * g.K * 4.0;
+    g.nfast = g_gemm3_nfast && (long)g.M > (long)g.N ? (g_gemm3_group > 1 && wbytes > 3e6 && g.M >= 1024 ? g_gemm3_group : 1) : 0;
+    return gemm3_launch_split<PREC_F16X2, Epi>(g, epi, Z, cfg == G3_128x128_W4 ? G3_128x128 : cfg, st);
 }

@@ -15,6 +15,13 @@ hipError_t gemm3_store(const Gemm3Operands& g, int act, const EpiStore<ACT_NONE>
     return hipErrorInvalidValue;
 }
 
+// PREC_F16X2 (gemm3_launch_x2): fp32 store epilogue only — the codec's ConvTranspose-as-GEMM products
+hipError_t gemm3_store_x2(const Gemm3Operands& g, const EpiStore<ACT_NONE>& p, hipStream_t st, int cfg) {
+    ProfScope ps(st, gemm3_prof_name(g, false, cfg < 0 ? gemm3_pick_cfg(g.M, g.N, false, false) : cfg, PREC_F16X2, "store"), gemm3_flops(g, 1),
+                 (double)g.M * g.K * 2.0 + (double)g.N * g.K * 4.0 + (double)g.M * g.N * 4.0, gemm_bytes8d(g.N, g.K, 1));
+    return gemm3_launch_x2(g, p, 1, st, cfg);
+}
+
 #ifdef G3_TIMELINE   // debug build only (tools/gemm3_timeline.py): the k-tile stamps of this translation unit's gemm3 instantiations
 extern "C" int smtts_debug_read_timeline(unsigned long long* host, int n) {
     return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g3_tl_buf), (size_t)n * 8);

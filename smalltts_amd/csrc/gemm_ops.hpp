@@ -55,6 +55,7 @@ static inline double gemm3_bytes(const Gemm3Operands& g, int Z, int split, doubl
 // SURVEY 8(d) bytes of a GEMM launch: the weights once at 2 B / parameter ("bf16 weights read once per use, activations negligible")
 static inline double gemm_bytes8d(int N, int K, int Z, bool w_shared = false) { return (double)N * K * 2.0 * (w_shared ? 1 : Z); }
 hipError_t gemm3_store(const Gemm3Operands& g, int act, const EpiStore<ACT_NONE>& p, int Z, int split, hipStream_t st, int cfg = -1);
+hipError_t gemm3_store_x2(const Gemm3Operands& g, const EpiStore<ACT_NONE>& p, hipStream_t st, int cfg = -1);   // PREC_F16X2: A = g.Ahi (fp16), W = g.Whi + g.Wlo (fp16 pair)
 hipError_t gemm3_swiglu(const Gemm3Operands& g, const EpiSwiGLU& p, int split, hipStream_t st);
 hipError_t gemm3_resid(const Gemm3Operands& g, int gate_mode, const EpiResid<0>& p, int split, hipStream_t st, int cfg = -1);
 hipError_t gemm3_kv(const Gemm3Operands& g, const EpiKV& p, int split, hipStream_t st);

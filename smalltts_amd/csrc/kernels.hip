@@ -377,6 +377,23 @@ hipError_t launch_split_rows(const float* src, long src_ld, bf16_t* hi, bf16_t* 
     LAUNCH_CHECK();
 }
 
+// l16 = fp16(src - float(h16)): the low half of an fp16 hi + lo weight pair (PREC_F16X2); h16 holds fp16(src) already
+__global__ void f16_residual_kernel(const float* __restrict__ src, long src_ld, const bf16_t* __restrict__ h16, bf16_t* __restrict__ l16,
+                                    long dst_ld, int rows, int cols) {
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)rows * cols) return;
+    const int r = (int)(i / cols), c = (int)(i % cols);
+    const long o = (long)r * dst_ld + c;
+    const float hi = (float)reinterpret_cast<const half_t*>(h16)[o];
+    reinterpret_cast<half_t*>(l16)[o] = (half_t)(src[(long)r * src_ld + c] - hi);
+}
+hipError_t launch_f16_residual(const float* src, long src_ld, const bf16_t* h16, bf16_t* l16, long dst_ld, int rows, int cols, hipStream_t st) {
+    const long n = (long)rows * cols;
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(f16_residual_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, src, src_ld, h16, l16, dst_ld, rows, cols);
+    LAUNCH_CHECK();
+}
+
 __global__ void fill_kernel(float* __restrict__ p, float v, long n) {
     long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) p[i] = v;

@@ -17,7 +17,8 @@ from .weights import (DEFAULT_CODEC, CodecSpec, codec_decoder_param_specs, codec
 
 N_LAYERS, N_HEADS, HEAD_DIM, LATENT = 12, 8, 120, 64
 ACT = {"none": 0, "silu": 1, "gelu": 2, "mish": 3}
-PRECISION = {"bf16x3": 3, "f16": 2, "bf16": 1}   # presets of smtts_set_precision (include/smalltts_hip.h)
+PRECISION = {"bf16x3": 3, "f16": 2, "bf16": 1,   # presets of smtts_set_precision (include/smalltts_hip.h)
+             "f16x2": 4}                          # site value only (codec_conv): fp16 activations x fp16 hi + lo weights, two MFMA passes
 SITES = {"dit_block": 0, "encoder": 1, "cross_kv": 2, "cond": 3, "codec_ffn": 4, "codec_conv": 5, "convpos": 6, "attn": 7}
 DEFAULT_PRECISION = "f16"
 

@@ -139,7 +139,7 @@ def test_default_precision_codec_decode_and_ladder(eng, golden_seed):
         assert s > SNR_F16, f"utterance {b}: decode SNR {s:.1f} dB at the default precision"
     rows = []
     try:
-        for p in ("f16", "f16,codec_conv=f16", "bf16x3,codec_ffn=f16", "bf16x3", "bf16"):
+        for p in ("f16", "f16,codec_conv=f16x2", "f16,codec_conv=f16", "bf16x3,codec_ffn=f16", "bf16x3", "bf16"):
             eng.set_precision(p)
             rows.append((p, snr_db(eng.codec_decode(lat[:1]).cpu().numpy(), refs[0])))
     finally:
