@@ -1538,9 +1538,7 @@ int Engine::codec_decode(hipStream_t st, const float* latents, int B, int T, flo
     float* xn = w.xb;
     int Ti = T;
     int C = dec_.stages[0].C;
-    HIPC(launch_zero_pad_frames(x, B, Ti, C, pad, st));
-    HIPC(launch_zero_pad_frames(xn, B, Ti, C, pad, st));
-    HIPC(launch_zero_pad_frames(w.nb, B, Ti, C, pad, st));
+    HIPC(launch_zero_pad_frames3(x, xn, w.nb, B, Ti, C, pad, st));
     {
         RowMap am = rowmap_batched(L, Ti, (long)(pad + Ti) * L, (long)(pad - (Kc - 1)) * L);
         RowMap om = rowmap_batched(C, Ti, (long)(pad + Ti) * C, (long)pad * C);
@@ -1553,8 +1551,6 @@ int Engine::codec_decode(hipStream_t st, const float* latents, int B, int T, flo
         if (i > 0) {
             // ConvTranspose1d(k = 2r, stride r), causal trim: rows (x[t-1], x[t]) -> r output frames
             const int r = sg.r, Cn = sg.C, Tn = Ti * r;
-            HIPC(launch_zero_pad_frames(xn, B, Tn, Cn, pad, st));
-            HIPC(launch_zero_pad_frames(w.nb, B, Tn, Cn, pad, st));
             RowMap am = rowmap_batched(C, Ti, (long)(pad + Ti) * C, (long)(pad - 1) * C);
             RowMap om = rowmap_batched((long)r * Cn, Ti, (long)(pad + Tn) * Cn, (long)pad * Cn);
             if (fused_ffn_ && codec_upsample_wave_ok(sg.resample.K, sg.resample.N) && sg.resample.K == 2 * C && sg.resample.N == r * Cn)
@@ -1580,7 +1576,9 @@ int Engine::codec_decode(hipStream_t st, const float* latents, int B, int T, flo
             float* t = x; x = xn; xn = t;
             Ti = Tn;
             C = Cn;
-            HIPC(launch_zero_pad_frames(xn, B, Ti, C, pad, st));  // the ping-pong partner needs zero pads at this geometry too
+            // zero pads of the three images at the new geometry, in one launch BEHIND the product: it writes data rows only, and its
+            // input (now the ping-pong partner) is free to be overwritten from here on
+            HIPC(launch_zero_pad_frames3(x, xn, w.nb, B, Ti, C, pad, st));
         }
         for (const CodecBlockW& b : sg.blocks)
             if (codec_block(st, b, &x, &xn, w.nb, w.n2hi, w.n2lo, w.hhi, w.hlo, B, Ti, C, max_img)) return 1;
@@ -1658,9 +1656,7 @@ int Engine::codec_encode(hipStream_t st, const float* audio, int B, int S_, floa
         if (e != hipSuccess) { fail_hip(e, "codec_encode: split-K conv"); conv_err = true; }
         return true;
     };
-    HIPC(launch_zero_pad_frames(x, B, Ti, C, pad, st));
-    HIPC(launch_zero_pad_frames(xn, B, Ti, C, pad, st));
-    HIPC(launch_zero_pad_frames(w.nb, B, Ti, C, pad, st));
+    HIPC(launch_zero_pad_frames3(x, xn, w.nb, B, Ti, C, pad, st));
     HIPC(launch_stem_conv1(audio, enc_.stem_w_raw, enc_.stem_b, x, B, Ti, C, Kc, pad, st));
     static const char* kEncTags[] = {"cenc.s0", "cenc.s1", "cenc.s2", "cenc.s3", "cenc.s4", "cenc.s5", "cenc.s6", "cenc.s7"};
     for (int i = 0; i < S; ++i) {
@@ -1669,8 +1665,6 @@ int Engine::codec_encode(hipStream_t st, const float* audio, int B, int S_, floa
         if (i > 0) {
             // Conv1d(k = 2r, stride r), causal left pad r: out[t] reads frames [(t-1) r, (t+1) r)
             const int r = sg.r, Cn = sg.C, Tn = Ti / r;
-            HIPC(launch_zero_pad_frames(xn, B, Tn, Cn, pad, st));
-            HIPC(launch_zero_pad_frames(w.nb, B, Tn, Cn, pad, st));
             RowMap am = rowmap_batched((long)r * C, Tn, (long)(pad + Ti) * C, (long)(pad - r) * C);
             RowMap om = rowmap_batched(Cn, Tn, (long)(pad + Tn) * Cn, (long)pad * Cn);
             if (!conv_small_m(x, (long)B * (pad + Ti), C, am, sg.resample, sg.resample_bias, xn, om, B * Tn))
@@ -1679,7 +1673,7 @@ int Engine::codec_encode(hipStream_t st, const float* audio, int B, int S_, floa
             float* t = x; x = xn; xn = t;
             Ti = Tn;
             C = Cn;
-            HIPC(launch_zero_pad_frames(xn, B, Ti, C, pad, st));
+            HIPC(launch_zero_pad_frames3(x, xn, w.nb, B, Ti, C, pad, st));   // (behind the product, as in the decoder)
         }
         for (const CodecBlockW& b : sg.blocks)
             if (codec_block(st, b, &x, &xn, w.nb, w.n2hi, w.n2lo, w.hhi, w.hlo, B, Ti, C, max_img)) return 1;

@@ -657,6 +657,22 @@ __global__ void zero_pad_frames_kernel(float* __restrict__ x, int B, int T, int 
     long o = i % per;
     x[(long)b * (pad + T) * C + o] = 0.f;
 }
+// the same pads of up to three images of one geometry in one launch (blockIdx.y picks the image)
+__global__ void zero_pad_frames3_kernel(float* __restrict__ x0, float* __restrict__ x1, float* __restrict__ x2, int B, int T, int C, int pad) {
+    float* x = blockIdx.y == 0 ? x0 : blockIdx.y == 1 ? x1 : x2;
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    long per = (long)pad * C;
+    if (i >= (long)B * per) return;
+    int b = (int)(i / per);
+    long o = i % per;
+    x[(long)b * (pad + T) * C + o] = 0.f;
+}
+hipError_t launch_zero_pad_frames3(float* x0, float* x1, float* x2, int B, int T, int C, int pad, hipStream_t st) {
+    long n = (long)B * pad * C;
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(zero_pad_frames3_kernel, dim3((unsigned)((n + 255) / 256), x2 ? 3 : 2), dim3(256), 0, st, x0, x1, x2, B, T, C, pad);
+    LAUNCH_CHECK();
+}
 hipError_t launch_zero_pad_frames(float* x, int B, int T, int C, int pad, hipStream_t st) {
     long n = (long)B * pad * C;
     if (n == 0) return hipSuccess;

@@ -149,6 +149,7 @@ hipError_t launch_head_conv(const float* x, const float* w, float bias, float* a
 hipError_t launch_stem_conv1(const float* audio, const float* w, const float* bias, float* x, int B, int T, int C,
                              int K, int pad, hipStream_t st);
 hipError_t launch_zero_pad_frames(float* x, int B, int T, int C, int pad, hipStream_t st);
+hipError_t launch_zero_pad_frames3(float* x0, float* x1, float* x2 /* may be null */, int B, int T, int C, int pad, hipStream_t st);
 
 // Fused codec FFN block for C in {32, 64, 128}: x += gamma * (W2 gelu(W1 rmsnorm(x) + b1) + b2), hidden kept in LDS.
 // w1 packed [F][CP], w2 packed [CP][F] with CP = max(C, 64) (zero padded).  (codec_ffn.hip)
