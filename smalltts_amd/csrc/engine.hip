@@ -58,6 +58,7 @@ Engine::Engine(int device) : device_(device) {
     if ((s = getenv("SMTTS_ATTN_EPI"))) attn_epi_ = atoi(s) != 0;
     if ((s = getenv("SMTTS_ATTN_IMG"))) attn_img_ = atoi(s) != 0;
     if ((s = getenv("SMTTS_UP_G3_MINK")) && atoi(s) >= 64) up_g3_mink_ = atoi(s);
+    if ((s = getenv("SMTTS_MIXER_WIDE"))) mixer_wide_ = atoi(s) != 0;
     if ((s = getenv("SMTTS_X2_MINK")) && atoi(s) >= 64) x2_mink_ = atoi(s);
     if ((s = getenv("SMTTS_X2_MAXK")) && atoi(s) >= 64) x2_maxk_ = atoi(s);
     if ((s = getenv("SMTTS_KSPLIT_OUT")) && atoi(s) >= 1 && atoi(s) <= kSplitK) ksplit_out_ = atoi(s);
@@ -1396,6 +1397,14 @@ int Engine::codec_block(hipStream_t st, const CodecBlockW& w, float** xp, float*
         *xp = *xaltp;
         *xaltp = x;
         x = *xp;
+    } else if (fused_ffn_ && mixer_wide_ && mixer_wide_ok(C, cspec_.kernel) && F % 64 == 0 && (size_t)M * C <= n2_elems) {
+        // wide stages: mixer + the FFN's RMSNorm in one out-of-place pass (no normalised fp32 image in between), then swap images
+        HIPC(launch_mixer_wide(x, *xaltp, w.norm_w, w.dw_w, w.dw_b, w.gamma, w.ffn_norm_w, n2hi, n2lo_f, B, T, C, cspec_.kernel, pad,
+                               cspec_.eps, st));
+        *xp = *xaltp;
+        *xaltp = x;
+        x = *xp;
+        n2_done = true;
     } else {
         HIPC(launch_rmsnorm(x, img, nbuf, nullptr, nullptr, img, M, C, cspec_.eps, w.norm_w, st));
         if (fused_ffn_ && C % 64 == 0 && F % 64 == 0 && C <= 2048) {  // + the FFN's RMSNorm of the updated rows (split pair n2)

@@ -229,6 +229,7 @@ class Engine {
     int prec_[SITE_COUNT] = {3, 3, 3, 3, 3, 3, 3, 3};
     bool fused_ffn_ = true;  // test hook: smtts_test_set_fused_ffn
     bool block_wave_ = true;  // codec stages with C = 32 / 64: mixer + FFN in one kernel (SMTTS_BLOCK_WAVE=0: mixer_fused + codec_ffn_wave)
+    bool mixer_wide_ = true;   // codec blocks of the wide stages: mixer + FFN norm in one pass (SMTTS_MIXER_WIDE=0: rmsnorm + dwconv_resid_rms)
     int x2_mink_ = 512, x2_maxk_ = 1024;   // PREC_F16X2 on SITE_CODEC_CONV: the ConvTranspose stages with K in this range (SMTTS_X2_MINK / _MAXK)
     int up_g3_mink_ = 2048;  // codec ConvTranspose-as-GEMM: gemm3 on a converted copy of the image from this K up (SMTTS_UP_G3_MINK; below: fp32-A kernel)
     int ksplit_enc_ = 4;  // split-K of the encoders' residual projections (1 = fused-epilogue GEMM + separate RMSNorm)

@@ -980,6 +980,165 @@ __global__ __launch_bounds__(256) void mixer_fused_kernel(const float* __restric
         reinterpret_cast<float4*>(xout + img0 + (long)(t + H) * C)[c4] = xv;
     }
 }
+// The same mixer for the WIDE stages (C = 512 / 1024 / 2048), plus the FFN's RMSNorm of the updated rows: one pass over the image
+//     x_mid = x + gamma * (norm_w * conv7(x * rstd(x)) + dw_b)            -> xout (fp32 image, out of place)
+//     n2    = x_mid * rstd(x_mid) * ffn_norm_w                            -> 16-bit operand rows of the first FFN product
+// instead of rmsnorm (x -> fp32 normalised image) + dwconv_resid_rms (reads both): the normalised image (one write + one read of
+// the stage's rows) and a launch per block go.  A workgroup stages TT + 6 raw frames of one utterance in LDS, computes their
+// rstd (one wave per frame), then every thread owns 4 * CPT channels: conv over the seven staged rows, residual, partial sums of
+// squares per output frame (reduced over the waves that share a frame through LDS), and the two stores.  All global loads of the
+// tile are issued before the first use; stores only after the last load (shared vmcnt).
+template <int C, int TT>
+__global__ __launch_bounds__(256) void mixer_wide_kernel(const float* __restrict__ xin, float* __restrict__ xout,
+                                                         const float* __restrict__ norm_w, const float* __restrict__ w,
+                                                         const float* __restrict__ bias, const float* __restrict__ gamma,
+                                                         const float* __restrict__ ffn_norm_w, bf16_t* __restrict__ n2hi,
+                                                         bf16_t* __restrict__ n2lo, int T, int pad, float eps, int tiles_per_b) {
+    constexpr int C4 = C / 4, H = 6, NF = TT + H;
+    constexpr int LPR = C4 < 256 ? C4 : 256;   // threads that share a frame
+    constexpr int FPP = 256 / LPR;             // frames worked on in parallel
+    constexpr int CPT = C4 / LPR;              // float4 channel groups per thread
+    constexpr int FT = TT / FPP;               // output frames per thread
+    constexpr int NI = (NF * C4 + 255) / 256;  // staging loads per thread
+    constexpr int WPF = LPR / 64;              // waves that share a frame
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* xs = sm;                    // [NF][C] raw frames
+    float* rs = sm + (size_t)NF * C;   // [NF] rstd of the raw frames
+    float* red = rs + NF;              // [TT][WPF] partial sums of squares of the updated frames
+    const int b = blockIdx.x / tiles_per_b, t0 = (blockIdx.x % tiles_per_b) * TT;
+    const int nout = T - t0 < TT ? T - t0 : TT, nfr = nout + H;
+    const long img0 = ((long)b * (pad + T) + pad + t0 - H) * C;  // first halo frame (inside the zero pad for t0 = 0)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    {
+        float4 stg[NI];
+#pragma unroll
+        for (int it = 0; it < NI; ++it) {
+            const int i = it * 256 + tid, f = i / C4, c4 = i % C4;
+            stg[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (f < nfr) stg[it] = reinterpret_cast<const float4*>(xin + img0 + (long)f * C)[c4];
+        }
+#pragma unroll
+        for (int it = 0; it < NI; ++it) {
+            const int i = it * 256 + tid, f = i / C4, c4 = i % C4;
+            if (f < nfr) reinterpret_cast<float4*>(xs + (size_t)f * C)[c4] = stg[it];
+        }
+    }
+    // per-thread constants (loaded while the tile settles)
+    const int cg = tid % LPR, fsel = tid / LPR;
+    float4 wv[CPT][7], g[CPT], bb[CPT], gm[CPT], w2[CPT];
+#pragma unroll
+    for (int j = 0; j < CPT; ++j) {
+        const int c4 = cg + j * LPR;
+#pragma unroll
+        for (int k = 0; k < 7; ++k) wv[j][k] = reinterpret_cast<const float4*>(w)[(long)k * C4 + c4];
+        g[j] = reinterpret_cast<const float4*>(norm_w)[c4];
+        bb[j] = reinterpret_cast<const float4*>(bias)[c4];
+        gm[j] = reinterpret_cast<const float4*>(gamma)[c4];
+        w2[j] = reinterpret_cast<const float4*>(ffn_norm_w)[c4];
+    }
+    __syncthreads();
+    for (int f = wave; f < nfr; f += 4) {   // rstd of the staged frames: one wave per frame
+        float ss = 0.f;
+        for (int c4 = lane; c4 < C4; c4 += 64) {
+            const float4 v = reinterpret_cast<const float4*>(xs + (size_t)f * C)[c4];
+            ss += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
+        if (lane == 0) rs[f] = 1.0f / sqrtf(ss / (float)C + eps);
+    }
+    __syncthreads();
+    float4 xv[FT][CPT];
+    float ssp[FT];
+#pragma unroll
+    for (int ti = 0; ti < FT; ++ti) {
+        const int t = fsel + ti * FPP;
+        ssp[ti] = 0.f;
+        if (t < nout) {
+            float r[7];
+#pragma unroll
+            for (int k = 0; k < 7; ++k) r[k] = rs[t + k];
+#pragma unroll
+            for (int j = 0; j < CPT; ++j) {
+                const int c4 = cg + j * LPR;
+                float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int k = 0; k < 7; ++k) {
+                    const float4 u = reinterpret_cast<const float4*>(xs + (size_t)(t + k) * C)[c4];
+                    acc.x += wv[j][k].x * r[k] * u.x; acc.y += wv[j][k].y * r[k] * u.y;
+                    acc.z += wv[j][k].z * r[k] * u.z; acc.w += wv[j][k].w * r[k] * u.w;
+                }
+                float4 v = reinterpret_cast<const float4*>(xs + (size_t)(t + H) * C)[c4];
+                v.x += gm[j].x * (g[j].x * acc.x + bb[j].x); v.y += gm[j].y * (g[j].y * acc.y + bb[j].y);
+                v.z += gm[j].z * (g[j].z * acc.z + bb[j].z); v.w += gm[j].w * (g[j].w * acc.w + bb[j].w);
+                xv[ti][j] = v;
+                ssp[ti] += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+            }
+        }
+    }
+#pragma unroll
+    for (int ti = 0; ti < FT; ++ti) {
+        float ss = ssp[ti];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
+        if (lane == 0) red[(fsel + ti * FPP) * WPF + (wave % WPF)] = ss;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int ti = 0; ti < FT; ++ti) {
+        const int t = fsel + ti * FPP;
+        if (t < nout) {
+            float ss = 0.f;
+#pragma unroll
+            for (int q = 0; q < WPF; ++q) ss += red[t * WPF + q];
+            const float r2 = 1.0f / sqrtf(ss / (float)C + eps);
+            const long row = (long)b * T + t0 + t;
+#pragma unroll
+            for (int j = 0; j < CPT; ++j) {
+                const int c4 = cg + j * LPR;
+                const float4 v = xv[ti][j];
+                reinterpret_cast<float4*>(xout + img0 + (long)(t + H) * C)[c4] = v;
+                store_split4(n2hi, n2lo, row * C + c4 * 4,
+                             make_float4(v.x * r2 * w2[j].x, v.y * r2 * w2[j].y, v.z * r2 * w2[j].z, v.w * r2 * w2[j].w));
+            }
+        }
+    }
+}
+bool mixer_wide_ok(int C, int K) { return K == 7 && (C == 512 || C == 1024 || C == 2048); }
+hipError_t launch_mixer_wide(const float* xin, float* xout, const float* norm_w, const float* w, const float* bias, const float* gamma,
+                             const float* ffn_norm_w, bf16_t* n2hi, bf16_t* n2lo, int B, int T, int C, int K, int pad, float eps,
+                             hipStream_t st) {
+    if (!mixer_wide_ok(C, K) || pad < K - 1 || xin == xout || !n2hi) return hipErrorInvalidValue;
+    if ((long)B * T == 0) return hipSuccess;
+    ProfScope ps(st, "mixer_wide", 2.0 * B * T * C * (K + 7), 10.0 * B * T * C);
+    // Frames per tile: SMALL tiles win — the phases of a workgroup (load, rstd, conv, reduce, store) are serial, so the CU needs
+    // several workgroups to overlap them, and the halo re-reads (6 frames per tile) are L2 hits.  Measured, us per launch at
+    // TT = 32 / 16 / 8 / 4 (profiles/r03z_*): C = 512 (24000 rows) 68.6 / 38.5 / 36.3 / 40.2; C = 1024 (4800 rows) - / 42.4 /
+    // 27.4 / 23.8; C = 2048 (600 rows) - / - / 18.0 / 13.7 — against 64.2 / 37.8 / 23.7 for the two kernels this replaces.
+#define MW_GO(CC, TT)                                                                                                              \
+    do {                                                                                                                           \
+        constexpr int WPF = ((CC) / 4 < 256 ? (CC) / 4 : 256) / 64;                                                                \
+        const size_t lds = ((size_t)((TT) + 6) * (CC) + ((TT) + 6) + (size_t)(TT) * WPF) * sizeof(float);                          \
+        auto kern = mixer_wide_kernel<CC, TT>;                                                                                     \
+        static DevOnce once;                                                                                                       \
+        hipError_t e = once.ensure([&] {                                                                                           \
+            return hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        });                                                                                                                        \
+        if (e != hipSuccess) return e;                                                                                             \
+        const int tiles = (T + (TT) - 1) / (TT);                                                                                   \
+        hipLaunchKernelGGL(kern, dim3((unsigned)(B * tiles)), dim3(256), lds, st, xin, xout, norm_w, w, bias, gamma, ffn_norm_w,   \
+                           n2hi, n2lo, T, pad, eps, tiles);                                                                        \
+    } while (0)
+    static const int tt512 = getenv("SMTTS_MW_TT512") ? atoi(getenv("SMTTS_MW_TT512")) : 8;
+    static const int tt1024 = getenv("SMTTS_MW_TT1024") ? atoi(getenv("SMTTS_MW_TT1024")) : 4;
+    static const int tt2048 = getenv("SMTTS_MW_TT2048") ? atoi(getenv("SMTTS_MW_TT2048")) : 4;
+    if (C == 2048) { if (tt2048 == 4) MW_GO(2048, 4); else MW_GO(2048, 8); }
+    else if (C == 1024) { if (tt1024 == 4) MW_GO(1024, 4); else if (tt1024 == 8) MW_GO(1024, 8); else MW_GO(1024, 16); }
+    else { if (tt512 == 4) MW_GO(512, 4); else if (tt512 == 8) MW_GO(512, 8); else if (tt512 == 16) MW_GO(512, 16); else MW_GO(512, 32); }
+#undef MW_GO
+    LAUNCH_CHECK();
+}
+
 hipError_t launch_mixer_fused(const float* xin, float* xout, const float* norm_w, const float* w, const float* bias,
                               const float* gamma, int B, int T, int C, int K, int pad, float eps, hipStream_t st) {
     if (C % 4 || C > 256 || (256 % (C / 4)) || pad < K - 1 || xin == xout || K > 7) return hipErrorInvalidValue;

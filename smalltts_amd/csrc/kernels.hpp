@@ -139,6 +139,11 @@ hipError_t launch_rope_cossin(const float* ang, float* c, float* s, int n, hipSt
 hipError_t launch_dwconv_resid(float* x, const float* n, const float* w, const float* bias, const float* gamma,
                                int B, int T, int C, int K, int pad, hipStream_t st);
 // dwconv_resid + the RMSNorm (weight norm_w) of the updated rows written as a split bf16 pair (the next GEMM's A operand)
+// wide-stage codec mixer + the FFN's RMSNorm in one pass (kernels.hip mixer_wide_kernel): xin -> xout (another image), n2 = 16-bit rows [B*T][C]
+bool mixer_wide_ok(int C, int K);
+hipError_t launch_mixer_wide(const float* xin, float* xout, const float* norm_w, const float* w, const float* bias, const float* gamma,
+                             const float* ffn_norm_w, bf16_t* n2hi, bf16_t* n2lo, int B, int T, int C, int K, int pad, float eps,
+                             hipStream_t st);
 hipError_t launch_dwconv_resid_rms(float* x, const float* n, const float* w, const float* bias, const float* gamma, int B, int T,
                                    int C, int K, int pad, float eps, const float* norm_w, bf16_t* yhi, bf16_t* ylo, RowMap ymap,
                                    hipStream_t st);
