@@ -504,6 +504,7 @@ static hipError_t ffn_stream_go(const FfnStreamArgs& a, hipStream_t st) {
         return hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     }, &cus);
     if (e != hipSuccess) return e;
+    { extern int g_persist_mask; if (!(g_persist_mask & 1)) cus = once.real_cus(); }   // (A/B: which persistent kernels the throughput-mode grid cap applies to)
     const int npass = (a.M + NW * 32 - 1) / (NW * 32);
     // NW = 4 (one wave per SIMD per workgroup): two workgroups share a CU when the ring is small enough — their steps drift
     // freely against each other, only the four waves of one ring meet at its barrier

@@ -565,6 +565,7 @@ static hipError_t ffn_wave_go(const FfnWaveArgs& a, hipStream_t st) {
         return hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     }, &cus);
     if (e != hipSuccess) return e;
+    { extern int g_persist_mask; if (!(g_persist_mask & 2)) cus = once.real_cus(); }   // (A/B: which persistent kernels the throughput-mode grid cap applies to)
     const int ntiles = (a.M + 31) / 32;
     // persistent: as many workgroups as fit (LDS, and 32 waves per CU), each wave walks tiles
     int per_cu = (int)((160 * 1024) / lds);

@@ -152,6 +152,7 @@ hipError_t upsample_go(const UpsampleArgs& a, hipStream_t st) {
         return hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     }, &cus);
     if (e != hipSuccess) return e;
+    { extern int g_persist_mask; if (!(g_persist_mask & 4)) cus = once.real_cus(); }   // (A/B: which persistent kernels the throughput-mode grid cap applies to)
     const int ntiles = (a.M + 31) / 32;
     const int per_cu = lds * 2 <= 160 * 1024 ? 2 : 1;
     int grid = (ntiles + 7) / 8;

@@ -31,9 +31,13 @@ struct DevOnce {
             cus[dev] = n;
             mask.fetch_or(1u << dev, std::memory_order_release);
         }
-        if (cu_out) *cu_out = cus[dev];
+        if (cu_out) {
+            extern thread_local int g_persist_cus;   // engine.hip: cap on the grid of the persistent codec kernels (0 = every CU), installed per codec call
+            *cu_out = g_persist_cus > 0 && g_persist_cus < cus[dev] ? g_persist_cus : cus[dev];
+        }
         return hipSuccess;
     }
+    int real_cus() const { int dev = 0; (void)hipGetDevice(&dev); return cus[dev & 15]; }   // (after ensure) the device's CU count, uncapped
 };
 
 // Row addressing shared by GEMM operands/outputs: logical row m -> element offset.

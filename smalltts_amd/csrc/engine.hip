@@ -33,6 +33,12 @@ thread_local int g_gemm3_deep = 1;   // gemm3 ring depth for single-array operan
 namespace { struct DeepScope { int prev; explicit DeepScope(int v) : prev(g_gemm3_deep) { g_gemm3_deep = v; } ~DeepScope() { g_gemm3_deep = prev; } }; }
 int g_gemm3_w4_minm = 0;  // gemm3: 4-wave 128x128 tiles (wave 64x64) for single-array products with M >= this and N >= 2048 (SMTTS_GEMM_W4_MINM; 0 = off)
 int g_gemm3_stage16 = 1;  // gemm3: 16-bit outputs through the LDS-staged epilogue (SMTTS_GEMM_STAGE16=0: scalar stores)
+// Persistent codec kernels (streamed / one-pass FFN, upsample): workgroups launched at most (0 = one per CU).  A persistent grid
+// that covers every CU keeps all other streams' kernels out until it ends; with several batches in flight (throughput tuning) it
+// leaves a quarter of the CUs to them (Engine::persist_cus_, installed per codec call like the ring depth).
+thread_local int g_persist_cus = 0;
+int g_persist_mask = 7;   // 1 streamed FFN, 2 one-pass / wave FFN, 4 upsample (SMTTS_PERSIST_MASK)
+namespace { struct PersistScope { int prev; explicit PersistScope(int v) : prev(g_persist_cus) { g_persist_cus = v; } ~PersistScope() { g_persist_cus = prev; } }; }
 int g_gemm_xcd = 1;     // fp32-A GEMM: XCD-aware tile order for unbatched launches (SMTTS_GEMM_XCD=0: plain blockIdx mapping)
 int g_gemm3_group = 4;  // gemm3 tile order when neither operand fits an XCD's L2: bands of this many row tiles (SMTTS_GEMM_GROUP=1: plain N fastest)
 int g_gemm3_nfast = 1;  // gemm3 tile order: N fastest when M > N (SMTTS_GEMM_NFAST=0 restores M fastest everywhere)
@@ -46,6 +52,8 @@ Engine::Engine(int device) : device_(device) {
     if (const char* nf = getenv("SMTTS_GEMM_NFAST")) g_gemm3_nfast = atoi(nf);
     if (const char* gg = getenv("SMTTS_GEMM_GROUP")) g_gemm3_group = atoi(gg);
     if (const char* gx = getenv("SMTTS_GEMM_XCD")) g_gemm_xcd = atoi(gx);
+    if (const char* pc = getenv("SMTTS_PERSIST_CUS")) persist_cus_tp_ = atoi(pc);
+    if (const char* pm = getenv("SMTTS_PERSIST_MASK")) g_persist_mask = atoi(pm);
     if (const char* dp = getenv("SMTTS_GEMM_DEEP")) gemm_deep_ = atoi(dp);
     if (const char* s16 = getenv("SMTTS_GEMM_STAGE16")) g_gemm3_stage16 = atoi(s16);
     if (const char* w4 = getenv("SMTTS_GEMM_W4_MINM")) g_gemm3_w4_minm = atoi(w4);
@@ -66,6 +74,9 @@ Engine::Engine(int device) : device_(device) {
     if ((s = getenv("SMTTS_KSPLIT_FF2")) && atoi(s) >= 1 && atoi(s) <= kSplitK) ksplit_ff2_ = atoi(s);
     int cus = 0;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) num_cus_ = cus;
+    // three quarters of the CUs, in whole rounds of the 32 shader engines the dispatcher deals workgroups to (measured in flight,
+    // ms per batch at 256 / 224 / 208 / 192 / 176 / 160 / 128 workgroups: 8.62 / 8.46 / 8.55 / 8.41 / 8.49 / 8.44 / 8.54)
+    if (!getenv("SMTTS_PERSIST_CUS")) persist_cus_tp_ = num_cus_ >= 64 ? num_cus_ * 3 / 4 / 32 * 32 : 0;
 }
 
 void Engine::set_tuning(int mode) {
@@ -74,9 +85,11 @@ void Engine::set_tuning(int mode) {
         tuning_ = TUNE_THROUGHPUT;
         dual_stream_ = false;
         gemm_deep_ = 0;
+        persist_cus_ = persist_cus_tp_;
     } else {
         if (tuning_ == TUNE_THROUGHPUT) dual_stream_ = dual_stream_latency_;
         tuning_ = TUNE_LATENCY;
+        persist_cus_ = 0;
         gemm_deep_ = getenv("SMTTS_GEMM_DEEP") ? atoi(getenv("SMTTS_GEMM_DEEP")) : 1;
     }
 }
@@ -1515,6 +1528,7 @@ size_t Engine::decode_ws_bytes(int B, int T) const {
 
 int Engine::codec_decode(hipStream_t st, const float* latents, int B, int T, float* audio, void* ws, size_t ws_bytes) {
     DeepScope deep_scope(gemm_deep_);
+    PersistScope persist_scope(persist_cus_);
     if (!dec_.ready) return fail("codec_decode: decoder weights not finalized");
     if (ws_bytes < decode_ws_bytes(B, T)) return fail("codec_decode: workspace too small");
     HIPC(hipSetDevice(device_));
@@ -1622,6 +1636,7 @@ size_t Engine::encode_ws_bytes(int B, int S_) const {
 
 int Engine::codec_encode(hipStream_t st, const float* audio, int B, int S_, float* latents, void* ws, size_t ws_bytes) {
     DeepScope deep_scope(gemm_deep_);
+    PersistScope persist_scope(persist_cus_);
     if (!enc_.ready) return fail("codec_encode: encoder weights not finalized");
     if (ws_bytes < encode_ws_bytes(B, S_)) return fail("codec_encode: workspace too small");
     HIPC(hipSetDevice(device_));

@@ -224,6 +224,8 @@ class Engine {
     bool packing_ = false;
     int tuning_ = TUNE_LATENCY;
     int gemm_deep_ = 1;   // gemm3 ring depth of this engine's launches (1 deep: latency tuning, 0 shallow: throughput); installed per operator call (DeepScope)
+    int persist_cus_ = 0;        // grid cap of the persistent codec kernels for this engine's calls (0 = one workgroup per CU): 0 under latency tuning,
+    int persist_cus_tp_ = 192;   // this under throughput tuning (SMTTS_PERSIST_CUS; profiles/r03ac_*, r03ad_*)
     bool dual_stream_latency_ = true;  // the dual-stream setting that TUNE_LATENCY restores
     int preset_ = kDefaultPrecision;   // set_precision(kDefaultPrecision) in the constructor fills prec_
     int prec_[SITE_COUNT] = {3, 3, 3, 3, 3, 3, 3, 3};
