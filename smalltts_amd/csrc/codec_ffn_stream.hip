@@ -16,6 +16,8 @@
 #include "prof.hpp"
 #include <type_traits>
 
+extern int g_persist_mask;   // engine.hip: which persistent kernels the throughput-mode grid cap applies to (1 streamed FFN, 2 one-pass / wave FFN, 4 upsample)
+
 typedef float f32x2s __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
 // (a, b) -> packed bf16 pair in one v_cvt_pk_bf16_f32; split_pair also returns the packed bf16 of the two residuals
@@ -504,7 +506,7 @@ static hipError_t ffn_stream_go(const FfnStreamArgs& a, hipStream_t st) {
         return hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     }, &cus);
     if (e != hipSuccess) return e;
-    { extern int g_persist_mask; if (!(g_persist_mask & 1)) cus = once.real_cus(); }   // (A/B: which persistent kernels the throughput-mode grid cap applies to)
+    if (!(g_persist_mask & 1)) cus = once.real_cus();   // (A/B: which persistent kernels the throughput-mode grid cap applies to)
     const int npass = (a.M + NW * 32 - 1) / (NW * 32);
     // NW = 4 (one wave per SIMD per workgroup): two workgroups share a CU when the ring is small enough — their steps drift
     // freely against each other, only the four waves of one ring meet at its barrier

@@ -18,6 +18,8 @@
 #include "prof.hpp"
 #include <type_traits>
 
+extern int g_persist_mask;   // engine.hip: which persistent kernels the throughput-mode grid cap applies to (1 streamed FFN, 2 one-pass / wave FFN, 4 upsample)
+
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
@@ -565,7 +567,7 @@ static hipError_t ffn_wave_go(const FfnWaveArgs& a, hipStream_t st) {
         return hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     }, &cus);
     if (e != hipSuccess) return e;
-    { extern int g_persist_mask; if (!(g_persist_mask & 2)) cus = once.real_cus(); }   // (A/B: which persistent kernels the throughput-mode grid cap applies to)
+    if (!(g_persist_mask & 2)) cus = once.real_cus();   // (A/B: which persistent kernels the throughput-mode grid cap applies to)
     const int ntiles = (a.M + 31) / 32;
     // persistent: as many workgroups as fit (LDS, and 32 waves per CU), each wave walks tiles
     int per_cu = (int)((160 * 1024) / lds);

@@ -12,6 +12,8 @@
 #include "kernels.hpp"
 #include "prof.hpp"
 
+extern int g_persist_mask;   // engine.hip: which persistent kernels the throughput-mode grid cap applies to (1 streamed FFN, 2 one-pass / wave FFN, 4 upsample)
+
 namespace {
 typedef float f32x2u __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x2u __attribute__((ext_vector_type(2)));
@@ -152,7 +154,7 @@ hipError_t upsample_go(const UpsampleArgs& a, hipStream_t st) {
         return hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     }, &cus);
     if (e != hipSuccess) return e;
-    { extern int g_persist_mask; if (!(g_persist_mask & 4)) cus = once.real_cus(); }   // (A/B: which persistent kernels the throughput-mode grid cap applies to)
+    if (!(g_persist_mask & 4)) cus = once.real_cus();   // (A/B: which persistent kernels the throughput-mode grid cap applies to)
     const int ntiles = (a.M + 31) / 32;
     const int per_cu = lds * 2 <= 160 * 1024 ? 2 : 1;
     int grid = (ntiles + 7) / 8;
