@@ -83,8 +83,11 @@ void Engine::set_tuning(int mode) {
     if (mode == TUNE_THROUGHPUT) {
         if (tuning_ != TUNE_THROUGHPUT) dual_stream_latency_ = dual_stream_;
         tuning_ = TUNE_THROUGHPUT;
-        dual_stream_ = false;
-        gemm_deep_ = 0;
+        dual_stream_ = getenv("SMTTS_DUAL_TP") && atoi(getenv("SMTTS_DUAL_TP")) != 0;   // (A/B only: engine-owned side stream with batches in flight)
+        // Ring depth with batches in flight: round 2 measured shallow rings ahead (10.14 vs 10.38 ms: a workgroup holding 64-128 KiB
+        // of LDS while it waits kept the other streams' kernels off its CU).  Re-measured at the end of round 3 — fp16 operand images,
+        // shorter epilogues, persistent codec grids capped — deep rings win: 8.53 -> 8.42 ms (profiles/r03ag_*).
+        gemm_deep_ = getenv("SMTTS_GEMM_DEEP_TP") ? atoi(getenv("SMTTS_GEMM_DEEP_TP")) : 1;
         persist_cus_ = persist_cus_tp_;
     } else {
         if (tuning_ == TUNE_THROUGHPUT) dual_stream_ = dual_stream_latency_;
@@ -1099,7 +1102,8 @@ int Engine::denoise_core(hipStream_t st, const float* x_t, const uint8_t* mask, 
     // sampler (M = 1800: 435 tiles) fill it without, and the fused epilogue is cheaper than partials + reduce (495 -> 454 ms)
     // ... and so do several batches in flight (throughput tuning): there the unsplit GEMM + a separate AdaLN costs 2.3x fewer
     // workgroup-microseconds than three K slices + reduce, and that is what counts when other streams want the CUs
-    const bool unsplit = M > 1024 || tuning_ == TUNE_THROUGHPUT;
+    static const bool splitk_tp = getenv("SMTTS_SPLITK_TP") && atoi(getenv("SMTTS_SPLITK_TP")) != 0;   // (A/B only)
+    const bool unsplit = M > 1024 || (tuning_ == TUNE_THROUGHPUT && !splitk_tp);
     const int ks_out = unsplit ? 1 : ksplit_out_, ks_ff2 = unsplit ? 1 : ksplit_ff2_;
     for (int l = 0; l < kBlocks; ++l) {
         const DitBlockW& b = blocks_[l];
