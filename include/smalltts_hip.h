@@ -141,7 +141,7 @@ int smtts_pcm16(smtts_handle h, void* stream, const float* x, int64_t n, int16_t
 int smtts_set_dual_stream(smtts_handle h, int on);
 /* Tuning mode: 0 = latency (default: one batch at a time finishes as early as possible: split-K on the small-M projections, deep
  * DMA rings, text encoder on the side stream), 1 = throughput (the caller keeps several independent batches in flight on its own
- * streams: unsplit GEMMs, shallow rings, no side stream, so that kernels cost the fewest CU-microseconds and leave LDS for the
+ * streams: unsplit GEMMs, no side stream, persistent codec kernels on three quarters of the CUs, so that kernels cost the fewest CU-microseconds and leave LDS for the
  * other streams).  Results differ between the modes only by fp32 summation order. */
 int smtts_set_tuning(smtts_handle h, int mode);
 

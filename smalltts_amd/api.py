@@ -218,7 +218,7 @@ class SmallTTS:
         for st in streams:
             st.wait_stream(cur)
         pending = []
-        # throughput tuning: unsplit GEMMs, shallow rings, no engine side stream (it would serialise the text encoders of all
+        # throughput tuning: unsplit GEMMs, capped persistent codec grids, no engine side stream (it would serialise the text encoders of all
         # batches in flight); the caller's mode is restored afterwards
         prev_tuning = eng.set_tuning("throughput")
         try:

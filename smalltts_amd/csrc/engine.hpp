@@ -129,7 +129,7 @@ class Engine {
     // Tuning mode.  TUNE_LATENCY (default): one batch at a time should finish as early as possible — split-K on the small-M
     // projections, deep DMA rings, text encoder on the side stream.  TUNE_THROUGHPUT: several independent batches are in flight
     // on the caller's streams (SmallTTS.synthesize_batches, bench.py) — kernels should cost the fewest CU-microseconds and hold
-    // the least LDS so that other streams' kernels fit beside them: no split-K, shallow rings, no side stream.
+    // the least LDS so that other streams' kernels fit beside them: no split-K, no side stream, persistent codec kernels on three quarters of the CUs (deep rings in both modes since round 3).
     enum { TUNE_LATENCY = 0, TUNE_THROUGHPUT = 1 };
     void set_tuning(int mode);
     int tuning() const { return tuning_; }
@@ -223,7 +223,7 @@ class Engine {
     std::vector<void*> pack_allocs_;  // everything finalize() builds: freed and rebuilt by the next finalize()
     bool packing_ = false;
     int tuning_ = TUNE_LATENCY;
-    int gemm_deep_ = 1;   // gemm3 ring depth of this engine's launches (1 deep: latency tuning, 0 shallow: throughput); installed per operator call (DeepScope)
+    int gemm_deep_ = 1;   // gemm3 ring depth of this engine's launches (1 deep — both tunings since round 3; 0 shallow: SMTTS_GEMM_DEEP / SMTTS_GEMM_DEEP_TP); installed per operator call (DeepScope)
     int persist_cus_ = 0;        // grid cap of the persistent codec kernels for this engine's calls (0 = one workgroup per CU): 0 under latency tuning,
     int persist_cus_tp_ = 192;   // this under throughput tuning (SMTTS_PERSIST_CUS; profiles/r03ac_*, r03ad_*)
     bool dual_stream_latency_ = true;  // the dual-stream setting that TUNE_LATENCY restores
