@@ -478,7 +478,11 @@ __global__ __launch_bounds__(NW * 64) void codec_ffn_stream_kernel(FfnStreamArgs
                     o.y += gv.y * (acc2[ot][4 * q + 1] + bv.y);
                     o.z += gv.z * (acc2[ot][4 * q + 2] + bv.z);
                     o.w += gv.w * (acc2[ot][4 * q + 3] + bv.w);
+#ifdef FS_LIN_STORE   // (timing experiment, results wrong: the same bytes written as whole 1-KiB wave stores instead of 32-B pieces of 32 rows)
+                    *reinterpret_cast<float4*>(a.x + a.img.at(0) + ((((long)(pass * NW + wave) * NOT + ot) * 4 + q) * 64 + lane) * 4) = o;
+#else
                     *reinterpret_cast<float4*>(xr + c0) = o;
+#endif
                 }
             }
         }
