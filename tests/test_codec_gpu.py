@@ -84,3 +84,45 @@ def test_full_spec_decode_vs_oracle():
           f"(bound {SNR_BOUND_DB} dB)")
     assert s2 > SNR_BOUND_DB
     assert s > SNR_BOUND_DB, f"decode SNR {s:.1f} dB"
+
+
+_ALT = r"""
+import sys, numpy as np, torch
+from smalltts_amd.engine import HipEngine
+eng = HipEngine(0)
+eng.load_synthetic(5, parts=("decoder",)); eng.finalize()
+eng.set_tuning(sys.argv[2])
+lat = torch.randn(2, 75, 64, generator=torch.Generator().manual_seed(21)).cuda()
+np.save(sys.argv[1], eng.codec_decode(lat).cpu().numpy())
+"""
+
+
+def _decode_in_subprocess(tmp_path, tag, env_extra, tuning="latency"):
+    """The A/B switches are read when the engine is created: each alternative runs in its own interpreter."""
+    import os, subprocess, sys
+    out = tmp_path / f"{tag}.npy"
+    env = dict(os.environ, **env_extra)
+    env["PYTHONPATH"] = os.path.dirname(os.path.dirname(os.path.abspath(__file__))) + os.pathsep + env.get("PYTHONPATH", "")
+    subprocess.run([sys.executable, "-c", _ALT, str(out), tuning], check=True, env=env, timeout=600)
+    return np.load(out)
+
+
+def test_alternative_paths_agree_with_the_default(tmp_path):
+    """Full-size decode (2 x 75 frames) on the A/B alternatives of the round-3 changes: scheduling-only switches (tile orders, the
+    persistent kernels' grid, ring depth) must not change a bit; the two-kernel wide-stage mixer differs by fp32 summation order."""
+    base = _decode_in_subprocess(tmp_path, "base", {})
+    for tag, env in (("tile_orders", {"SMTTS_GEMM_XCD": "0", "SMTTS_GEMM_GROUP": "1"}), ("shallow", {"SMTTS_GEMM_DEEP": "0"})):
+        alt = _decode_in_subprocess(tmp_path, tag, env)
+        assert np.array_equal(alt, base), tag
+    tp = _decode_in_subprocess(tmp_path, "tp", {}, "throughput")
+    for tag, env in (("grid_all_cus", {"SMTTS_PERSIST_CUS": "0"}), ("grid_half", {"SMTTS_PERSIST_CUS": "128"}),
+                     ("tp_shallow", {"SMTTS_GEMM_DEEP_TP": "0"})):
+        alt = _decode_in_subprocess(tmp_path, tag, env, "throughput")
+        assert np.array_equal(alt, tp), tag
+    # the two-kernel mixer sums the rows' squares in another order; at the default precision the normalised rows are then rounded to
+    # fp16, so a last-bit difference moves some of those roundings: the two paths differ by about what each differs from fp32
+    # (68.7 dB vs the oracle; measured 72 dB between them)
+    two = _decode_in_subprocess(tmp_path, "two_kernel_mixer", {"SMTTS_MIXER_WIDE": "0"})
+    assert snr_db(two, base) > 66.0
+    x2 = _decode_in_subprocess(tmp_path, "mixer_tiles", {"SMTTS_MW_TT512": "32", "SMTTS_MW_TT1024": "16", "SMTTS_MW_TT2048": "8"})
+    assert np.array_equal(x2, base)   # (the thread -> channel mapping and every reduction order are the same for every tile size)
