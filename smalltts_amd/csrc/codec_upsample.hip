@@ -48,7 +48,9 @@ __global__ __launch_bounds__(512) void codec_upsample_wave_kernel(UpsampleArgs a
     constexpr int NARR = SPLIT == 3 ? 2 : 1;
     constexpr int W_ARR = N * RB;
     constexpr int OFF_B = NARR * W_ARR;    // bias[N] (fp32)
-    constexpr int PF = KK >= 16 ? 8 : 4;   // raw rows are loaded PF k16 steps ahead, across tile boundaries (the ring never drains)
+    // raw rows are loaded PF k16 steps ahead, across tile boundaries (the ring never drains).  K = 256: a whole tile ahead (16 steps:
+    // 179 -> 164 us against 8, profiles/r03ap_*); K = 128 keeps 4 — its W fragments live in 128 registers and a deeper ring spills.
+    constexpr int PF = KK >= 16 ? 16 : 4;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
