@@ -49,8 +49,13 @@ __global__ __launch_bounds__(512) void codec_upsample_wave_kernel(UpsampleArgs a
     constexpr int W_ARR = N * RB;
     constexpr int OFF_B = NARR * W_ARR;    // bias[N] (fp32)
     // raw rows are loaded PF k16 steps ahead, across tile boundaries (the ring never drains).  K = 256: a whole tile ahead (16 steps:
-    // 179 -> 164 us against 8, profiles/r03ap_*); K = 128 keeps 4 — its W fragments live in 128 registers and a deeper ring spills.
-    constexpr int PF = KK >= 16 ? 16 : 4;
+    // 179 -> 164 us against 8, profiles/r03ap_*); K = 128 with its W fragments hoisted into 128 registers spills with a deeper ring.
+    // K = 128: a whole tile ahead too (8 steps), with the W fragments re-read from LDS per tile instead of living in 128 registers
+    // (-DUP_OPAQUE128=0: the round-2 form, 4 steps ahead and hoisted fragments): 151.5 -> 143.5 us (profiles/r03ar_*)
+#ifndef UP_OPAQUE128
+#define UP_OPAQUE128 1
+#endif
+    constexpr int PF = KK >= 16 ? 16 : (UP_OPAQUE128 ? 8 : 4);
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -93,7 +98,7 @@ __global__ __launch_bounds__(512) void codec_upsample_wave_kernel(UpsampleArgs a
         // keeps all 128 registers of them (no LDS traffic at all); at K = 256, N = 128 they would need 512 registers, so the
         // address is made opaque per tile and the reads stay inside the loop.
         int wa = w_a0;
-        if (KK * NT * NARR * 4 > 160) asm volatile("" : "+v"(wa));
+        if (KK * NT * NARR * 4 > 160 || UP_OPAQUE128) asm volatile("" : "+v"(wa));
         const float* xr = xr_next;
         xr_next = row_ptr(wt + nwg < ntiles ? wt + nwg : wt);  // (last tile: harmless re-read of its own first steps)
         floatx16 acc[NT];
