@@ -115,6 +115,7 @@ def test_alternative_paths_agree_with_the_default(tmp_path):
         alt = _decode_in_subprocess(tmp_path, tag, env)
         assert np.array_equal(alt, base), tag
     tp = _decode_in_subprocess(tmp_path, "tp", {}, "throughput")
+    assert snr_db(tp, base) > 80.0     # throughput tuning is held to the latency-tuned decode, not only to its own variants
     for tag, env in (("grid_all_cus", {"SMTTS_PERSIST_CUS": "0"}), ("grid_half", {"SMTTS_PERSIST_CUS": "128"}),
                      ("tp_shallow", {"SMTTS_GEMM_DEEP_TP": "0"})):
         alt = _decode_in_subprocess(tmp_path, tag, env, "throughput")
