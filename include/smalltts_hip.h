@@ -48,6 +48,10 @@ int smtts_create(int device_id, smtts_handle* out);
 int smtts_destroy(smtts_handle h);
 const char* smtts_last_error(smtts_handle h); /* h may be NULL: last creation error */
 const char* smtts_version(void);
+/* bumped on every signature / default change: 4 = round 4 (workspace queries take R and P, new handles default to preset 2,
+ * smtts_get_saturations) */
+#define SMTTS_ABI_VERSION 4
+int smtts_abi_version(void);
 
 /* ---- weights (replaces the ONNX initialisers; names/shapes = DiTModel.state_dict(),
  *      src/scripts/test_checkpoint.py:44-73, plus codec.* names of smalltts_amd/weights.py) ---- */
@@ -76,6 +80,16 @@ int smtts_default_precision(void);         /* host-only: the preset smtts_create
  * 4 = "fp16 x 2": fp16 activations against fp16 hi + lo weights, two passes instead of split-bf16's three, on the decoder's
  * ConvTranspose stages with 512 <= K <= 1024 (the other stages stay split-bf16) */
 int smtts_set_site_precision(smtts_handle h, int site, int prec);
+/* fp16 range guard.  fp16 operands saturate at +-65504 instead of overflowing to inf, which is silent; every producer of an
+ * fp16 operand therefore counts the values it had to clamp into a per-site device counter (sites as above).  counts[i] = clamps
+ * of site i since the last reset; for site 4 additionally the number of fused codec FFN blocks whose hidden / input range could
+ * not be certified from the weights at smtts_finalize (those kernels carry no run-time check; smtts_range_report names them).
+ * Non-zero = the results of that site are clipped: re-run with smtts_set_site_precision(site, 3) (split-bf16 has fp32 range) —
+ * smalltts_amd/api.py does that automatically.  Synchronises the device.  Real checkpoints enter through
+ * src/scripts/train/dmd2/distill.py:468-479; the SwiGLU hidden (models/backbone/dit.py:176-186) is the likeliest site. */
+int smtts_get_saturations(smtts_handle h, uint32_t* counts, int n_sites, int reset);
+const char* smtts_range_report(smtts_handle h);      /* "" when every fused FFN block was certified */
+float smtts_range_worst_bound(smtts_handle h);       /* largest certified bound of the last finalize (fp16 max: 65504) */
 int smtts_has_part(smtts_handle h, int part); /* 0 dit, 1 codec decoder, 2 codec encoder */
 
 /* ---- condition encoder ---------------------------------------------------------------------- */

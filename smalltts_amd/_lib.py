@@ -14,6 +14,7 @@ LIB_PATH = os.environ.get("SMTTS_LIB") or os.path.join(_HERE, "libsmalltts_hip.s
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "smalltts_hip.h")
 
 _lib = None
+ABI_VERSION = 4   # include/smalltts_hip.h SMTTS_ABI_VERSION
 
 vp, i32, i64, u64, f32, sz = C.c_void_p, C.c_int, C.c_int64, C.c_uint64, C.c_float, C.c_size_t
 cstr = C.c_char_p
@@ -24,6 +25,10 @@ SIGNATURES: Dict[str, Tuple[object, List[object]]] = {
     "smtts_destroy": (i32, [vp]),
     "smtts_last_error": (cstr, [vp]),
     "smtts_version": (cstr, []),
+    "smtts_abi_version": (i32, []),
+    "smtts_get_saturations": (i32, [vp, C.POINTER(C.c_uint32), i32, i32]),
+    "smtts_range_report": (cstr, [vp]),
+    "smtts_range_worst_bound": (f32, [vp]),
     "smtts_set_tensor": (i32, [vp, cstr, vp, C.POINTER(i64), i32, i32]),
     "smtts_synth_tensor": (i32, [vp, cstr, C.POINTER(i64), i32, u64, f32, f32]),
     "smtts_get_tensor": (i32, [vp, cstr, vp, i64]),
@@ -88,5 +93,8 @@ def load():
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
+    if lib.smtts_abi_version() != ABI_VERSION:
+        raise RuntimeError(f"{LIB_PATH} has ABI version {lib.smtts_abi_version()}, this host side was written for {ABI_VERSION} "
+                           "(include/smalltts_hip.h SMTTS_ABI_VERSION): rebuild with `make -C smalltts_amd/csrc`")
     _lib = lib
     return lib

@@ -105,6 +105,9 @@ def _load_weights_into(eng: HipEngine, weights, parts: Sequence[str]) -> None:
         eng.load_state_dict(tensors)
         note(tensors)
     eng.finalize()
+    # real weights (anything but the seeded recipe): hold the preset to split-bf16 on a probe batch once, demote what drifts
+    if any(not src.startswith("synthetic") for src in _split_sources(weights)) and os.environ.get("SMTTS_CALIBRATE", "1") != "0":
+        eng.calibrate()
 
 
 def get_engine(weights: Optional[str] = None, device: int = 0, precision: str = DEFAULT_PRECISION,
@@ -190,12 +193,20 @@ class SmallTTS:
             pm[b, :ps[b]] = True
             mask[b, :ns[b]] = True
         eng = self.engine
-        cache = eng.cond_encode(ref, np.asarray(rs, np.int64), ids, pm)
-        x = eng.sample(cache, mask, num_steps=self.num_steps, noise=noise, seed=self._next_seed())
-        audio = eng.codec_decode(x)                           # (B, 1, HOP * Nm); causal => prefixes are exact
+        seed = self._next_seed()
+
+        def run():
+            cache = eng.cond_encode(ref, np.asarray(rs, np.int64), ids, pm)
+            x_ = eng.sample(cache, mask, num_steps=self.num_steps, noise=noise, seed=seed)
+            return eng.codec_decode(x_), x_                    # (B, 1, HOP * Nm); causal => prefixes are exact
+
+        audio, x = run()
         if _defer:                                             # synthesize_batches: stay on the device / stream
-            return audio, x, ns
+            return audio, x, ns, run
         audio = audio.cpu().numpy()
+        if eng.check_fp16_range("synthesize"):                 # an fp16 operand clipped: the site is split-bf16 now, run again
+            audio, x = run()
+            audio = audio.cpu().numpy()
         outs = [audio[b, :, : HOP_SIZE * ns[b]] for b in range(B)]
         if return_latents:
             xl = x.cpu().numpy()
@@ -231,8 +242,11 @@ class SmallTTS:
             eng.set_tuning(prev_tuning)
         for st in streams:
             cur.wait_stream(st)
+        torch.cuda.synchronize(dev)
+        if eng.check_fp16_range("synthesize_batches"):         # clipped somewhere: every batch again, one at a time, at the demoted precision
+            pending = [(*run(), ns, run) for _a, _x, ns, run in pending]
         outs = []
-        for audio, _, ns in pending:
+        for audio, _, ns, _run in pending:
             a = audio.cpu().numpy()
             outs.append([a[b, :, : HOP_SIZE * ns[b]] for b in range(len(ns))])
         if release_workspaces:

@@ -20,7 +20,8 @@ static thread_local std::string g_create_err;
 
 extern "C" {
 
-const char* smtts_version(void) { return "smalltts-hip 0.1 (gfx950)"; }
+const char* smtts_version(void) { return "smalltts-hip 0.4 (gfx950)"; }
+int smtts_abi_version(void) { return SMTTS_ABI_VERSION; }
 
 int smtts_create(int device_id, smtts_handle* out) {
     if (!out) return 1;
@@ -74,6 +75,15 @@ int smtts_set_precision(smtts_handle h, int preset) { NULLCHK;
 int smtts_get_precision(smtts_handle h) { NULLCHK; return E.precision(); }
 int smtts_default_precision(void) { return kDefaultPrecision; }
 int smtts_set_site_precision(smtts_handle h, int site, int prec) { NULLCHK; return E.set_site_precision(site, prec); }
+int smtts_get_saturations(smtts_handle h, uint32_t* counts, int n_sites, int reset) { NULLCHK;
+    if (!counts || n_sites < 0) return E.fail("get_saturations: bad arguments");
+    return E.get_saturations(counts, n_sites, reset != 0);
+}
+const char* smtts_range_report(smtts_handle h) {
+    if (!h) { g_create_err = std::string(__func__) + ": null handle"; return ""; }
+    return E.range_report().c_str();
+}
+float smtts_range_worst_bound(smtts_handle h) { NULLCHK0; return E.range_worst(); }
 int smtts_has_part(smtts_handle h, int part) { NULLCHK0;
     return part == 0 ? E.has_dit() : part == 1 ? E.has_decoder() : part == 2 ? E.has_encoder() : 0;
 }

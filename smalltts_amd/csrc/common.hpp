@@ -156,20 +156,48 @@ typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
 typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
 typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
 typedef float f32x2_t __attribute__((ext_vector_type(2)));
+// The fp16 tag: low two address bits == 2.  The REST of the tag, when non-zero, is the address of a saturation counter (unsigned,
+// 4-byte aligned, device memory): every producer that clamps a value to +-65504 while writing this format adds to it (sat_note).
+// Real lo arrays are 256-byte aligned workspace carve-outs (engine.hip Bump) or hipMalloc'ed packs, so their low bits are zero.
 #define SM_F16_TAG (reinterpret_cast<bf16_t*>((uintptr_t)2))
-__host__ __device__ __forceinline__ bool sm_is_f16(const bf16_t* lo) { return lo == SM_F16_TAG; }
-__host__ __device__ __forceinline__ bool sm_is_split(const bf16_t* lo) { return lo != nullptr && lo != SM_F16_TAG; }
-// lo pointer that tells a producer which format to write for a consumer of precision `prec`
-static inline bf16_t* sm_lo_for(int prec, bf16_t* lo) { return prec == PREC_BF16X3 ? lo : (prec == PREC_F16 || prec == PREC_F16X2) ? SM_F16_TAG : nullptr; }
+__host__ __device__ __forceinline__ bool sm_is_f16(const bf16_t* lo) { return ((uintptr_t)lo & 3u) == 2u; }
+__host__ __device__ __forceinline__ bool sm_is_split(const bf16_t* lo) { return lo != nullptr && !sm_is_f16(lo); }
+__host__ __device__ __forceinline__ unsigned* sm_sat_counter(const bf16_t* lo) {
+    return sm_is_f16(lo) ? reinterpret_cast<unsigned*>((uintptr_t)lo & ~(uintptr_t)3) : nullptr;
+}
+// lo pointer that tells a producer which format to write for a consumer of precision `prec` (fp16: + where to count clamps)
+static inline bf16_t* sm_lo_for(int prec, bf16_t* lo, unsigned* sat_counter = nullptr) {
+    return prec == PREC_BF16X3 ? lo
+           : (prec == PREC_F16 || prec == PREC_F16X2) ? reinterpret_cast<bf16_t*>((uintptr_t)sat_counter | 2u)
+                                                      : nullptr;
+}
 
-// (a, b) -> packed fp16 pair, round to nearest even, saturating at +-65504 (v_cvt_pk_f16_f32 + v_pk_min/max_f16)
-__device__ __forceinline__ unsigned cvt_pk_f16_sat(float a, float b) {
+// fp16 range guard.  The conversions saturate instead of producing inf, which keeps a rare outlier from
+// poisoning a softmax / residual row but is SILENT; `diff` collects raw ^ clamped of every converted pair, and sat_note() adds the
+// number of lanes that clamped anything to the site's counter — one atomic per wave and call, on a path that is never taken with
+// in-range data.  Call sat_note only where no load is consumed afterwards (stores and loads share vmcnt: DESIGN 5a).
+__device__ __forceinline__ unsigned cvt_pk_f16_sat(float a, float b, unsigned& diff) {
     f32x2_t v;
     v.x = a; v.y = b;
-    half2_t h = __builtin_convertvector(v, half2_t);
+    const half2_t raw = __builtin_convertvector(v, half2_t);
     const half2_t mx = {(half_t)65504.f, (half_t)65504.f};
-    h = __builtin_elementwise_max(__builtin_elementwise_min(h, mx), -mx);
+    const half2_t h = __builtin_elementwise_max(__builtin_elementwise_min(raw, mx), -mx);
+    diff |= __builtin_bit_cast(unsigned, raw) ^ __builtin_bit_cast(unsigned, h);
     return __builtin_bit_cast(unsigned, h);
+}
+__device__ __forceinline__ void sat_note(unsigned diff, const bf16_t* tag) {
+    if (__builtin_expect(diff != 0u, 0)) {
+        unsigned* c = sm_sat_counter(tag);
+        if (c) {
+            const unsigned long long m = __ballot(1);   // the lanes inside this branch
+            if ((int)(threadIdx.x & 63) == __ffsll((long long)m) - 1) atomicAdd(c, (unsigned)__popcll(m));
+        }
+    }
+}
+// (a, b) -> packed fp16 pair, round to nearest even, saturating at +-65504 (v_cvt_pk_f16_f32 + v_pk_min/max_f16)
+__device__ __forceinline__ unsigned cvt_pk_f16_sat(float a, float b) {
+    unsigned d = 0;
+    return cvt_pk_f16_sat(a, b, d);
 }
 // same for values bounded below (GELU / SiLU-gated outputs): only +inf can occur, one v_pk_min_f16
 __device__ __forceinline__ unsigned cvt_pk_f16_satpos(float a, float b) {
@@ -191,7 +219,9 @@ __device__ __forceinline__ void split1(float v, bf16_t& h, bf16_t& l) {
 // one activation value / four consecutive ones in the GEMM-operand format selected by `lo` (see above)
 __device__ __forceinline__ void store_act1(bf16_t* hi, bf16_t* lo, long off, float v) {
     if (sm_is_f16(lo)) {
-        reinterpret_cast<unsigned short*>(hi)[off] = cvt_f16_sat(v);
+        unsigned d = 0;
+        reinterpret_cast<unsigned short*>(hi)[off] = (unsigned short)(cvt_pk_f16_sat(v, 0.f, d) & 0xffffu);
+        sat_note(d, lo);
         return;
     }
     bf16_t h, l;
@@ -202,9 +232,11 @@ __device__ __forceinline__ void store_act1(bf16_t* hi, bf16_t* lo, long off, flo
 __device__ __forceinline__ void store_split4(bf16_t* hi, bf16_t* lo, long off, const float4& v) {
     if (sm_is_f16(lo)) {
         uint2 p;
-        p.x = cvt_pk_f16_sat(v.x, v.y);
-        p.y = cvt_pk_f16_sat(v.z, v.w);
+        unsigned d = 0;
+        p.x = cvt_pk_f16_sat(v.x, v.y, d);
+        p.y = cvt_pk_f16_sat(v.z, v.w, d);
         *reinterpret_cast<uint2*>(hi + off) = p;
+        sat_note(d, lo);
         return;
     }
     bf16x4 h, l;
@@ -225,8 +257,10 @@ __device__ __forceinline__ floatx16 mfma16(const bf16x8& a, const bf16x8& b, con
 
 // ---- attention operand images (attention_img.hip): element stores in format `prec` and the q / k head prep -------------------
 __device__ __forceinline__ void store_img2(bf16_t* hi, bf16_t* lo, int prec, long off, float a, float b) {   // off even
-    if (prec == PREC_F16) {
-        *reinterpret_cast<unsigned*>(hi + off) = cvt_pk_f16_sat(a, b);
+    if (prec == PREC_F16) {   // (`lo` is not an array in this format: it carries the fp16 tag + saturation counter, or null)
+        unsigned dd = 0;
+        *reinterpret_cast<unsigned*>(hi + off) = cvt_pk_f16_sat(a, b, dd);
+        sat_note(dd, lo);
         return;
     }
     bf16_t ah, al, bh, bl;
@@ -240,7 +274,9 @@ __device__ __forceinline__ void store_img2(bf16_t* hi, bf16_t* lo, int prec, lon
 }
 __device__ __forceinline__ void store_img1(bf16_t* hi, bf16_t* lo, int prec, long off, float v) {
     if (prec == PREC_F16) {
-        reinterpret_cast<unsigned short*>(hi)[off] = cvt_f16_sat(v);
+        unsigned dd = 0;
+        reinterpret_cast<unsigned short*>(hi)[off] = (unsigned short)(cvt_pk_f16_sat(v, 0.f, dd) & 0xffffu);
+        sat_note(dd, lo);
     } else {
         bf16_t hh, ll;
         split1(v, hh, ll);

@@ -77,6 +77,22 @@ Engine::Engine(int device) : device_(device) {
     // three quarters of the CUs, in whole rounds of the 32 shader engines the dispatcher deals workgroups to (measured in flight,
     // ms per batch at 256 / 224 / 208 / 192 / 176 / 160 / 128 workgroups: 8.62 / 8.46 / 8.55 / 8.41 / 8.49 / 8.44 / 8.54)
     if (!getenv("SMTTS_PERSIST_CUS")) persist_cus_tp_ = num_cus_ >= 64 ? num_cus_ * 3 / 4 / 32 * 32 : 0;
+    // fp16 range guard: one saturation counter per precision site (+ two floats of scratch for finalize's certificates)
+    if (hipSetDevice(device) == hipSuccess) {
+        sat_ = static_cast<unsigned*>(dalloc((SITE_COUNT + 2) * sizeof(unsigned)));
+        if (sat_ && hipMemset(sat_, 0, (SITE_COUNT + 2) * sizeof(unsigned)) != hipSuccess) sat_ = nullptr;
+        if (sat_) cert_scratch_ = reinterpret_cast<float*>(sat_ + SITE_COUNT);
+    }
+}
+
+int Engine::get_saturations(unsigned* out, int n, bool reset) {
+    HIPC(hipSetDevice(device_));
+    HIPC(hipDeviceSynchronize());
+    unsigned dev[SITE_COUNT] = {};
+    if (sat_) HIPC(hipMemcpy(dev, sat_, sizeof dev, hipMemcpyDeviceToHost));
+    for (int i = 0; i < n; ++i) out[i] = i < SITE_COUNT ? dev[i] + sat_static_[i] : 0u;
+    if (reset && sat_) HIPC(hipMemset(sat_, 0, sizeof dev));   // (the static part is a property of the weights: it stays)
+    return 0;
 }
 
 void Engine::set_tuning(int mode) {
@@ -601,6 +617,7 @@ int Engine::finalize_codec(bool decoder) {
                 b.w2t.N = (F / 32) * C;
                 b.w2t.K = 32;
             }
+            if (certify_codec_ffn(p, b, C, F)) return 1;
             st.blocks.push_back(b);
         }
         h.stages.push_back(st);
@@ -640,11 +657,38 @@ int Engine::finalize_codec(bool decoder) {
     return 0;
 }
 
+// The fused codec FFN kernels (codec_ffn_wave / codec_ffn_stream: C <= 256) convert their normalised input and their GELU
+// hidden to fp16 in registers and are VALU-bound: a per-value range check there would cost every batch ~4 % of the decoder for
+// an event the weights can RULE OUT.  The input is RMS-normalised, so both are bounded by the weights alone
+// (ffn_range_bound_kernel); a block whose bound stays inside the fp16 range needs no run-time check, one whose bound does not
+// is reported through get_saturations (static part of SITE_CODEC_FFN), which makes the host side demote the site.
+int Engine::certify_codec_ffn(const std::string& name, const CodecBlockW& b, int C, int F) {
+    if (!(C == 32 || C == 64 || C == 128 || C == 256) || F != 4 * C || !cert_scratch_) return 0;   // the wider stages' hiddens are counted at run time
+    const float* w1 = rawp(name + ".ffn.w1.weight");
+    if (!w1) return 0;
+    HIPC(hipMemsetAsync(cert_scratch_, 0, 2 * sizeof(float), 0));
+    HIPC(launch_ffn_range_bound(w1, b.b1, b.ffn_norm_w, F, C, cert_scratch_, 0));
+    float bound[2] = {0.f, 0.f};
+    HIPC(hipMemcpy(bound, cert_scratch_, sizeof bound, hipMemcpyDeviceToHost));
+    const float worst = bound[0] > bound[1] ? bound[0] : bound[1];
+    if (worst > range_worst_) range_worst_ = worst;
+    if (!(worst <= 65504.f)) {
+        ++sat_static_[SITE_CODEC_FFN];
+        char buf[256];
+        snprintf(buf, sizeof buf, "%s: fused FFN hidden bound %.4g, input bound %.4g exceed the fp16 range; ", name.c_str(), bound[0], bound[1]);
+        range_report_ += buf;
+    }
+    return 0;
+}
+
 int Engine::finalize() {
     HIPC(hipSetDevice(device_));
     HIPC(hipDeviceSynchronize());  // nothing in flight may still read the packs of an earlier finalize()
     invalidate();
     free_packs();
+    for (unsigned& v : sat_static_) v = 0;
+    range_report_.clear();
+    range_worst_ = 0.f;
     struct PackMode { bool& f; explicit PackMode(bool& b) : f(b) { f = true; } ~PackMode() { f = false; } } pm(packing_);
     if (raw("velocity.weight")) {
         if (finalize_dit()) return 1;
@@ -682,7 +726,8 @@ struct SplitBuf {  // activation buffer feeding gemm3 as its A operand: a split 
     bf16_t* hi;     // of precision PREC_F16 / PREC_BF16 — one 16-bit array in `hi` (`lo` allocated but unused)
     bf16_t* lo;
     // the (hi, lo) pair a PRODUCER is handed so that it writes the format a consumer of precision `prec` reads (common.hpp)
-    SplitBuf as(int prec) const { return SplitBuf{hi, sm_lo_for(prec, lo)}; }
+    // (`sat`: the consumer site's saturation counter, counted into by fp16 producers — common.hpp sat_note)
+    SplitBuf as(int prec, unsigned* sat = nullptr) const { return SplitBuf{hi, sm_lo_for(prec, lo, sat)}; }
 };
 static inline Gemm3Operands ops3(SplitBuf a, RowMap amap, const PW& w, int M, int prec, int row0 = 0, int nrows = -1) {
     Gemm3Operands g;
@@ -778,7 +823,8 @@ struct EncWs {
     SplitBuf y, o, ffh, seqs;
     SplitBuf qi, ki, vti, gi;   // attention operand images (attention_img.hip): [B][H][S][dhp] x 2, [B][H][dhp][pad8(S)], [M][D]
     size_t vt_elems;
-    void plan(Bump& b, int Mx) {
+    void plan(Bump& b, int B, int S) {
+        const int Mx = B * S > 0 ? B * S : 1;
         x = b.take<float>((size_t)Mx * 512);
         part = b.take<float>((size_t)kSplitK * Mx * 512);
         qkvg = b.take<float>((size_t)Mx * 2048);
@@ -787,10 +833,11 @@ struct EncWs {
         o = take_split(b, (size_t)Mx * 512);
         ffh = take_split(b, (size_t)Mx * 1536);
         seqs = take_split(b, (size_t)Mx * kHidden);
-        // H * dhp = 512 for both encoders (8 x 64, 4 x 128); V^T rows are padded to 8 keys per utterance: at most Mx + 7 * B <= 8 Mx
+        // H * dhp = 512 for both encoders (8 x 64, 4 x 128); V^T rows are padded to 8 keys per utterance: B x 512 x pad8(S)
+        // (round 3 took 8 Mx x 512 here, "at most Mx + 7 B <= 8 Mx": 16 KB per row, GBs at large B x P — ADVICE r3)
         qi = take_split(b, (size_t)Mx * 512);
         ki = take_split(b, (size_t)Mx * 512);
-        vt_elems = (size_t)Mx * 8 * 512;
+        vt_elems = (size_t)(B > 0 ? B : 1) * 512 * (size_t)pad8(S > 0 ? S : 1);
         vti = take_split(b, vt_elems);
         gi = take_split(b, (size_t)Mx * 512);
     }
@@ -805,7 +852,8 @@ int Engine::run_encoder(hipStream_t st, const EncoderW& e, void* wsv, int B, int
     const RowMap rd = rowmap_plain(D);
     if (e.blocks.empty()) return fail("encoder without blocks");
     const int pe = prec_[SITE_ENCODER];
-    const SplitBuf y = w.y.as(pe), o = w.o.as(pe), ffh = w.ffh.as(pe);  // every activation here feeds a SITE_ENCODER GEMM
+    unsigned* const se = satp(SITE_ENCODER);
+    const SplitBuf y = w.y.as(pe, se), o = w.o.as(pe, se), ffh = w.ffh.as(pe, se);  // every activation here feeds a SITE_ENCODER GEMM
     HIPC(launch_rmsnorm(w.x, rd, nullptr, y.hi, y.lo, rd, M, D, e.eps, e.blocks[0].an, st));
     for (size_t l = 0; l < e.blocks.size(); ++l) {
         const EncBlockW& b = e.blocks[l];
@@ -825,8 +873,8 @@ int Engine::run_encoder(hipStream_t st, const EncoderW& e, void* wsv, int B, int
             QkvPackArgs pk{};
             pk.qkvg = w.qkvg; pk.qw = b.qn; pk.kw = b.kn; pk.eps = e.eps; pk.q_scale = 1.0f / sqrtf((float)e.dh);
             pk.rope_cos = e.rope_cos; pk.rope_sin = e.rope_sin; pk.rot_dim = e.dh; pk.prec = pa;
-            pk.q = w.qi.hi; pk.q_lo = w.qi.lo; pk.k = w.ki.hi; pk.k_lo = w.ki.lo; pk.vt = w.vti.hi; pk.vt_lo = w.vti.lo;
-            pk.g = w.gi.hi; pk.g_lo = w.gi.lo;
+            pk.q = w.qi.hi; pk.q_lo = img_lo(pa, w.qi.lo); pk.k = w.ki.hi; pk.k_lo = img_lo(pa, w.ki.lo); pk.vt = w.vti.hi; pk.vt_lo = img_lo(pa, w.vti.lo);
+            pk.g = w.gi.hi; pk.g_lo = img_lo(pa, w.gi.lo);
             pk.B = B; pk.N = S; pk.H = e.heads; pk.dh = e.dh; pk.dhp = e.dh <= 64 ? 64 : 128; pk.Np = Sp;
             if (l == 0 && Sp != S) {   // pad key columns of V^T: zero once per call (the producer only writes n < S)
                 HIPC(hipMemsetAsync(w.vti.hi, 0, (size_t)B * e.heads * pk.dhp * Sp * 2, st));
@@ -841,8 +889,8 @@ int Engine::run_encoder(hipStream_t st, const EncoderW& e, void* wsv, int B, int
             }
             AttnImg ai{};
             ai.prec = pa;
-            ai.q = pk.q; ai.q_lo = pk.q_lo; ai.k = pk.k; ai.k_lo = pk.k_lo; ai.vt = pk.vt; ai.vt_lo = pk.vt_lo;
-            ai.g = pk.g; ai.g_lo = sm_lo_for(pa, pk.g_lo);
+            ai.q = pk.q; ai.q_lo = w.qi.lo; ai.k = pk.k; ai.k_lo = w.ki.lo; ai.vt = pk.vt; ai.vt_lo = w.vti.lo;   // (the consumer reads the lo ARRAYS, split format only)
+            ai.g = pk.g; ai.g_lo = sm_lo_for(pa, w.gi.lo);
             ai.mask_self = key_mask;
             ai.out_hi = o.hi; ai.out_lo = o.lo; ai.ors = D;
             ai.B = B; ai.N = S; ai.H = e.heads; ai.dh = e.dh; ai.Np = Sp;
@@ -879,8 +927,8 @@ int Engine::run_encoder(hipStream_t st, const EncoderW& e, void* wsv, int B, int
 size_t Engine::cond_ws_bytes(int B, int R, int P) const {
     Bump b(nullptr);
     EncWs ws, wt;  // the style and the text encoder run concurrently: one workspace each
-    ws.plan(b, B * R > 0 ? B * R : 1);
-    wt.plan(b, B * P > 0 ? B * P : 1);
+    ws.plan(b, B, R);
+    wt.plan(b, B, P);
     return b.off + 256;
 }
 
@@ -906,8 +954,8 @@ int Engine::cond_encode(hipStream_t st, const float* ref, const int64_t* ref_len
     HIPC(hipSetDevice(device_));
     Bump bump(ws);
     EncWs w, wt;
-    w.plan(bump, B * R > 0 ? B * R : 1);
-    wt.plan(bump, B * P > 0 ? B * P : 1);
+    w.plan(bump, B, R);
+    wt.plan(bump, B, P);
     const RowMap r512 = rowmap_plain(512), rh = rowmap_plain(kHidden);
     const int pe = prec_[SITE_ENCODER], pk = prec_[SITE_CROSS_KV], pc = prec_[SITE_COND];
     const bool fork = dual_stream_ && R > 0 && P > 0;
@@ -927,7 +975,7 @@ int Engine::cond_encode(hipStream_t st, const float* ref, const int64_t* ref_len
         float* mem = mem_out ? mem_out : wt.seq;
         HIPC(gemm3_store(ops3(wt.y, r512, phproj_, M, pe), ACT_NONE,
                          store_to(mem, rh, rawp("dit.phoneme_proj.bias"), 1.f, ph_mask), 1, pe, stt));
-        HIPC(launch_to_split(mem, rh, wt.seqs.hi, wt.seqs.as(pk).lo, rh, M, kHidden, stt));
+        HIPC(launch_to_split(mem, rh, wt.seqs.hi, wt.seqs.as(pk, satp(SITE_CROSS_KV)).lo, rh, M, kHidden, stt));
         EpiKV kv{k_text, v_text, kvtext_b_, B, kHeads, kDh, P};
         HIPC(gemm3_kv(ops3(wt.seqs, rh, kvtext_, M, pk), kv, pk, stt));
         HIPC(launch_headnorm(k_text, kBlocks, B, kHeads, P, kDh, 1e-6f, knc_, stt));
@@ -944,7 +992,7 @@ int Engine::cond_encode(hipStream_t st, const float* ref, const int64_t* ref_len
         HIPC(gemm3_store(ops3(w.y, r512, style_out_, M, pe), ACT_NONE,
                          store_to(seq, rh, rawp("style_encoder.out_proj.bias"), 1.f, ref_mask), 1, pe, st));
         // ---- E3 cross KV for the reference tokens (dit.py:80-93) -------------------------------
-        HIPC(launch_to_split(seq, rh, w.seqs.hi, w.seqs.as(pk).lo, rh, M, kHidden, st));
+        HIPC(launch_to_split(seq, rh, w.seqs.hi, w.seqs.as(pk, satp(SITE_CROSS_KV)).lo, rh, M, kHidden, st));
         EpiKV kv{k_ref, v_ref, kvref_b_, B, kHeads, kDh, R};
         HIPC(gemm3_kv(ops3(w.seqs, rh, kvref_, M, pk), kv, pk, st));
         HIPC(launch_headnorm(k_ref, kBlocks, B, kHeads, R, kDh, 1e-6f, knc_, st));
@@ -1043,7 +1091,8 @@ int Engine::denoise_core(hipStream_t st, const float* x_t, const uint8_t* mask, 
     // operand formats: the block GEMMs run at SITE_DIT_BLOCK precision, the latent in-projection / conv pos-embed / velocity
     // head at SITE_COND; each activation buffer is written in the format of the GEMM that reads it
     const int pb = prec_[SITE_DIT_BLOCK], pc = prec_[SITE_COND], pcp = prec_[SITE_CONVPOS];
-    const SplitBuf gm1 = w.gm1.as(pcp), gm2 = w.gm2.as(pcp), yb = w.y.as(pb), ob = w.o.as(pb), ffh = w.ffh.as(pb);
+    unsigned* const sb = satp(SITE_DIT_BLOCK);
+    const SplitBuf gm1 = w.gm1.as(pcp, satp(SITE_CONVPOS)), gm2 = w.gm2.as(pcp, satp(SITE_CONVPOS)), yb = w.y.as(pb, sb), ob = w.o.as(pb, sb), ffh = w.ffh.as(pb, sb);
     // D2 input embedding (dit.py:246-253): h = proj(x); x = mask*mish(conv2(mask*mish(conv1(mask*h)))) + h
     HIPC(gemm_store(ops(x_t, rowmap_plain(kLatent), inproj_, M), ACT_NONE,
                     store_to(w.h, rh, rawp("dit.input_embed.proj.bias")), 1, pc, st));
@@ -1129,8 +1178,8 @@ int Engine::denoise_core(hipStream_t st, const float* x_t, const uint8_t* mask, 
             QkvPackArgs pk{};
             pk.qkvg = w.qkvg; pk.qw = b.qn; pk.kw = b.kn; pk.eps = 1e-6f; pk.q_scale = 1.0f / sqrtf((float)kDh);
             pk.rope_cos = rc; pk.rope_sin = rs; pk.rot_dim = 64; pk.prec = pa;
-            pk.q = w.qi.hi; pk.q_lo = w.qi.lo; pk.k = w.ki.hi; pk.k_lo = w.ki.lo; pk.vt = w.vti.hi; pk.vt_lo = w.vti.lo;
-            pk.g = w.gi.hi; pk.g_lo = w.gi.lo;
+            pk.q = w.qi.hi; pk.q_lo = img_lo(pa, w.qi.lo); pk.k = w.ki.hi; pk.k_lo = img_lo(pa, w.ki.lo); pk.vt = w.vti.hi; pk.vt_lo = img_lo(pa, w.vti.lo);
+            pk.g = w.gi.hi; pk.g_lo = img_lo(pa, w.gi.lo);
             pk.B = B; pk.N = N; pk.H = kHeads; pk.dh = kDh; pk.dhp = 128; pk.Np = Np;
             if (l == 0 && Np != N && init_ws) {   // pad key columns of V^T (the producer only writes n < N)
                 HIPC(hipMemsetAsync(w.vti.hi, 0, w.vt_elems * 2, st));
@@ -1145,8 +1194,8 @@ int Engine::denoise_core(hipStream_t st, const float* x_t, const uint8_t* mask, 
             }
             AttnImg ai{};
             ai.prec = pa;
-            ai.q = pk.q; ai.q_lo = pk.q_lo; ai.k = pk.k; ai.k_lo = pk.k_lo; ai.vt = pk.vt; ai.vt_lo = pk.vt_lo;
-            ai.g = pk.g; ai.g_lo = sm_lo_for(pa, pk.g_lo);
+            ai.q = pk.q; ai.q_lo = w.qi.lo; ai.k = pk.k; ai.k_lo = w.ki.lo; ai.vt = pk.vt; ai.vt_lo = w.vti.lo;   // (the consumer reads the lo ARRAYS, split format only)
+            ai.g = pk.g; ai.g_lo = sm_lo_for(pa, w.gi.lo);
             if (ci.Cp > 0) {
                 const long lc = (long)l * B * kHeads * ci.Cp * 128;
                 ai.kc = ci.kc + lc; ai.vtc = ci.vtc + lc;
@@ -1178,7 +1227,7 @@ int Engine::denoise_core(hipStream_t st, const float* x_t, const uint8_t* mask, 
         // dit.py:37) after the last block
         EpiResid<0> r2{w.x, rh, b.b2, m + 5 * kHidden, kModLd, mod_row0, mod_rstride, N, nullptr};
         const float* mn = m + kModPerBlock;  // next block's modulation (or the final norm's [scale | shift])
-        const SplitBuf yv = w.y.as(pc);  // the final AdaLN feeds the velocity head (SITE_COND)
+        const SplitBuf yv = w.y.as(pc, satp(SITE_COND));  // the final AdaLN feeds the velocity head (SITE_COND)
         NextLN ln2 = l + 1 < kBlocks ? NextLN{mn + 0 * kHidden, mn + 1 * kHidden, yb.hi, yb.lo}
                                      : NextLN{mn + kHidden, mn, yv.hi, yv.lo};
         if (ks_ff2 > 1) {
@@ -1214,7 +1263,7 @@ int Engine::pack_cross(hipStream_t st, const float* k_ref, const float* v_ref, c
     ci.vtc = bump.take<bf16_t>(n); ci.vtc_lo = bump.take<bf16_t>(n);
     CrossPackArgs p{};
     p.k_ref = k_ref; p.v_ref = v_ref; p.k_text = k_text; p.v_text = v_text;
-    p.kc = ci.kc; p.kc_lo = ci.kc_lo; p.vtc = ci.vtc; p.vtc_lo = ci.vtc_lo;
+    p.kc = ci.kc; p.kc_lo = img_lo(pa, ci.kc_lo); p.vtc = ci.vtc; p.vtc_lo = img_lo(pa, ci.vtc_lo);
     p.prec = pa; p.L = kBlocks; p.B = B; p.H = kHeads; p.dh = kDh; p.dhp = 128;
     p.R = R > 0 ? R : 0; p.P = P > 0 ? P : 0; p.Rp = ci.Rp; p.Cp = ci.Cp;
     ProfTag ptag("dit");
@@ -1328,13 +1377,20 @@ int Engine::sample(hipStream_t st, int mode, int n_steps, int cfg, float s_text,
     // The table does not depend on the batch's data, only the first AdaLN needs it: in latency tuning it is computed on the
     // engine's side stream while the main stream packs the cross-KV images and embeds the first step's input (0.2 ms of tiny-M
     // GEMMs that fill a fraction of the chip); the main stream joins right before its first ln_modulate (denoise_core).
+    // (an early return between the fork and the first denoise_core must not leave the flag set for the next call, nor the side
+    // stream's writes into this workspace unordered against whatever the caller does next on `st`: ADVICE r3)
+    struct JoinGuard {
+        Engine* e; hipStream_t st;
+        ~JoinGuard() { if (e->join_pending_) { (void)hipStreamWaitEvent(st, e->ev_join_, 0); e->join_pending_ = false; } }
+    } join_guard{this, st};
     if (dual_stream_ && !prof_on_) {
         if (ensure_aux()) return 1;
         HIPC(hipEventRecord(ev_fork_, st));
         HIPC(hipStreamWaitEvent(aux_, ev_fork_, 0));
-        if (modulation(aux_, s.ts, n_steps, m.sinb, m.t1, m.temb, m.e1, m.semb, m.mod)) return 1;
-        HIPC(hipEventRecord(ev_join_, aux_));
+        const int mod_rc = modulation(aux_, s.ts, n_steps, m.sinb, m.t1, m.temb, m.e1, m.semb, m.mod);
+        HIPC(hipEventRecord(ev_join_, aux_));   // recorded even when the chain failed half-way: the guard joins what was enqueued
         join_pending_ = true;
+        if (mod_rc) return 1;
     } else if (modulation(st, s.ts, n_steps, m.sinb, m.t1, m.temb, m.e1, m.semb, m.mod)) {
         return 1;
     }
@@ -1397,7 +1453,8 @@ int Engine::codec_block(hipStream_t st, const CodecBlockW& w, float** xp, float*
     const int F = cspec_.ffn_mult * C;
     const RowMap rc = rowmap_plain(C), rf = rowmap_plain(F);
     const int pf = prec_[SITE_CODEC_FFN];
-    bf16_t* const n2lo_f = sm_lo_for(pf, n2lo);  // (hi, lo) pairs handed to producers: the format the FFN GEMMs read
+    unsigned* const sf = satp(SITE_CODEC_FFN);
+    bf16_t* const n2lo_f = sm_lo_for(pf, n2lo, sf);  // (hi, lo) pairs handed to producers: the format the FFN GEMMs read
     auto wsel = [pf](const PW& w) { return pf == PREC_F16 ? w.h16 : w.hi; };
     bool n2_done = false;  // the FFN's normalised input was already produced by the fused depthwise-conv kernel
     // narrowest stages: the whole block in one pass over the image (mixer + FFN, codec_ffn_wave.hip MIX kernels)
@@ -1459,10 +1516,10 @@ int Engine::codec_block(hipStream_t st, const CodecBlockW& w, float** xp, float*
     if (C % 64 == 0) {
         SplitBuf n2{n2hi, n2lo};
         if (!n2_done) HIPC(launch_rmsnorm(x, img, nullptr, n2hi, n2lo_f, rc, M, C, cspec_.eps, w.ffn_norm_w, st));
-        HIPC(gemm3_store(ops3(n2, rc, w.w1, M, pf), ACT_GELU, store_split_to(hid.as(pf), rf, w.b1), 1, pf, st));
+        HIPC(gemm3_store(ops3(n2, rc, w.w1, M, pf), ACT_GELU, store_split_to(hid.as(pf, sf), rf, w.b1), 1, pf, st));
     } else {  // K = C < 64 (last stage, C = 32): one k-tile on the fp32-A kernel, still writing the split hidden
         HIPC(launch_rmsnorm(x, img, nbuf, nullptr, nullptr, img, M, C, cspec_.eps, w.ffn_norm_w, st));
-        HIPC(gemm_store(ops(nbuf, img, w.w1, M), ACT_GELU, store_split_to(hid.as(pf), rf, w.b1), 1, pf, st));
+        HIPC(gemm_store(ops(nbuf, img, w.w1, M), ACT_GELU, store_split_to(hid.as(pf, sf), rf, w.b1), 1, pf, st));
     }
     EpiResid<0> r{x, img, w.b2, w.ffn_gamma, 0, 0, 0, 1, nullptr};
     {
@@ -1587,7 +1644,7 @@ int Engine::codec_decode(hipStream_t st, const float* latents, int B, int T, flo
                      C % 8 == 0 && (size_t)B * (pad + Ti) * C <= max_img) {
                 // two-pass fp16 product: the image once as ONE fp16 array (pads included: the causal zeros), the weights as an fp16
                 // hi + lo pair — A W_lo + A W_hi on the DMA-ring GEMM instead of three split-bf16 passes on the fp32-A kernel
-                HIPC(launch_to_split(x, rowmap_plain(C), w.n2hi, SM_F16_TAG, rowmap_plain(C), B * (pad + Ti), C, st));
+                HIPC(launch_to_split(x, rowmap_plain(C), w.n2hi, sm_lo_for(PREC_F16, nullptr, satp(SITE_CODEC_CONV)), rowmap_plain(C), B * (pad + Ti), C, st));
                 Gemm3Operands g3 = ops3(SplitBuf{w.n2hi, w.n2lo}, am, sg.resample, B * Ti, PREC_F16);
                 g3.Wlo = sg.resample.l16;
                 HIPC(gemm3_store_x2(g3, store_to(xn, om, sg.resample_bias), st));
@@ -1596,7 +1653,7 @@ int Engine::codec_decode(hipStream_t st, const float* latents, int B, int T, flo
                 // widest stages (K >= 2048; measured: 215 -> 148 us and 216 -> 193 us, no gain at K <= 1024): split the image once (pads included: they are the causal zeros) and run the DMA-ring GEMM on
                 // the overlapping rows of the split pair (n2 is free between blocks)
                 SplitBuf xs{w.n2hi, w.n2lo};
-                HIPC(launch_to_split(x, rowmap_plain(C), xs.hi, xs.as(pg).lo, rowmap_plain(C), B * (pad + Ti), C, st));
+                HIPC(launch_to_split(x, rowmap_plain(C), xs.hi, xs.as(pg, satp(SITE_CODEC_CONV)).lo, rowmap_plain(C), B * (pad + Ti), C, st));
                 HIPC(gemm3_store(ops3(xs, am, sg.resample, B * Ti, pg), ACT_NONE, store_to(xn, om, sg.resample_bias), 1, pg, st));
             } else
                 HIPC(gemm_store(ops(x, am, sg.resample, B * Ti), ACT_NONE, store_to(xn, om, sg.resample_bias), 1, pcv3, st));
@@ -1679,7 +1736,7 @@ int Engine::codec_encode(hipStream_t st, const float* audio, int B, int S_, floa
             return false;
         SplitBuf xs{w.n2hi, w.n2lo};
         float* part = reinterpret_cast<float*>(w.hhi);   // max_hid bf16 = max_hid / 2 floats
-        hipError_t e = launch_to_split(img, rowmap_plain(Cin), xs.hi, xs.as(pcv).lo, rowmap_plain(Cin), (int)img_rows, Cin, st);
+        hipError_t e = launch_to_split(img, rowmap_plain(Cin), xs.hi, xs.as(pcv, satp(SITE_CODEC_CONV)).lo, rowmap_plain(Cin), (int)img_rows, Cin, st);
         if (e == hipSuccess) e = gemm3_store_splitk(ops3(xs, am, wt, M, pcv), part, splits, pcv, bias, out, om, st);
         if (e != hipSuccess) { fail_hip(e, "codec_encode: split-K conv"); conv_err = true; }
         return true;

@@ -181,6 +181,14 @@ class Engine {
     int test_gemm3(hipStream_t st, const float* A, const float* W, const float* bias, int M, int N, int K, int act,
                    int split, int cfg, float* C);
 
+    // fp16 range guard: per-site count of values that fp16 producers clamped to +-65504 since the last reset (device counters,
+    // common.hpp sat_note) + the static part: codec FFN blocks whose fused kernels' hidden / input bound could not be certified
+    // below the fp16 range at finalize() (those kernels do not count at run time: they are VALU-bound, see finalize_codec).
+    // Synchronises the device.
+    int get_saturations(unsigned* out, int n, bool reset);
+    const std::string& range_report() const { return range_report_; }
+    float range_worst() const { return range_worst_; }
+
     int fail(const std::string& m) { err_ = m; return 1; }
     int fail_hip(hipError_t e, const char* what);
 
@@ -215,6 +223,16 @@ class Engine {
     int check_shape(const std::string& name, std::initializer_list<long> want);
     void invalidate() { finalized_ = false; dit_ready_ = false; dec_.ready = false; enc_.ready = false; }
     void free_packs();
+
+    // the tag a producer of attention operand images is handed in place of the (unused) lo array when the images are fp16
+    bf16_t* img_lo(int pa, bf16_t* lo) const { return pa == PREC_F16 ? sm_lo_for(PREC_F16, nullptr, satp(SITE_ATTN)) : lo; }
+    int certify_codec_ffn(const std::string& name, const CodecBlockW& b, int C, int F);
+    unsigned* sat_ = nullptr;                 // [SITE_COUNT] device counters (null if the allocation failed: nothing is counted)
+    unsigned* satp(int site) const { return sat_ ? sat_ + site : nullptr; }
+    unsigned sat_static_[SITE_COUNT] = {};    // uncertified fused-kernel blocks (set by finalize)
+    float* cert_scratch_ = nullptr;           // 2 floats: max hidden bound, max input bound
+    std::string range_report_;
+    float range_worst_ = 0.f;                 // largest certified bound of the last finalize (diagnostic)
 
     int device_;
     std::string err_;

@@ -275,6 +275,7 @@ struct EpiStore {
     __device__ __forceinline__ void col16(int z, int n, const RowCtx& rc, const floatx16& acc, unsigned short (&o)[16]) const {
         const float b = bias ? bias[(long)z * bias_z + n] : 0.f;
         const bool f16 = sm_is_f16(olo);
+        unsigned sat = 0;
 #pragma unroll
         for (int r = 0; r < 16; r += 2) {
             float v0, v1;
@@ -287,7 +288,7 @@ struct EpiStore {
             v1 = rc.aux[r + 1] ? v1 : 0.f;
             unsigned p;
             if (f16) {
-                p = cvt_pk_f16_sat(v0, v1);
+                p = cvt_pk_f16_sat(v0, v1, sat);
             } else {
                 bf16x4 t;
                 t[0] = (bf16_t)v0; t[1] = (bf16_t)v1; t[2] = t[0]; t[3] = t[1];
@@ -296,6 +297,7 @@ struct EpiStore {
             o[r] = (unsigned short)(p & 0xffffu);
             o[r + 1] = (unsigned short)(p >> 16);
         }
+        sat_note(sat, olo);   // (rows past M / masked rows are zero or finite garbage of zero-padded operands: they cannot clamp)
     }
     __device__ __forceinline__ void colpair16(int, int, const RowCtx&, const floatx16&, const floatx16&, unsigned short (&)[16]) const {}
 };
@@ -345,13 +347,14 @@ struct EpiSwiGLU {
     __device__ __forceinline__ void colpair16(int, int nh, const RowCtx&, const floatx16& a, const floatx16& b, unsigned short (&o)[16]) const {
         const float v1 = b1 ? b1[nh] : 0.f, v3 = b1 ? b3[nh] : 0.f;
         const bool f16 = sm_is_f16(olo);
+        unsigned sat = 0;
 #pragma unroll
         for (int r = 0; r < 16; r += 2) {
             const float x0 = a[r] + v1, x1 = a[r + 1] + v1;
             const float w0 = silu_f(x0) * (b[r] + v3), w1 = silu_f(x1) * (b[r + 1] + v3);
             unsigned p;
             if (f16) {
-                p = cvt_pk_f16_sat(w0, w1);
+                p = cvt_pk_f16_sat(w0, w1, sat);
             } else {
                 bf16x4 t;
                 t[0] = (bf16_t)w0; t[1] = (bf16_t)w1; t[2] = t[0]; t[3] = t[1];
@@ -360,6 +363,7 @@ struct EpiSwiGLU {
             o[r] = (unsigned short)(p & 0xffffu);
             o[r + 1] = (unsigned short)(p >> 16);
         }
+        sat_note(sat, olo);
     }
 };
 

@@ -394,6 +394,38 @@ hipError_t launch_f16_residual(const float* src, long src_ld, const bf16_t* h16,
     LAUNCH_CHECK();
 }
 
+// fp16 range certificate of a fused codec FFN block (Engine::certify_codec_ffn).  The block's input is RMS-normalised,
+// n = x / rms(x) o g with ||x / rms(x)||_2 <= sqrt(C), so for every hidden unit j and EVERY input
+//     |gelu(W1_j . n + b1_j)| <= |W1_j . n + b1_j| <= sqrt(C) ||W1_j o g||_2 + |b1_j|        (Cauchy-Schwarz)
+// out[0] = max over j of that bound, out[1] = sqrt(C) max_c |g_c| (bound of the normalised input itself).  Non-negative floats
+// order like their bit patterns, so the maxima are integer atomics.  One wave per hidden unit.
+__global__ __launch_bounds__(256) void ffn_range_bound_kernel(const float* __restrict__ w1, const float* __restrict__ b1,
+                                                              const float* __restrict__ g, int F, int C, float* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (j >= F) return;
+    float ss = 0.f, gm = 0.f;
+    for (int c = lane; c < C; c += 64) {
+        const float gv = g ? g[c] : 1.f;
+        const float v = w1[(long)j * C + c] * gv;
+        ss = fmaf(v, v, ss);
+        gm = fmaxf(gm, fabsf(gv));
+    }
+    ss = wave_sum(ss);
+    gm = wave_max(gm);
+    if (lane == 0) {
+        const float rc = sqrtf((float)C);
+        float bound = rc * sqrtf(ss) * 1.0001f + (b1 ? fabsf(b1[j]) : 0.f);   // (1.0001: rounding of this very sum)
+        if (!(bound == bound)) bound = INFINITY;                              // NaN weights certify nothing
+        atomicMax(reinterpret_cast<int*>(out), __float_as_int(bound));
+        if (j == 0) atomicMax(reinterpret_cast<int*>(out) + 1, __float_as_int(rc * gm));
+    }
+}
+hipError_t launch_ffn_range_bound(const float* w1, const float* b1, const float* g, int F, int C, float* out2, hipStream_t st) {
+    hipLaunchKernelGGL(ffn_range_bound_kernel, dim3((F + 3) / 4), dim3(256), 0, st, w1, b1, g, F, C, out2);
+    LAUNCH_CHECK();
+}
+
 __global__ void fill_kernel(float* __restrict__ p, float v, long n) {
     long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) p[i] = v;

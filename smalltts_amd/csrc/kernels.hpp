@@ -123,6 +123,8 @@ hipError_t launch_split_rows(const float* src, long src_ld, bf16_t* hi, bf16_t* 
                              const int* perm, hipStream_t st, bf16_t* h16 = nullptr);
 // l16 = fp16(src - float(h16)) over [rows][cols] (dst row stride dst_ld): low half of the fp16 weight pair of PREC_F16X2
 hipError_t launch_f16_residual(const float* src, long src_ld, const bf16_t* h16, bf16_t* l16, long dst_ld, int rows, int cols, hipStream_t st);
+// out2[0] = max_j (sqrt(C) ||W1_j o g|| + |b1_j|), out2[1] = sqrt(C) max |g|   (out2 zeroed by the caller; g / b1 may be null)
+hipError_t launch_ffn_range_bound(const float* w1, const float* b1, const float* g, int F, int C, float* out2, hipStream_t st);
 hipError_t launch_fill(float* p, float v, long n, hipStream_t st);
 hipError_t launch_copy_strided(const float* src, long sld, float* dst, long dld, int rows, int cols, hipStream_t st);
 // dst[n][k] (fp32, row-major N x K) = src[base + n1*sn1 + n0*sn0 + k1*sk1 + k0*sk0]  if k0 < k0valid else 0

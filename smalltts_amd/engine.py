@@ -19,6 +19,7 @@ N_LAYERS, N_HEADS, HEAD_DIM, LATENT = 12, 8, 120, 64
 ACT = {"none": 0, "silu": 1, "gelu": 2, "mish": 3}
 PRECISION = {"bf16x3": 3, "f16": 2, "bf16": 1,   # presets of smtts_set_precision (include/smalltts_hip.h)
              "f16x2": 4}                          # site value only (codec_conv): fp16 activations x fp16 hi + lo weights, two MFMA passes
+PRESETS = ("bf16x3", "f16", "bf16")              # what set_precision accepts in front of the site overrides
 SITES = {"dit_block": 0, "encoder": 1, "cross_kv": 2, "cond": 3, "codec_ffn": 4, "codec_conv": 5, "convpos": 6, "attn": 7}
 DEFAULT_PRECISION = "f16"
 
@@ -43,6 +44,7 @@ class HipEngine:
         self._ws_slot: Optional[str] = None   # set via use_workspace(): separate scratch per concurrent stream
         self.codec_spec: CodecSpec = DEFAULT_CODEC
         self._banks: Dict[tuple, tuple] = {}   # (down, up) -> (polyphase bank on the device, width)
+        self._demoted: Dict[str, str] = {}     # site -> why: sites the fp16 range guard moved to split-bf16 (sticky across set_precision)
         self.set_precision(precision)
 
     # ---- plumbing ------------------------------------------------------------------------------
@@ -110,13 +112,124 @@ class HipEngine:
         self._ws_named.clear()
 
     def set_precision(self, precision: str):
-        """Preset ("f16" mixed / "bf16x3" / "bf16"), optionally followed by per-site overrides: "f16,codec_ffn=bf16x3"."""
+        """Preset ("f16" mixed / "bf16x3" / "bf16"), optionally followed by per-site overrides: "f16,codec_ffn=bf16x3".
+        Sites the fp16 range guard demoted (check_fp16_range) stay at split-bf16 whatever the preset says."""
         preset, *over = precision.split(",")
+        if preset not in PRESETS:
+            raise ValueError(f"precision preset {preset!r}: one of {PRESETS} (\"f16x2\" is a value of the codec_conv site only)")
         self.precision = precision
         self._ck(self.lib.smtts_set_precision(self.h, PRECISION[preset]), "set_precision")
         for o in over:
             site, prec = o.split("=")
             self._ck(self.lib.smtts_set_site_precision(self.h, SITES[site.strip()], PRECISION[prec.strip()]), "set_site_precision")
+        for site in self._demoted:
+            self._ck(self.lib.smtts_set_site_precision(self.h, SITES[site], PRECISION["bf16x3"]), "set_site_precision")
+
+    # ---- fp16 range guard (include/smalltts_hip.h smtts_get_saturations) ----------------------------------------------
+    def saturations(self, reset: bool = True) -> Dict[str, int]:
+        """site -> number of values an fp16 producer clamped to +-65504 since the last reset (+ for codec_ffn the fused FFN
+        blocks whose range could not be certified from the weights).  Synchronises the device."""
+        n = len(SITES)
+        buf = (C.c_uint32 * n)()
+        self._ck(self.lib.smtts_get_saturations(self.h, buf, n, int(bool(reset))), "get_saturations")
+        return {name: int(buf[i]) for name, i in SITES.items()}
+
+    def check_fp16_range(self, what: str = "") -> list:
+        """Reads the saturation counters; every site that clamped is switched to split-bf16 (fp32 range) for the rest of this
+        engine's life and a RuntimeWarning says so.  Returns the sites demoted by THIS call: the caller should run the
+        operation again — its results were clipped."""
+        import warnings
+        hit = {k: v for k, v in self.saturations(reset=True).items() if v and k not in self._demoted}
+        for site, count in hit.items():
+            rep = self.lib.smtts_range_report(self.h).decode() if site == "codec_ffn" else ""
+            self._demoted[site] = f"{count} clamp(s)" + (f"; {rep}" if rep else "")
+            self._ck(self.lib.smtts_set_site_precision(self.h, SITES[site], PRECISION["bf16x3"]), "set_site_precision")
+            warnings.warn(f"fp16 range guard{' (' + what + ')' if what else ''}: site {site!r} clamped {count} value(s) to +-65504"
+                          f"{' [' + rep.strip('; ') + ']' if rep else ''}; the site now runs split-bf16 (fp32 range, ~3x its MFMA passes)",
+                          RuntimeWarning, stacklevel=3)
+        return list(hit)
+
+    def calibrate(self, tol: float = 4e-4, codec_snr_db: float = 62.0, seed: int = 1234) -> Dict[str, object]:
+        """Checks the precision preset in force ON THE WEIGHTS THAT ARE LOADED: one seeded probe batch (B = 2, N = 40, R = 10,
+        P = 12, four DMD steps; six frames through the decoder) at the preset against the same batch at split-bf16 (fp32-class
+        operands).  The synthetic recipe's tensors are outlier-free; real checkpoints are not, and "massive" hidden units make
+        every 11-bit operand rounding that follows them count for more (tools/outlier_ladder.py: rows of ff.w1 / ff.w3 x30 take
+        the fp16 DiT blocks from 1.3e-4 to 2e-2 WITHOUT a single clamp, so the saturation counters alone do not see it).  While
+        the latents differ by more than `tol` (rel-L2; the contract vs fp32 is 1e-3) the sites are moved to split-bf16 in the
+        order of their measured impact (dit_block, attn, encoder, cross_kv, then everything); likewise codec_ffn / codec_conv
+        against `codec_snr_db`.  Demotions are sticky (set_precision keeps them).  Returns what was measured and done."""
+        import warnings
+
+        def rel(a, b):
+            return float((a - b).double().norm() / b.double().norm().clamp_min(1e-30))
+
+        rep: Dict[str, object] = {"tol": tol, "demoted": []}
+        keep = self.precision
+        g = torch.Generator().manual_seed(seed)
+        if self.has("dit"):
+            B, N, R, P = 2, 40, 10, 12
+            ref = torch.randn(B, R, 64, generator=g)
+            ids = torch.randint(1, 198, (B, P), generator=g)
+            pm, mask = torch.ones(B, P, dtype=torch.bool), torch.ones(B, N, dtype=torch.bool)
+            noise = torch.randn(4, B, N, 64, generator=g)
+            rl = torch.full((B,), R)
+
+            def latents():
+                return self.sample(self.cond_encode(ref, rl, ids, pm), mask, num_steps=4, noise=noise).clone()
+
+            saved = dict(self._demoted)
+            try:
+                self._demoted = {}
+                self.set_precision("bf16x3")
+                want = latents()
+            finally:
+                self._demoted = saved
+                self.set_precision(keep)
+            err = rel(latents(), want)
+            self.check_fp16_range("calibrate")
+            rep["latent_rel_l2"] = [("as configured", err)]
+            for site in ("dit_block", "attn", "encoder", "cross_kv", "cond", "convpos"):
+                if err <= tol:
+                    break
+                if site in self._demoted:
+                    continue
+                self._demoted[site] = f"calibration: latents {err:.2e} from split-bf16 (> {tol:.0e})"
+                self.set_precision(keep)
+                err = rel(latents(), want)
+                rep["latent_rel_l2"].append((f"+ {site}=bf16x3", err))
+                rep["demoted"].append(site)
+        if self.has("decoder"):
+            lat = torch.randn(1, 6, 64, generator=g)
+
+            def snr():
+                got = self.codec_decode(lat).double()
+                return float(10 * torch.log10((wav ** 2).sum() / ((got - wav) ** 2).sum().clamp_min(1e-300)))
+
+            saved = dict(self._demoted)
+            try:
+                self._demoted = {}
+                self.set_precision("bf16x3")
+                wav = self.codec_decode(lat).double().clone()
+            finally:
+                self._demoted = saved
+                self.set_precision(keep)
+            s = snr()
+            self.check_fp16_range("calibrate")
+            rep["codec_snr_db"] = [("as configured", s)]
+            for site in ("codec_ffn", "codec_conv"):
+                if s >= codec_snr_db:
+                    break
+                if site in self._demoted:
+                    continue
+                self._demoted[site] = f"calibration: decode {s:.1f} dB from split-bf16 (< {codec_snr_db:.0f})"
+                self.set_precision(keep)
+                s = snr()
+                rep["codec_snr_db"].append((f"+ {site}=bf16x3", s))
+                rep["demoted"].append(site)
+        if rep["demoted"]:
+            warnings.warn(f"precision calibration: {', '.join(rep['demoted'])} moved to split-bf16 on these weights "
+                          f"({rep.get('latent_rel_l2')}, {rep.get('codec_snr_db')})", RuntimeWarning, stacklevel=2)
+        return rep
 
     # ---- weights -------------------------------------------------------------------------------
     def set_codec_spec(self, spec: CodecSpec):
@@ -168,6 +281,7 @@ class HipEngine:
 
     def finalize(self):
         self._ck(self.lib.smtts_finalize(self.h), "finalize")
+        self.check_fp16_range("finalize")   # static part: fused codec FFN blocks whose range the weights do not certify
 
     def has(self, part: str) -> bool:
         return bool(self.lib.smtts_has_part(self.h, {"dit": 0, "decoder": 1, "encoder": 2}[part]))

@@ -106,6 +106,33 @@ def frames_for(duration: float) -> int:
 
 MAX_FRAMES = 4096   # the engine's rope tables (dit.py:139): frames per utterance, tokens per text
 MAX_TOKENS = 4096
+MAX_REF_FRAMES = 1024   # reference voice: 137 s at 24 kHz (a 2 MiB body holds 44 s of 24 kHz PCM16, more at lower rates)
+# A padded batch costs B x max(frames) (x max(tokens), x max(ref frames)) whatever its members asked for: the packer bounds THAT,
+# not the request count.  2400 padded frames = 32 utterances of 10 s: ~10 GB of codec workspace per batch in flight; one request
+# above the budget (up to MAX_FRAMES) runs alone.  (24 x 4096 frames would have been ~100 GB and a 500 for all 24.)
+PACK_FRAMES = 2400
+PACK_TOKENS = 8192
+PACK_REF_FRAMES = 2400
+PACK_LENGTH_RATIO = 4.0   # frames of the longest / shortest member of one batch: short requests do not wait on long ones
+
+
+def plan_batches(ns, ps, rs, max_pack, frames=PACK_FRAMES, tokens=PACK_TOKENS, ref_frames=PACK_REF_FRAMES, ratio=PACK_LENGTH_RATIO):
+    """Greedy partition, in arrival order, of requests with frame counts `ns`, token counts `ps` and reference frame counts `rs`
+    into batches whose PADDED work stays inside the budgets.  Returns lists of indices; every index appears exactly once."""
+    groups, cur = [], []
+    for i in range(len(ns)):
+        trial = cur + [i]
+        n_hi, n_lo = max(ns[j] for j in trial), min(ns[j] for j in trial)
+        fits = (len(trial) <= max_pack and len(trial) * n_hi <= frames and len(trial) * max(ps[j] for j in trial) <= tokens
+                and len(trial) * max(rs[j] for j in trial) <= ref_frames and n_hi <= ratio * n_lo)
+        if cur and not fits:
+            groups.append(cur)
+            cur = [i]
+        else:
+            cur = trial
+    if cur:
+        groups.append(cur)
+    return groups
 
 
 def validate_request(duration: float, tokens) -> int:
@@ -194,6 +221,8 @@ class Batcher:
         n = (len(y) // HOP) * HOP
         if n == 0:
             raise HttpError(400, "audio decode failed: reference shorter than one codec frame (3200 samples at 24 kHz)")
+        if n // HOP > MAX_REF_FRAMES:
+            raise HttpError(400, f"audio decode failed: reference longer than {MAX_REF_FRAMES * HOP / SAMPLE_RATE:.0f} s")
         before = len(type(self.enc)._ref_cache or {})
         lat = self.enc.encode_reference(torch.from_numpy(np.ascontiguousarray(y[:n]))[None, None])
         if len(type(self.enc)._ref_cache or {}) == before:
@@ -225,31 +254,45 @@ class Batcher:
                         r.future.set_exception(HttpError(500, f"inference failed: {e}"))
                 if not ok:
                     continue
-                self._slots.acquire()                       # at most in_flight batches on the GPU
-                slot = i % self.in_flight
-                i += 1
-                try:
-                    with torch.cuda.stream(streams[slot]):
-                        self.eng.use_workspace(f"srv{slot}")
-                        # per-request noise streams: a request's result does not depend on the batch it rides in
-                        noise = torch.zeros(self.steps, len(ok), max(ns), LATENT, device=dev)
-                        for b, r in enumerate(ok):
-                            for s in range(self.steps):
-                                noise[s, b, :ns[b]] = self.eng.randn(ns[b] * LATENT, r.seed, s).view(ns[b], LATENT)
-                        audio, _, _ = self.tts.synthesize_batch(refs, [r.tokens for r in ok], [r.duration for r in ok],
-                                                                noise=noise, frames=ns, _defer=True)
-                        ev = torch.cuda.Event()
-                        ev.record()
-                    self.eng.use_workspace(None)
-                    self.stats["requests"] += len(ok)
-                    self.stats["batches"] += 1
-                    self.stats["max_batch_seen"] = max(self.stats["max_batch_seen"], len(ok))
-                    self.done_q.put((ev, audio, ns, ok))
-                except Exception as e:
-                    self.eng.use_workspace(None)
-                    self._slots.release()
-                    for r in ok:
-                        r.future.set_exception(HttpError(500, f"inference failed: {e}"))
+                # padded-work budgets, not a request count: one long request neither blows the workspace up for 23 batch-mates
+                # nor makes short requests wait for it (plan_batches); the groups go out back to back, each its own batch in flight
+                for grp in plan_batches(ns, [len(r.tokens) for r in ok], [int(x.shape[0]) for x in refs], self.max_pack):
+                    g_ok, g_refs, g_ns = [ok[j] for j in grp], [refs[j] for j in grp], [ns[j] for j in grp]
+                    self._slots.acquire()                       # at most in_flight batches on the GPU
+                    slot = i % self.in_flight
+                    i += 1
+                    try:
+                        with torch.cuda.stream(streams[slot]):
+                            self.eng.use_workspace(f"srv{slot}")
+                            # per-request noise streams: a request's result does not depend on the batch it rides in
+                            noise = torch.zeros(self.steps, len(g_ok), max(g_ns), LATENT, device=dev)
+                            for b, r in enumerate(g_ok):
+                                for s_ in range(self.steps):
+                                    noise[s_, b, :g_ns[b]] = self.eng.randn(g_ns[b] * LATENT, r.seed, s_).view(g_ns[b], LATENT)
+                            audio, _, _, _ = self.tts.synthesize_batch(g_refs, [r.tokens for r in g_ok], [r.duration for r in g_ok],
+                                                                       noise=noise, frames=g_ns, _defer=True)
+                            ev = torch.cuda.Event()
+                            ev.record()
+                        self.eng.use_workspace(None)
+                        self.stats["requests"] += len(g_ok)
+                        self.stats["batches"] += 1
+                        self.stats["max_batch_seen"] = max(self.stats["max_batch_seen"], len(g_ok))
+                        self.stats["max_padded_frames"] = max(self.stats.get("max_padded_frames", 0), len(g_ok) * max(g_ns))
+                        self.done_q.put((ev, audio, g_ns, g_ok))
+                    except Exception as e:
+                        self.eng.use_workspace(None)
+                        self._slots.release()
+                        for r in g_ok:
+                            r.future.set_exception(HttpError(500, f"inference failed: {e}"))
+                # fp16 range guard (engine.check_fp16_range): the counters are read when the queue has run dry — a device
+                # synchronisation the busy path should not pay per batch.  A site that clamped runs split-bf16 from then on; the
+                # requests that hit it were answered with saturated (finite) operands, which is what the warning is for.
+                if self.q.empty():
+                    try:
+                        if self.eng.check_fp16_range("server"):
+                            self.stats["range_demotions"] = sorted(self.eng._demoted)
+                    except Exception:
+                        pass
         finally:
             self.eng.set_tuning(prev)
             self.done_q.put(None)

@@ -131,3 +131,28 @@ def test_dispatcher_packs_a_deep_queue_but_never_waits_beyond_max_batch():
     assert g._gather() == [0, 1, 2]
     g.q.put(7); g.q.put(None)
     assert g._gather() == [7] and g._gather() is None
+
+
+def test_packing_is_bounded_by_padded_work_not_by_request_count():
+    """a padded batch costs B x max(frames); the packer bounds that (and tokens, reference frames, the length
+    ratio inside a batch) instead of packing 24 requests whatever their lengths."""
+    from smalltts_amd.server import PACK_FRAMES, PACK_LENGTH_RATIO, plan_batches
+    # 24 ordinary 10-s requests: one batch (24 x 75 = 1800 padded frames)
+    assert plan_batches([75] * 24, [30] * 24, [15] * 24, 24) == [list(range(24))]
+    # one maximal request among 23 short ones: it rides alone, the short ones share batches without it
+    ns = [75] * 10 + [4096] + [75] * 13
+    groups = plan_batches(ns, [30] * 24, [15] * 24, 24)
+    assert sorted(i for g in groups for i in g) == list(range(24))          # nobody lost, nobody twice
+    assert [10] in groups
+    for g in groups:
+        n_hi, n_lo = max(ns[i] for i in g), min(ns[i] for i in g)
+        assert len(g) == 1 or (len(g) * n_hi <= PACK_FRAMES and n_hi <= PACK_LENGTH_RATIO * n_lo), (g, n_hi, n_lo)
+    # arrival order is kept inside and across groups
+    flat = [i for g in groups for i in g]
+    assert flat == sorted(flat)
+    # token and reference budgets bind too
+    assert len(plan_batches([75] * 8, [4096] * 8, [15] * 8, 24)) == 4       # 2 x 4096 tokens per batch
+    assert len(plan_batches([75] * 8, [30] * 8, [1024] * 8, 24)) == 4       # 2 x 1024 reference frames per batch
+    # short requests do not wait on a long one: 1-s and 30-s requests never share a batch
+    groups = plan_batches([8, 225, 8, 8], [10] * 4, [15] * 4, 24)
+    assert all(len({ns_ > 100 for ns_ in ([8, 225, 8, 8][i] for i in g)}) == 1 for g in groups)
