@@ -128,6 +128,55 @@ def test_clone_cli_end_to_end(tmp_path):
     assert rate == 24000 and a.shape == (3200 * 7,) and np.isfinite(a).all()
 
 
+def test_tryme_cli_end_to_end(tmp_path):
+    """tryme.py surface (reference src/scripts/tryme.py:12-30): text (+ pre-tokenised ids: no espeak offline) -> 24 kHz PCM_16 of
+    3200 * floor(7.5 * estimate_duration(text)) samples; the reference voice falls back to a seeded one when the asset is absent."""
+    from smalltts_amd.api import estimate_duration
+    from smalltts_amd.audio import read_wav
+    text = "hello world this is a test"
+    out = tmp_path / "out" / "tryme.wav"
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-m", "smalltts_amd.scripts.tryme", text, "--tokens", "5,9,14,33,41,14,77,120,3", "--out", str(out),
+                        "--ref-latents", str(tmp_path / "absent.npy"), "--weights", "synthetic:3", "--seed", "0"],
+                       cwd=root, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "loading model" in r.stdout and str(out) in r.stdout
+    a, rate = read_wav(str(out))
+    n = max(1, int(estimate_duration(text) * 7.5))
+    assert rate == 24000 and a.shape == (3200 * n,) and np.isfinite(a).all() and np.abs(a).max() > 0
+    with open(out, "rb") as f:
+        hdr = f.read(44)
+    assert hdr[:4] == b"RIFF" and int.from_bytes(hdr[20:22], "little") == 1 and int.from_bytes(hdr[34:36], "little") == 16   # PCM_16
+
+
+def test_batch_cli_end_to_end(tmp_path):
+    """batch.py surface (reference src/scripts/infer/batch.py:13-46): assets/test_audio/transcriptions.json -> one cloned utterance
+    per listed file, out/<stem>_gen.wav, 24 kHz PCM_16 of 3200 * N samples each (here: one padded batch instead of a loop)."""
+    import json
+    from smalltts_amd.api import estimate_duration
+    from smalltts_amd.audio import read_wav, write_wav_pcm16
+    from smalltts_amd.scripts.batch import TEXTS
+    td = tmp_path / "test_audio"
+    td.mkdir()
+    names = []
+    for i, (sr, secs, f0) in enumerate(((16000, 0.9, 440.0), (24000, 1.4, 330.0), (44100, 0.7, 220.0))):
+        t = np.arange(int(secs * sr)) / sr
+        write_wav_pcm16(str(td / f"voice{i}.wav"), 0.4 * np.sin(2 * np.pi * f0 * t), sr)
+        names.append({"filename": f"voice{i}.wav", "transcription": "unused by batch.py"})
+    with open(td / "transcriptions.json", "w") as f:
+        json.dump(names, f)
+    outdir = tmp_path / "out"
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-m", "smalltts_amd.scripts.batch", "--dir", str(td), "--out", str(outdir), "--weights",
+                        "synthetic:3", "--seed", "0", "--tokenizer", "chars"], cwd=root, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    for i in range(3):
+        a, rate = read_wav(str(outdir / f"voice{i}_gen.wav"))
+        n = max(1, int(estimate_duration(TEXTS[i]) * 7.5))
+        assert rate == 24000 and a.shape == (3200 * n,) and np.isfinite(a).all(), (i, a.shape, n)
+        assert f"[{i + 1}/3] voice{i}.wav" in r.stdout
+
+
 def test_interactive_cli_loop_writes_one_wav_per_line(tmp_path):
     """interactive.py surface (reference src/scripts/infer/interactive.py:17-60): lines in, one utterance each."""
     from smalltts_amd import api
