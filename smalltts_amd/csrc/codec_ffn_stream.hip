@@ -374,11 +374,54 @@ __global__ __launch_bounds__(NW * 64) void codec_ffn_stream_kernel(FfnStreamArgs
                     fw.h[s2] = __builtin_bit_cast(bf16x8, *reinterpret_cast<uint4*>(fhh));
                 }
             };
+            // ---- the same formula on value PAIRS in packed fp16 (round 4, common.hpp gelu_q5_pk_*): v_pk_fma_f16 runs at the plain-VALU
+            // rate in the MFMA shadow (tools/ubench/mfma_valu.hip KIND 6), 5 plain + 1 transcendental instruction per value
+            // instead of 9 + 1.  17 tasks per half: per pair {convert, |.|, two Horner steps} {three Horner steps} {exp2 x 2, pack}
+            // {max, fma -> the operand pair}, then the lane swap.  No clamp: the hidden's range is certified from the weights.
+            unsigned hpP[4], axP[4], qP[4];
+            auto task_pk = [&](int k0) {
+                const int s2 = k0 / 17, k = k0 % 17;
+                if (k < 16) {
+                    const int j = k >> 2, ph = k & 3;
+                    if (ph == 0) {
+                        f32x2_t v;
+                        v.x = hr[8 * s2 + 2 * j]; v.y = hr[8 * s2 + 2 * j + 1];
+                        hpP[j] = __builtin_bit_cast(unsigned, __builtin_convertvector(v, half2_t));
+                        axP[j] = hpP[j] & 0x7fff7fffu;
+                        const half2_t ax = __builtin_bit_cast(half2_t, axP[j]);
+                        half2_t q = __builtin_elementwise_fma(h2_splat(GeluQ5::Q5), ax, h2_splat(GeluQ5::Q4));
+                        q = __builtin_elementwise_fma(q, ax, h2_splat(GeluQ5::Q3));
+                        qP[j] = __builtin_bit_cast(unsigned, q);
+                    } else if (ph == 1) {
+                        const half2_t ax = __builtin_bit_cast(half2_t, axP[j]);
+                        half2_t q = __builtin_elementwise_fma(__builtin_bit_cast(half2_t, qP[j]), ax, h2_splat(GeluQ5::Q2));
+                        q = __builtin_elementwise_fma(q, ax, h2_splat(GeluQ5::Q1));
+                        q = __builtin_elementwise_fma(q, ax, h2_splat(GeluQ5::Q0));
+                        qP[j] = __builtin_bit_cast(unsigned, q);
+                    } else if (ph == 2) {
+                        qP[j] = __builtin_bit_cast(unsigned, __builtin_elementwise_exp2(__builtin_bit_cast(half2_t, qP[j])));
+                    } else {
+                        hiP[j] = gelu_q5_pk_back(hpP[j], axP[j], qP[j]);
+                    }
+                } else {
+                    unsigned fhh[4];
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        auto rh = __builtin_amdgcn_permlane32_swap(hiP[e], hiP[2 + e], false, false);
+                        fhh[e] = rh[0]; fhh[2 + e] = rh[1];
+                    }
+                    fw.h[s2] = __builtin_bit_cast(bf16x8, *reinterpret_cast<uint4*>(fhh));
+                }
+            };
 #ifndef FFN_GELUQ5
 #define FFN_GELUQ5 1
 #endif
+#ifndef FFN_GELU_PK16
+#define FFN_GELU_PK16 1
+#endif
             constexpr bool PK = FFN_GELUQ5 && G3;
-            constexpr int NTASK = PK ? 58 : 84;
+            constexpr bool PK16 = FFN_GELU_PK16 && PK && SPLIT == PREC_F16;
+            constexpr int NTASK = PK16 ? 34 : PK ? 58 : 84;
             if (NG == 0) {
                 // (no such step: the first step has P1, the last has P2)
             }
@@ -423,7 +466,7 @@ __global__ __launch_bounds__(NW * 64) void codec_ffn_stream_kernel(FfnStreamArgs
                     if (G)
 #pragma unroll
                         for (int k = NTASK * c / NCH; k < NTASK * (c + 1) / NCH; ++k) {
-                            if constexpr (PK) task_q5(k); else task(k);
+                            if constexpr (PK16) task_pk(k); else if constexpr (PK) task_q5(k); else task(k);
                         }
 #endif
                 }

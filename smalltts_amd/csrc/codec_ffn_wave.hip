@@ -95,6 +95,11 @@ __global__ __launch_bounds__(NWV * 64, (C == 64 && SPLIT != 3 && NWV == 4) ? FW_
     // GeluQ5 (common.hpp): max(x, 0) - |x| 2^q(|x|) — 8 plain instructions, one transcendental, no packed phases: replaces the
     // A / B / C / D split below for the single-array formats (B = Horner + exp2 under the first product, D = result + convert)
     constexpr bool Q5 = FFN_GELUQ5 && SPLIT != 3;
+#ifndef FFN_GELU_PK16
+#define FFN_GELU_PK16 1
+#endif
+    // ... and for the fp16 format in PACKED fp16 (common.hpp gelu_q5_pk_*): two values per lane-instruction, 5 + 1 instead of 9 + 1
+    constexpr bool PK16 = FFN_GELU_PK16 && Q5 && SPLIT == PREC_F16;
     constexpr int W_ARR = F * RB1;         // = C * RB2 = 8 C^2
     constexpr int OFF_W1 = 0, OFF_W2 = NARR * W_ARR, OFF_V = 2 * NARR * W_ARR;  // then b1[F] b2[C] gamma[C] norm_w[C] (fp32)
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -326,7 +331,12 @@ __global__ __launch_bounds__(NWV * 64, (C == 64 && SPLIT != 3 && NWV == 4) ? FW_
             __builtin_amdgcn_sched_barrier(0);
             // ---- B: first product of tile t+1 || t = 1 / (1 + p z), e = exp2(.) of the 16 values ----
             f32x2 tt[8], ee[8];
+            unsigned hp[8], axp[8], eep[8];   // PK16: the tile as packed fp16 pairs, |.| of them, 2^q(|.|)
             auto trans = [&](int v) {
+                if constexpr (PK16) {
+                    if (!(v & 1)) gelu_q5_pk_front(u[v >> 1].x, u[v >> 1].y, hp[v >> 1], axp[v >> 1], eep[v >> 1]);
+                    return;
+                }
                 const float xv = (v & 1) ? u[v >> 1].y : u[v >> 1].x;
                 if constexpr (Q5) {
                     const float ax = fabsf(xv);
@@ -388,6 +398,10 @@ __global__ __launch_bounds__(NWV * 64, (C == 64 && SPLIT != 3 && NWV == 4) ? FW_
             // ---- D: second product of tile t-1 || gelu = x/2 + |x/2| erf, bf16 split, lane swap -> fragments of tile t ----
             unsigned hiP[8], loP[8];
             auto finish = [&](int pr) {
+                if constexpr (PK16) {
+                    hiP[pr] = gelu_q5_pk_back(hp[pr], axp[pr], eep[pr]);
+                    return;
+                }
                 float rx, ry;
                 if constexpr (Q5) {
                     rx = fmaf(-fabsf(u[pr].x), ee[pr].x, relu_f(u[pr].x));

@@ -9,6 +9,11 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 typedef float floatx4 __attribute__((ext_vector_type(4)));
+typedef _Float16 half_t;
+typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
+typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
+typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
 
 #define SMTTS_WAVE 64
 
@@ -125,6 +130,33 @@ __device__ __forceinline__ float gelu_q5_f(float x) {
     q = fmaf(q, a, GeluQ5::Q0);
     return fmaf(-a, __builtin_amdgcn_exp2f(q), relu_f(x));
 }
+// GeluQ5 on a PAIR of values in packed fp16 (round 4; tests/studies/gelu_f16_packed.py, tools/ubench/mfma_valu.hip KIND 6):
+// the fused codec FFN kernels round the hidden to fp16 anyway, v_pk_fma_f16 handles two values per lane-instruction at the
+// plain-VALU rate AND in the shadow of MFMAs (unlike v_pk_fma_f32), so the same formula costs 5 plain + 1 transcendental
+// instruction per value instead of 9 + 1 (fp32 evaluation + convert + clamp).  Cost in audio: 67.8 -> 67.5 dB of decode SNR with
+// it on every stage from C = 256 down (CPU emulation).  The input is NOT clamped: callers run only where the hidden's range
+// is certified from the weights (Engine::certify_codec_ffn) — |h| < 65504 by construction.
+//   front: h -> (hp = fp16 pair, ax = |hp|, e = 2^q(ax));   back: max(hp, 0) - ax * e, already the packed operand pair
+__device__ __forceinline__ half2_t h2_splat(float c) { half2_t r = {(half_t)c, (half_t)c}; return r; }
+__device__ __forceinline__ void gelu_q5_pk_front(float a, float b, unsigned& hp, unsigned& axp, unsigned& ep) {
+    f32x2_t v;
+    v.x = a; v.y = b;
+    const half2_t h = __builtin_convertvector(v, half2_t);
+    hp = __builtin_bit_cast(unsigned, h);
+    axp = hp & 0x7fff7fffu;
+    const half2_t ax = __builtin_bit_cast(half2_t, axp);
+    half2_t q = __builtin_elementwise_fma(h2_splat(GeluQ5::Q5), ax, h2_splat(GeluQ5::Q4));
+    q = __builtin_elementwise_fma(q, ax, h2_splat(GeluQ5::Q3));
+    q = __builtin_elementwise_fma(q, ax, h2_splat(GeluQ5::Q2));
+    q = __builtin_elementwise_fma(q, ax, h2_splat(GeluQ5::Q1));
+    q = __builtin_elementwise_fma(q, ax, h2_splat(GeluQ5::Q0));
+    ep = __builtin_bit_cast(unsigned, __builtin_elementwise_exp2(q));
+}
+__device__ __forceinline__ unsigned gelu_q5_pk_back(unsigned hp, unsigned axp, unsigned ep) {
+    const half2_t z = {(half_t)0.f, (half_t)0.f};
+    const half2_t r = __builtin_elementwise_max(__builtin_bit_cast(half2_t, hp), z);
+    return __builtin_bit_cast(unsigned, __builtin_elementwise_fma(-__builtin_bit_cast(half2_t, axp), __builtin_bit_cast(half2_t, ep), r));
+}
 __device__ __forceinline__ float mish_f(float x) {
     // x * tanh(softplus(x)); softplus with torch's threshold (20) for parity
     float sp = x > 20.0f ? x : log1pf(expf(x));
@@ -151,11 +183,6 @@ __device__ __forceinline__ float apply_act(float x) {
 //   PREC_F16X2   (SITE_CODEC_CONV's ConvTranspose products only) A as one fp16 array, W as an fp16 hi + lo pair:
 //                acc += A W_lo + A W_hi (2 MFMAs): the weights exact to ~22 bits, the activations rounded to 11
 enum { PREC_BF16 = 1, PREC_F16 = 2, PREC_BF16X3 = 3, PREC_F16X2 = 4 };
-typedef _Float16 half_t;
-typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
-typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
-typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
-typedef float f32x2_t __attribute__((ext_vector_type(2)));
 // The fp16 tag: low two address bits == 2.  The REST of the tag, when non-zero, is the address of a saturation counter (unsigned,
 // 4-byte aligned, device memory): every producer that clamps a value to +-65504 while writing this format adds to it (sat_note).
 // Real lo arrays are 256-byte aligned workspace carve-outs (engine.hip Bump) or hipMalloc'ed packs, so their low bits are zero.

@@ -24,7 +24,8 @@ __device__ __forceinline__ void mfma_phase(floatx16& acc, bf16x8 a, bf16x8 b) {
     for (int i = 0; i < NM; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
 }
 struct V4 { f32x2 v[4]; float e[4]; };
-// KIND of the NV vector instructions: 0 v_pk_fma_f32, 1 v_fma_f32, 2 v_and_b32, 3 v_cvt_pk_bf16_f32, 4 v_pk_mul_f32, 5 none (only the NT v_exp_f32)
+// KIND of the NV vector instructions: 0 v_pk_fma_f32, 1 v_fma_f32, 2 v_and_b32, 3 v_cvt_pk_bf16_f32, 4 v_pk_mul_f32, 5 none (only the NT v_exp_f32),
+// 6 v_pk_fma_f16, 7 v_pk_max_f16, 8 v_cvt_pk_f16_f32;  -DTEXP16: the NT transcendentals are v_exp_f16
 #ifndef KIND
 #define KIND 0
 #endif
@@ -34,6 +35,16 @@ __device__ __forceinline__ void valu_one(V4& s, f32x2 c, int i) {
     if (KIND == 2) asm volatile("v_and_b32 %0, %0, %1" : "+v"(s.e[i & 3]) : "v"(c.x));
     if (KIND == 3) asm volatile("v_cvt_pk_bf16_f32 %0, %0, %1" : "+v"(s.e[i & 3]) : "v"(c.x));
     if (KIND == 4) asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(s.v[i & 3]) : "v"(c));
+    if (KIND == 6) asm volatile("v_pk_fma_f16 %0, %0, %1, %1" : "+v"(s.e[i & 3]) : "v"(c.x));   // round 4: packed fp16 (GELU in fp16?)
+    if (KIND == 7) asm volatile("v_pk_max_f16 %0, %0, %1" : "+v"(s.e[i & 3]) : "v"(c.x));
+    if (KIND == 8) asm volatile("v_cvt_pk_f16_f32 %0, %0, %1" : "+v"(s.e[i & 3]) : "v"(c.x));
+}
+__device__ __forceinline__ void texp(float& v) {
+#ifdef TEXP16
+    asm volatile("v_exp_f16 %0, %0" : "+v"(v));
+#else
+    asm volatile("v_exp_f32 %0, %0" : "+v"(v));
+#endif
 }
 __device__ __forceinline__ void valu_phase(V4& s, f32x2 c) {
 #pragma unroll
@@ -90,8 +101,8 @@ __global__ __launch_bounds__(512) void k(int steps, int mode, float* sink, unsig
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
 #pragma unroll
                 for (int j = 0; j < NV / NM; ++j) valu_one(st, c, j);
-                if (i < NT) asm volatile("v_exp_f32 %0, %0" : "+v"(st.e[i & 3]));
-                if (i + NM < NT) asm volatile("v_exp_f32 %0, %0" : "+v"(st.e[(i + 1) & 3]));
+                if (i < NT) texp(st.e[i & 3]);
+                if (i + NM < NT) texp(st.e[(i + 1) & 3]);
             }
         }
     }
