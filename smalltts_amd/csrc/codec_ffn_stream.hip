@@ -44,7 +44,6 @@ struct FfnStreamArgs {
     const float* gamma;    // [C]
     int M;
     float eps;
-    const bf16_t* n2;      // N2IN kernels: RMSNorm(x) * norm_w already written by the mixer as dense fp16 rows [M][C] (null: computed here)
 };
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -76,12 +75,12 @@ extern "C" int smtts_debug_clear_fs_timeline(void) {
 #define FS_STAMPR(i) do { } while (0)
 #endif
 
-// N2IN (round 4): the first product's operand comes from the mixer (kernels.hip mixer_fused, n2 rows) by LDS-DMA into a wave-private
-// tile [KK1][64 lanes][16 B] — the B fragments in register order — requested one whole pass ahead: the top of a pass is KK1
-// ds_read_b128 instead of a global round trip + RMSNorm + conversion of the fp32 tile (per-pass timeline, profiles/r04j_*: 4.4 us
-// of load + norm and 5.0 us of waiting at the first barrier for the slowest wave's tile, of a 36 us pass), and the fp32 tile's
-// C / 2 registers are never needed at the top.  The residual still comes from the fp32 image (re-read late, as before).
-template <int C, int SPLIT, int NW, int S, bool N2IN = false>
+// (Round 4 measured a variant that takes the first product's operand from the mixer — fp16 rows by LDS-DMA into a wave-private tile, one
+// pass ahead, no fp32 tile at the top of the pass: FFN 282 -> 268 us (C = 128) and 242 -> 222 us (C = 256), but the mixer that has to
+// write those rows 121 -> 163 and 73 -> 93 us — a net loss, and the per-pass timeline shows why the FFN gains so little: the wait only
+// moves to the residual re-read, which was an L2 hit behind the top-of-pass load and is a cold HBM read without it.  Commit aefe457,
+// profiles/r04k_*; tools/ffn_stream_timeline.py + -DFS_TIMELINE is the instrumentation.)
+template <int C, int SPLIT, int NW, int S>
 __global__ __launch_bounds__(NW * 64) void codec_ffn_stream_kernel(FfnStreamArgs a) {
     constexpr int F = 4 * C;
     constexpr int KK1 = C / 16;             // k16 steps of the first product
@@ -103,13 +102,7 @@ __global__ __launch_bounds__(NW * 64) void codec_ffn_stream_kernel(FfnStreamArgs
     constexpr int PW = PIECES / NW;         // per wave
     constexpr int HALF = NARR * (W1T / 1024);  // pieces [0, HALF) are W1, [HALF, PIECES) W2
     constexpr int OFF_V = S * SLOT;         // b1[F] b2[C] gamma[C] norm_w[C] (fp32)
-    constexpr int TILE_W = KK1 * 1024;      // N2IN: bytes of one wave's operand tile (32 frames x C fp16)
-#ifdef FS_TIMELINE
-    constexpr int OFF_T = OFF_V + 7 * C * 4 + FS_TL_PASSES * FS_TL_N * 8;
-#else
-    constexpr int OFF_T = OFF_V + 7 * C * 4;
-#endif
-    static_assert(!N2IN || SPLIT == PREC_F16, "the mixer writes one fp16 array");
+
     static_assert(PW * NW == PIECES, "DMA pieces must divide over the waves");
     static_assert((S - 2) * PW <= 63 && S >= 2, "vmcnt immediate");
     static_assert(NT1 % 2 == 0 && NT1 >= 4, "pipeline assumes an even number of hidden tiles");
@@ -178,15 +171,6 @@ __global__ __launch_bounds__(NW * 64) void codec_ffn_stream_kernel(FfnStreamArgs
         }
     };
 
-    // N2IN: this wave's operand tile of pass p (rows past M: a valid row, computed and not stored)
-    auto issue_tile = [&](int p) {
-        int mm = ((blockIdx.x + p * (int)gridDim.x) * NW + wave) * 32 + fr;
-        mm = mm < a.M ? mm : a.M - 1;
-        const unsigned voff = (unsigned)(mm * C + 8 * fh) * 2u;
-        const unsigned tb = lds0 + (unsigned)(OFF_T + wave * TILE_W);
-#pragma unroll
-        for (int kk = 0; kk < KK1; ++kk) dma16(a.n2 + 16 * kk, voff, tb + (unsigned)(kk * 1024));
-    };
 #ifdef FS_PHASE_TICKS   // (A/B builds: with two 4-wave workgroups per CU, hold the second half of the grid back by this many 10-ns ticks so
                         // that the two workgroups of a CU do their tile I/O at different times)
     if (blockIdx.x >= gridDim.x / 2) {
@@ -200,7 +184,6 @@ __global__ __launch_bounds__(NW * 64) void codec_ffn_stream_kernel(FfnStreamArgs
 #pragma unroll 1
     for (int s = 0; s < S - 1; ++s)
         if (s < total) issue(s);
-    if (N2IN && my_passes > 0) issue_tile(0);
 
     // fragment byte offsets inside a slot
     // W1 fragment of k16 step kk: row fr, 16-B chunk c = 2 kk + fh stored at (c & ~15) | ((c ^ fr) & 15).  (c ^ fr) & 15 =
@@ -241,9 +224,9 @@ __global__ __launch_bounds__(NW * 64) void codec_ffn_stream_kernel(FfnStreamArgs
     // within the same few microseconds (32 MB of stores, then 32 MB of reads, per round of passes), and nothing computes while
     // HBM serves it.  Each width keeps the variant that helps it (-DFS_XNEXT=0/1 -DFS_XO_EARLY=0/1 force one for A/B builds).
 #ifdef FS_XNEXT
-    constexpr bool XNEXT = FS_XNEXT && !N2IN;
+    constexpr bool XNEXT = FS_XNEXT;
 #else
-    constexpr bool XNEXT = C == 256 && !N2IN;
+    constexpr bool XNEXT = C == 256;
 #endif
 #ifdef FS_XO_EARLY
     constexpr bool XO_EARLY = FS_XO_EARLY;
@@ -251,7 +234,7 @@ __global__ __launch_bounds__(NW * 64) void codec_ffn_stream_kernel(FfnStreamArgs
     constexpr bool XO_EARLY = C == 128;
 #endif
     constexpr int XL = XO_EARLY ? 4 * NOT : 0;   // loads of the early re-read (per lane)
-    static_assert((S - 2) * PW + XL <= 63 && (S - 2) * PW + (N2IN ? KK1 : 0) <= 63, "vmcnt immediate");
+    static_assert((S - 2) * PW + XL <= 63, "vmcnt immediate");
     if (XNEXT && my_passes > 0) load_x(0);
 #pragma unroll 1
     for (int p = 0; p < my_passes; ++p) {
@@ -261,19 +244,7 @@ __global__ __launch_bounds__(NW * 64) void codec_ffn_stream_kernel(FfnStreamArgs
         FS_STAMPR(150);
         // ---- x -> RMSNorm -> split bf16 B fragments (lane = frame, channels 16 kk + 8 fh + e) -------------------
         bf16x8 nh[KK1], nl[KK1];
-        if constexpr (N2IN) {
-            if (p == 0) {
-                wait_vmcnt<0>();   // the first tile (and the ring prologue): once per launch
-                __syncthreads();   // the LDS vectors written above are visible
-            }
-            const char* tb = smem + OFF_T + wave * TILE_W + lane * 16;
-#pragma unroll
-            for (int kk = 0; kk < KK1; ++kk) { nh[kk] = *reinterpret_cast<const bf16x8*>(tb + kk * 1024); nl[kk] = nh[kk]; }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the reads are done before the next tile lands in the same bytes
-            // always requested (behind the last pass: a clamped row) — the counted waits of the first S - 1 steps allow for
-            // exactly these KK1 younger loads
-            issue_tile(p + 1);
-        } else {
+        {
             if (!XNEXT) load_x(p);
             float ss = 0.f;
 #pragma unroll
@@ -549,21 +520,10 @@ __global__ __launch_bounds__(NW * 64) void codec_ffn_stream_kernel(FfnStreamArgs
         using F_ = std::false_type;
         // step i: P1 -> H[i & 1]; GELU: H[(i+1) & 1] -> Fr[(i+1) & 1]; P2 reads Fr[i & 1]
         using Y0 = std::integral_constant<int, 0>;
-        // N2IN: the next pass's tile (KK1 DMA pieces per wave) was requested at the top of this pass, i.e. it is YOUNGER than the ring
-        // slots steps 0 .. S - 2 wait for and OLDER than those of every later step (which therefore complete behind it, in order)
-        static_assert(S <= 5 && NT1 >= 6, "the first four steps are peeled for the tile allowance");
-#define FS_YT(j) std::integral_constant<int, (N2IN && (j) <= S - 2) ? KK1 : 0>{}
-        step(T_{}, F_{}, F_{}, 0, H0, H0, F1, F0, FS_YT(0));  // (no GELU / second product yet: hr, fr_ unused)
-        step(T_{}, T_{}, F_{}, 1, H1, H0, F0, F1, FS_YT(1));
-        int i0 = 2;
-        if constexpr (N2IN && S > 2) {
-            step(T_{}, T_{}, T_{}, 2, H0, H1, F1, F0, FS_YT(2));
-            step(T_{}, T_{}, T_{}, 3, H1, H0, F0, F1, FS_YT(3));
-            i0 = 4;
-        }
-#undef FS_YT
+        step(T_{}, F_{}, F_{}, 0, H0, H0, F1, F0, Y0{});  // (no GELU / second product yet: hr, fr_ unused)
+        step(T_{}, T_{}, F_{}, 1, H1, H0, F0, F1, Y0{});
 #pragma unroll 1
-        for (int i = i0; i < NT1; i += 2) {
+        for (int i = 2; i < NT1; i += 2) {
             step(T_{}, T_{}, T_{}, i, H0, H1, F1, F0, Y0{});
             step(T_{}, T_{}, T_{}, i + 1, H1, H0, F0, F1, Y0{});
         }
@@ -633,16 +593,16 @@ __global__ __launch_bounds__(NW * 64) void codec_ffn_stream_kernel(FfnStreamArgs
 #endif
 }
 
-template <int C, int SPLIT, int NW, int S, bool N2IN = false>
+template <int C, int SPLIT, int NW, int S>
 static hipError_t ffn_stream_go(const FfnStreamArgs& a, hipStream_t st) {
     constexpr int NARR = SPLIT == 3 ? 2 : 1;
 #ifdef FS_TIMELINE
-    constexpr size_t lds = (size_t)S * NARR * 128 * C + (size_t)7 * C * 4 + FS_TL_PASSES * FS_TL_N * 8 + (N2IN ? (size_t)NW * 64 * C : 0);
+    constexpr size_t lds = (size_t)S * NARR * 128 * C + (size_t)7 * C * 4 + FS_TL_PASSES * FS_TL_N * 8;
 #else
-    constexpr size_t lds = (size_t)S * NARR * 128 * C + (size_t)7 * C * 4 + (N2IN ? (size_t)NW * 64 * C : 0);
+    constexpr size_t lds = (size_t)S * NARR * 128 * C + (size_t)7 * C * 4;
 #endif
-    static_assert(lds <= 160 * 1024, "ring + operand tiles exceed LDS");
-    auto kern = codec_ffn_stream_kernel<C, SPLIT, NW, S, N2IN>;
+    static_assert(lds <= 160 * 1024, "ring exceeds LDS");
+    auto kern = codec_ffn_stream_kernel<C, SPLIT, NW, S>;
     static DevOnce once;
     int cus = 256;
     hipError_t e = once.ensure([&] {
@@ -660,17 +620,12 @@ static hipError_t ffn_stream_go(const FfnStreamArgs& a, hipStream_t st) {
 }
 
 // C in {128, 256}; w1 [F][C] split bf16, w2t tile-major [F/32][C][32] split bf16 (launch_w2_tile_pack)
-bool codec_ffn_stream_takes_n2(int C, int split) {
-    static const bool off = getenv("SMTTS_STREAM_N2") && atoi(getenv("SMTTS_STREAM_N2")) == 0;   // A/B: mixer without n2 + in-kernel norm
-    return !off && (C == 128 || C == 256) && split == PREC_F16;
-}
 hipError_t launch_codec_ffn_stream(float* x, RowMap img, const float* norm_w, const bf16_t* w1hi, const bf16_t* w1lo,
                                    const float* b1, const bf16_t* w2thi, const bf16_t* w2tlo, const float* b2, const float* gamma,
-                                   int M, int C, int F, float eps, int split, hipStream_t st, const bf16_t* n2) {
+                                   int M, int C, int F, float eps, int split, hipStream_t st) {
     if (!(C == 128 || C == 256) || F != 4 * C || img.ld % 4 || img.off % 4 || (img.rpb && img.bstride % 4)) return hipErrorInvalidValue;
-    if (n2 && (split != PREC_F16 || (long)M * C * 2 >= (1L << 32))) return hipErrorInvalidValue;   // (32-bit lane offsets into the n2 rows)
     if (M <= 0) return hipSuccess;
-    FfnStreamArgs a{x, img, norm_w, w1hi, w1lo, b1, w2thi, w2tlo, b2, gamma, M, eps, n2};
+    FfnStreamArgs a{x, img, norm_w, w1hi, w1lo, b1, w2thi, w2tlo, b2, gamma, M, eps};
     ProfScope ps(st, C == 128 ? "codec_ffn_stream<128>" : "codec_ffn_stream<256>", 4.0 * M * (double)C * F, 8.0 * M * C + 8.0 * (double)C * F);
 #ifndef FS_S128
 #define FS_S128 4
@@ -681,10 +636,6 @@ hipError_t launch_codec_ffn_stream(float* x, RowMap img, const float* norm_w, co
 #ifndef FS_S256
 #define FS_S256 4
 #endif
-    if (n2) {   // operand tiles in LDS next to the ring: C = 128: 4 slots x 16 KiB + 8 x 8 KiB; C = 256: 2 slots x 32 KiB + 4 x 16 KiB
-        if (C == 128) return ffn_stream_go<128, 2, 8, 4, true>(a, st);
-        return ffn_stream_go<256, 2, 4, 2, true>(a, st);
-    }
     if (C == 128) return split == 3 ? ffn_stream_go<128, 3, 8, 4>(a, st) : split == PREC_F16 ? ffn_stream_go<128, 2, FS_NW128, FS_S128>(a, st) : ffn_stream_go<128, 1, 8, 4>(a, st);
     return split == 3 ? ffn_stream_go<256, 3, 4, 2>(a, st) : split == PREC_F16 ? ffn_stream_go<256, 2, 4, FS_S256>(a, st) : ffn_stream_go<256, 1, 4, 4>(a, st);
 }

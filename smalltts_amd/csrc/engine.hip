@@ -1466,12 +1466,8 @@ int Engine::codec_block(hipStream_t st, const CodecBlockW& w, float** xp, float*
         return 0;
     }
     // mixer: RMSNorm -> causal depthwise conv -> LayerScale residual
-    // the streamed FFN (C = 128 / 256, fp16) takes its first product's operand rows from the mixer (round 4)
-    const bool stream_n2 = w.w2t.N && fused_ffn_ && codec_ffn_stream_takes_n2(C, pf) && (size_t)M * C <= n2_elems;
     if (C <= 256 && 256 % (C / 4) == 0 && cspec_.kernel <= 7 && fused_ffn_) {  // narrow stages: one out-of-place kernel, then swap images
-        HIPC(launch_mixer_fused(x, *xaltp, w.norm_w, w.dw_w, w.dw_b, w.gamma, B, T, C, cspec_.kernel, pad, cspec_.eps, st,
-                                stream_n2 ? w.ffn_norm_w : nullptr, stream_n2 ? n2hi : nullptr, stream_n2 ? n2lo_f : nullptr));
-        n2_done = stream_n2;
+        HIPC(launch_mixer_fused(x, *xaltp, w.norm_w, w.dw_w, w.dw_b, w.gamma, B, T, C, cspec_.kernel, pad, cspec_.eps, st));
         *xp = *xaltp;
         *xaltp = x;
         x = *xp;
@@ -1503,7 +1499,7 @@ int Engine::codec_block(hipStream_t st, const CodecBlockW& w, float** xp, float*
     if (w.w2t.N && fused_ffn_) {
         // C = 128 / 256: weights stream through an LDS ring, hidden in registers (codec_ffn_stream.hip)
         HIPC(launch_codec_ffn_stream(x, img, w.ffn_norm_w, wsel(w.w1), w.w1.lo, w.b1, wsel(w.w2t), w.w2t.lo, w.b2, w.ffn_gamma, M, C, F,
-                                     cspec_.eps, pf, st, (stream_n2 && n2_done) ? n2hi : nullptr));
+                                     cspec_.eps, pf, st));
         return 0;
     }
     // wide stages: two gemm3 launches; n2 / hidden are split bf16 pairs

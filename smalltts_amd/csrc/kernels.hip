@@ -951,15 +951,10 @@ hipError_t launch_splitk_resid(const float* part, int S, float* x, const float* 
 // ------------------------------------------------------------------------------------------
 // fused RMSNorm + causal depthwise conv + LayerScale residual (codec mixer), C <= 256, out of place
 // ------------------------------------------------------------------------------------------
-// n2hi != null (round 4): additionally the FFN's normalised input of the updated rows, n2 = x_mid * rstd(x_mid) * ffn_norm_w, as
-// dense 16-bit rows [B * T][C] in the operand format `n2lo` selects (common.hpp) — codec_ffn_stream then takes its first product's
-// operand by LDS-DMA instead of loading, normalising and converting the fp32 tile at the top of every pass.
 __global__ __launch_bounds__(256) void mixer_fused_kernel(const float* __restrict__ xin, float* __restrict__ xout,
                                                           const float* __restrict__ norm_w, const float* __restrict__ w,
                                                           const float* __restrict__ bias, const float* __restrict__ gamma,
-                                                          int T, int C, int K, int pad, float eps, int TT, int tiles_per_b,
-                                                          const float* __restrict__ ffn_norm_w, bf16_t* __restrict__ n2hi,
-                                                          bf16_t* __restrict__ n2lo) {
+                                                          int T, int C, int K, int pad, float eps, int TT, int tiles_per_b) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int C4 = C >> 2, H = K - 1;
     float* xs = sm;                         // [(TT + H)][C]
@@ -998,16 +993,10 @@ __global__ __launch_bounds__(256) void mixer_fused_kernel(const float* __restric
     const float4 g = reinterpret_cast<const float4*>(norm_w)[c4];
     const float4 bb = reinterpret_cast<const float4*>(bias)[c4];
     const float4 gm = reinterpret_cast<const float4*>(gamma)[c4];
-    float4 g2 = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (n2hi) g2 = reinterpret_cast<const float4*>(ffn_norm_w)[c4];
     __syncthreads();
     // phase 2: the tile's output frames
     const int nout = nfr - H;
-    const int nround = (nout + fpp - 1) / fpp;   // (all lanes of a frame group walk the same number of rounds: the shuffles below)
-    for (int rd = 0, t = tid / C4; rd < nround; ++rd, t += fpp) {
-        if (n2hi == nullptr && t >= nout) break;
-        const bool live = t < nout;
-        if (!live) t = nout - 1;
+    for (int t = tid / C4; t < nout; t += fpp) {
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
         for (int k = 0; k < 7; ++k) {
@@ -1020,18 +1009,7 @@ __global__ __launch_bounds__(256) void mixer_fused_kernel(const float* __restric
         float4 xv = reinterpret_cast<const float4*>(xs + (size_t)(t + H) * C)[c4];
         xv.x += gm.x * (g.x * acc.x + bb.x); xv.y += gm.y * (g.y * acc.y + bb.y);
         xv.z += gm.z * (g.z * acc.z + bb.z); xv.w += gm.w * (g.w * acc.w + bb.w);
-        if (n2hi) {
-            float ss = xv.x * xv.x + xv.y * xv.y + xv.z * xv.z + xv.w * xv.w;
-            for (int o = lpr >> 1; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
-            const float r2 = 1.0f / sqrtf(ss / (float)C + eps);
-            if (live) {
-                reinterpret_cast<float4*>(xout + img0 + (long)(t + H) * C)[c4] = xv;
-                store_split4(n2hi, n2lo, ((long)b * T + t0 + t) * C + c4 * 4,
-                             make_float4(xv.x * r2 * g2.x, xv.y * r2 * g2.y, xv.z * r2 * g2.z, xv.w * r2 * g2.w));
-            }
-        } else {
-            reinterpret_cast<float4*>(xout + img0 + (long)(t + H) * C)[c4] = xv;
-        }
+        reinterpret_cast<float4*>(xout + img0 + (long)(t + H) * C)[c4] = xv;
     }
 }
 // The same mixer for the WIDE stages (C = 512 / 1024 / 2048), plus the FFN's RMSNorm of the updated rows: one pass over the image
@@ -1194,8 +1172,7 @@ hipError_t launch_mixer_wide(const float* xin, float* xout, const float* norm_w,
 }
 
 hipError_t launch_mixer_fused(const float* xin, float* xout, const float* norm_w, const float* w, const float* bias,
-                              const float* gamma, int B, int T, int C, int K, int pad, float eps, hipStream_t st,
-                              const float* ffn_norm_w, bf16_t* n2hi, bf16_t* n2lo) {
+                              const float* gamma, int B, int T, int C, int K, int pad, float eps, hipStream_t st) {
     if (C % 4 || C > 256 || (256 % (C / 4)) || pad < K - 1 || xin == xout || K > 7) return hipErrorInvalidValue;
     int TT = 8192 / C;
     if (TT < 8) TT = 8;
@@ -1203,10 +1180,9 @@ hipError_t launch_mixer_fused(const float* xin, float* xout, const float* norm_w
     const int tiles = (T + TT - 1) / TT;
     const size_t lds = ((size_t)(TT + K - 1) * C + (TT + K - 1)) * sizeof(float);
     if ((long)B * tiles == 0) return hipSuccess;
-    if (n2hi && (!ffn_norm_w || sm_is_split(n2lo))) return hipErrorInvalidValue;   // (n2 here: one 16-bit array)
-    ProfScope ps(st, n2hi ? "mixer_fused_n2" : "mixer_fused", 2.0 * B * T * C * (K + 4), (n2hi ? 10.0 : 8.0) * B * T * C);
+    ProfScope ps(st, "mixer_fused", 2.0 * B * T * C * (K + 4), 8.0 * B * T * C);
     hipLaunchKernelGGL(mixer_fused_kernel, dim3((unsigned)(B * tiles)), dim3(256), lds, st, xin, xout, norm_w, w, bias, gamma,
-                       T, C, K, pad, eps, TT, tiles, ffn_norm_w, n2hi, n2lo);
+                       T, C, K, pad, eps, TT, tiles);
     LAUNCH_CHECK();
 }
 

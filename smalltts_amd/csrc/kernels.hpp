@@ -173,8 +173,7 @@ hipError_t launch_codec_block_wave(const float* xin, float* xout, RowMap img, co
 // C in {128, 256}: weights streamed through an LDS ring (codec_ffn_stream.hip); w1 [F][C], w2t = launch_w2_tile_pack(W2 [C][F])
 hipError_t launch_codec_ffn_stream(float* x, RowMap img, const float* norm_w, const bf16_t* w1hi, const bf16_t* w1lo,
                                    const float* b1, const bf16_t* w2thi, const bf16_t* w2tlo, const float* b2, const float* gamma,
-                                   int M, int C, int F, float eps, int split, hipStream_t st, const bf16_t* n2 = nullptr);
-bool codec_ffn_stream_takes_n2(int C, int split);   // the mixer in front should write the fp16 operand rows (launch_mixer_fused n2hi)
+                                   int M, int C, int F, float eps, int split, hipStream_t st);
 hipError_t launch_w2_tile_pack(const bf16_t* in, bf16_t* out, int C, int F, hipStream_t st);
 
 
@@ -200,8 +199,7 @@ hipError_t launch_splitk_resid(const float* part, int S, float* x, const float* 
 // n = RMSNorm(xin; g, eps) recomputed in LDS for the tile + halo (x read once, written once).  Both images must have
 // zero pad frames.
 hipError_t launch_mixer_fused(const float* xin, float* xout, const float* norm_w, const float* w, const float* bias,
-                              const float* gamma, int B, int T, int C, int K, int pad, float eps, hipStream_t st,
-                              const float* ffn_norm_w = nullptr, bf16_t* n2hi = nullptr, bf16_t* n2lo = nullptr);
+                              const float* gamma, int B, int T, int C, int K, int pad, float eps, hipStream_t st);
 
 // device-side audio helpers (kernels.hip): polyphase resampler with a caller-built bank [up][klen], float -> PCM16
 hipError_t launch_resample_poly(const float* x, long n_in, const float* bank, int up, int down, int klen, int width, float* y,

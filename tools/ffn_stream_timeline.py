@@ -45,7 +45,7 @@ for Cw, spec in ((128, CodecSpec(n_filters=128, ratios=(8, 5, 5, 4), dec_depths=
     nstep = NT1 + 2
     M = 8 * 75 * spec.hop
     nw = 8 if Cw == 128 else 4
-    print(f"\n== [{os.environ.get('SMTTS_STREAM_N2', '1') != '0' and 'operand tile from the mixer by LDS-DMA' or 'fp32 tile loaded + normalised in the kernel'}]")
+    print()
     print(f"== codec_ffn_stream<{Cw}>  M = {M} rows ({M // (nw * 32)} passes of {nw * 32} frames over 256 workgroups), {us:.1f} us per launch by events")
     for p in range(PASSES):
         tp = t[:, p]
