@@ -264,7 +264,7 @@ __global__ __launch_bounds__(NW * 64) void codec_ffn_stream_kernel(FfnStreamArgs
                 unsigned nhp[4], nlp[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    if (SPLIT == PREC_F16) { nhp[e] = cvt_pk_f16_sat(v[2 * e], v[2 * e + 1]); nlp[e] = 0; }
+                    if (SPLIT == PREC_F16) { nhp[e] = cvt_pk_f16_raw(v[2 * e], v[2 * e + 1]); nlp[e] = 0; }   // |n| <= sqrt(C) max |g|: certified at finalize
                     else split_pair(v[2 * e], v[2 * e + 1], nhp[e], nlp[e]);
                 }
                 nh[kk] = __builtin_bit_cast(bf16x8, *reinterpret_cast<uint4*>(nhp));
@@ -438,7 +438,7 @@ __global__ __launch_bounds__(NW * 64) void codec_ffn_stream_kernel(FfnStreamArgs
                         q = __builtin_elementwise_fma(q, ax, h2_splat(GeluQ5::Q0));
                         qP[j] = __builtin_bit_cast(unsigned, q);
                     } else if (ph == 2) {
-                        qP[j] = __builtin_bit_cast(unsigned, __builtin_elementwise_exp2(__builtin_bit_cast(half2_t, qP[j])));
+                        qP[j] = exp2_pk_f16(qP[j]);
                     } else {
                         hiP[j] = gelu_q5_pk_back(hpP[j], axP[j], qP[j]);
                     }

@@ -138,6 +138,23 @@ __device__ __forceinline__ float gelu_q5_f(float x) {
 // is certified from the weights (Engine::certify_codec_ffn) — |h| < 65504 by construction.
 //   front: h -> (hp = fp16 pair, ax = |hp|, e = 2^q(ax));   back: max(hp, 0) - ax * e, already the packed operand pair
 __device__ __forceinline__ half2_t h2_splat(float c) { half2_t r = {(half_t)c, (half_t)c}; return r; }
+// 2^q of both halves of a packed pair.  hipcc's lowering of exp2 on a half2 is v_exp_f16 + v_exp_f16_sdwa (high half, zero-padded) +
+// v_pack_b32_f16; writing the high half in place (dst_unused:UNUSED_PRESERVE) needs no pack.  The s_nop is the wait state a
+// transcendental's result needs before a VALU instruction reads it (the SDWA write preserves, i.e. reads, the low half) — the
+// compiler's hazard recogniser does not look inside inline asm.  Consumers of the result must not be the very next instruction
+// either (SDWA dst_sel forwarding): every caller has other work in between.
+__device__ __forceinline__ unsigned exp2_pk_f16(unsigned q) {
+    unsigned e;
+    asm("v_exp_f16_e32 %0, %1\n\ts_nop 0\n\tv_exp_f16_sdwa %0, %1 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1\n\ts_nop 0"
+        : "=&v"(e) : "v"(q));
+    return e;
+}
+// (a, b) -> packed fp16 pair, round to nearest even, NO clamp: for values whose range is certified (Engine::certify_codec_ffn)
+__device__ __forceinline__ unsigned cvt_pk_f16_raw(float a, float b) {
+    f32x2_t v;
+    v.x = a; v.y = b;
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, half2_t));
+}
 __device__ __forceinline__ void gelu_q5_pk_front(float a, float b, unsigned& hp, unsigned& axp, unsigned& ep) {
     f32x2_t v;
     v.x = a; v.y = b;
@@ -150,7 +167,7 @@ __device__ __forceinline__ void gelu_q5_pk_front(float a, float b, unsigned& hp,
     q = __builtin_elementwise_fma(q, ax, h2_splat(GeluQ5::Q2));
     q = __builtin_elementwise_fma(q, ax, h2_splat(GeluQ5::Q1));
     q = __builtin_elementwise_fma(q, ax, h2_splat(GeluQ5::Q0));
-    ep = __builtin_bit_cast(unsigned, __builtin_elementwise_exp2(q));
+    ep = exp2_pk_f16(__builtin_bit_cast(unsigned, q));
 }
 __device__ __forceinline__ unsigned gelu_q5_pk_back(unsigned hp, unsigned axp, unsigned ep) {
     const half2_t z = {(half_t)0.f, (half_t)0.f};

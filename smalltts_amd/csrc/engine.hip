@@ -662,8 +662,9 @@ int Engine::finalize_codec(bool decoder) {
 // an event the weights can RULE OUT.  The input is RMS-normalised, so both are bounded by the weights alone
 // (ffn_range_bound_kernel); a block whose bound stays inside the fp16 range needs no run-time check, one whose bound does not
 // is reported through get_saturations (static part of SITE_CODEC_FFN), which makes the host side demote the site.
-int Engine::certify_codec_ffn(const std::string& name, const CodecBlockW& b, int C, int F) {
-    if (!(C == 32 || C == 64 || C == 128 || C == 256) || F != 4 * C || !cert_scratch_) return 0;   // the wider stages' hiddens are counted at run time
+int Engine::certify_codec_ffn(const std::string& name, CodecBlockW& b, int C, int F) {
+    if (!(C == 32 || C == 64 || C == 128 || C == 256) || F != 4 * C) return 0;   // the wider stages' hiddens are counted at run time
+    if (!cert_scratch_) { b.f16_ok = false; return 0; }   // (no scratch: nothing certified, the block stays at split-bf16)
     const float* w1 = rawp(name + ".ffn.w1.weight");
     if (!w1) return 0;
     HIPC(hipMemsetAsync(cert_scratch_, 0, 2 * sizeof(float), 0));
@@ -673,6 +674,7 @@ int Engine::certify_codec_ffn(const std::string& name, const CodecBlockW& b, int
     const float worst = bound[0] > bound[1] ? bound[0] : bound[1];
     if (worst > range_worst_) range_worst_ = worst;
     if (!(worst <= 65504.f)) {
+        b.f16_ok = false;
         ++sat_static_[SITE_CODEC_FFN];
         char buf[256];
         snprintf(buf, sizeof buf, "%s: fused FFN hidden bound %.4g, input bound %.4g exceed the fp16 range; ", name.c_str(), bound[0], bound[1]);
@@ -1452,7 +1454,8 @@ int Engine::codec_block(hipStream_t st, const CodecBlockW& w, float** xp, float*
     const RowMap img = rowmap_batched(C, T, (long)(pad + T) * C, (long)pad * C);
     const int F = cspec_.ffn_mult * C;
     const RowMap rc = rowmap_plain(C), rf = rowmap_plain(F);
-    const int pf = prec_[SITE_CODEC_FFN];
+    // a block whose fused-kernel range could not be certified never runs those kernels at fp16 (they do not clamp), whoever drives the C ABI
+    const int pf = (prec_[SITE_CODEC_FFN] == PREC_F16 && !w.f16_ok) ? PREC_BF16X3 : prec_[SITE_CODEC_FFN];
     unsigned* const sf = satp(SITE_CODEC_FFN);
     bf16_t* const n2lo_f = sm_lo_for(pf, n2lo, sf);  // (hi, lo) pairs handed to producers: the format the FFN GEMMs read
     auto wsel = [pf](const PW& w) { return pf == PREC_F16 ? w.h16 : w.hi; };

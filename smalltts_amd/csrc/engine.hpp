@@ -54,6 +54,8 @@ struct CodecBlockW {
     float* dw_w;  // [K][C]
     PW w1, w2;
     PW w2t;       // C = 128 / 256: W2 repacked hidden-tile-major [F/32][C][32] for codec_ffn_stream.hip; N == 0 when unused
+    bool f16_ok = true;   // the fused FFN kernels' hidden / input range is certified inside fp16 (Engine::certify_codec_ffn); false:
+                          // this block's FFN runs split-bf16 whatever the site precision says (those kernels convert WITHOUT clamping)
 };
 struct CodecStageW {
     int C = 0, r = 0;  // r: resample ratio entering this stage (0 for stage 0)
@@ -226,7 +228,7 @@ class Engine {
 
     // the tag a producer of attention operand images is handed in place of the (unused) lo array when the images are fp16
     bf16_t* img_lo(int pa, bf16_t* lo) const { return pa == PREC_F16 ? sm_lo_for(PREC_F16, nullptr, satp(SITE_ATTN)) : lo; }
-    int certify_codec_ffn(const std::string& name, const CodecBlockW& b, int C, int F);
+    int certify_codec_ffn(const std::string& name, CodecBlockW& b, int C, int F);
     unsigned* sat_ = nullptr;                 // [SITE_COUNT] device counters (null if the allocation failed: nothing is counted)
     unsigned* satp(int site) const { return sat_ ? sat_ + site : nullptr; }
     unsigned sat_static_[SITE_COUNT] = {};    // uncertified fused-kernel blocks (set by finalize)
