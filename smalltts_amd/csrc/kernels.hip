@@ -981,8 +981,12 @@ __global__ __launch_bounds__(256) void mixer_fused_kernel(const float* __restric
         float ss = v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
         for (int o = lpr >> 1; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
         if (f < nfr) {
-            reinterpret_cast<float4*>(xs + (size_t)f * C)[c4] = v;
-            if (c4 == 0) rs[f] = 1.0f / sqrtf(ss / (float)C + eps);
+            // staged NORMALISED (u = x * rstd): the seven taps of every output then cost one fma per value instead of a
+            // multiply by the frame's rstd + an fma and an LDS read of that rstd (round 4); the raw value the residual needs is
+            // u * rms of the centre tap (rs holds the rms, not its reciprocal)
+            const float rms = sqrtf(ss / (float)C + eps), r = 1.0f / rms;
+            reinterpret_cast<float4*>(xs + (size_t)f * C)[c4] = make_float4(v.x * r, v.y * r, v.z * r, v.w * r);
+            if (c4 == 0) rs[f] = rms;
         }
     }
     // per-thread constants: 256 % C4 == 0, so a thread always works on the same 4 channels
@@ -998,17 +1002,20 @@ __global__ __launch_bounds__(256) void mixer_fused_kernel(const float* __restric
     const int nout = nfr - H;
     for (int t = tid / C4; t < nout; t += fpp) {
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        float4 uc = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
         for (int k = 0; k < 7; ++k) {
             if (k < K) {
-                const float r = rs[t + k];
-                const float4 xv = reinterpret_cast<const float4*>(xs + (size_t)(t + k) * C)[c4];
-                acc.x += wv[k].x * r * xv.x; acc.y += wv[k].y * r * xv.y; acc.z += wv[k].z * r * xv.z; acc.w += wv[k].w * r * xv.w;
+                const float4 u = reinterpret_cast<const float4*>(xs + (size_t)(t + k) * C)[c4];
+                acc.x = fmaf(wv[k].x, u.x, acc.x); acc.y = fmaf(wv[k].y, u.y, acc.y);
+                acc.z = fmaf(wv[k].z, u.z, acc.z); acc.w = fmaf(wv[k].w, u.w, acc.w);
+                if (k == H) uc = u;
             }
         }
-        float4 xv = reinterpret_cast<const float4*>(xs + (size_t)(t + H) * C)[c4];
-        xv.x += gm.x * (g.x * acc.x + bb.x); xv.y += gm.y * (g.y * acc.y + bb.y);
-        xv.z += gm.z * (g.z * acc.z + bb.z); xv.w += gm.w * (g.w * acc.w + bb.w);
+        const float rms = rs[t + H];
+        float4 xv;
+        xv.x = fmaf(uc.x, rms, gm.x * (g.x * acc.x + bb.x)); xv.y = fmaf(uc.y, rms, gm.y * (g.y * acc.y + bb.y));
+        xv.z = fmaf(uc.z, rms, gm.z * (g.z * acc.z + bb.z)); xv.w = fmaf(uc.w, rms, gm.w * (g.w * acc.w + bb.w));
         reinterpret_cast<float4*>(xout + img0 + (long)(t + H) * C)[c4] = xv;
     }
 }
