@@ -11,7 +11,7 @@ Two sources, both optional at run time because neither exists offline:
   int64_data = 7 / name = 8 / raw_data = 9).  Tensors are matched to this build's parameter names by name;
   exporters rename MatMul weights (``onnx::MatMul_123``, stored transposed), so everything that cannot be matched
   by name is listed in the report instead of being guessed — codec parity stays "unpinned" until a name map for
-  the exported codec graph has been checked against real files (DESIGN.md §7).
+  the exported codec graph has been checked against real files (DESIGN.md §9).
 
 CLI:  python -m smalltts_amd.convert --checkpoint ckpt.pt --out weights.smtts
       python -m smalltts_amd.convert --onnx condition_encoder.onnx denoiser.onnx --out weights.smtts [--allow-partial]

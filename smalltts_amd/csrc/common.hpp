@@ -219,7 +219,7 @@ static inline bf16_t* sm_lo_for(int prec, bf16_t* lo, unsigned* sat_counter = nu
 // fp16 range guard.  The conversions saturate instead of producing inf, which keeps a rare outlier from
 // poisoning a softmax / residual row but is SILENT; `diff` collects raw ^ clamped of every converted pair, and sat_note() adds the
 // number of lanes that clamped anything to the site's counter — one atomic per wave and call, on a path that is never taken with
-// in-range data.  Call sat_note only where no load is consumed afterwards (stores and loads share vmcnt: DESIGN 5a).
+// in-range data.  Call sat_note only where no load is consumed afterwards (stores and loads share vmcnt: NOTEBOOK §5a).
 __device__ __forceinline__ unsigned cvt_pk_f16_sat(float a, float b, unsigned& diff) {
     f32x2_t v;
     v.x = a; v.y = b;

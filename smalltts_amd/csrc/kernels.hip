@@ -1,6 +1,7 @@
 // Non-GEMM kernels: norms, element-wise sampler steps, RNG, weight synthesis/packing helpers.
 // HBM-bound streaming kernels: one wave (or sub-wave group) per row, float4 accesses where the
 // layout permits, grid sized to cover the chip (>= 256 CUs x several waves).
+#include <cstdlib>
 #include "kernels.hpp"
 #include "prof.hpp"
 
@@ -1019,6 +1020,77 @@ __global__ __launch_bounds__(256) void mixer_fused_kernel(const float* __restric
         reinterpret_cast<float4*>(xout + img0 + (long)(t + H) * C)[c4] = xv;
     }
 }
+// The same arithmetic, in the same order (bit-identical results), as a STREAM along time for C = 128 / 256 (round 4): a group of C / 4
+// lanes owns a segment of L consecutive frames of one utterance and walks it with the last six normalised frames in registers — the
+// conv needs no LDS and no workgroup barrier, every wave is independent, and a chunk of eight frames is requested before the first is
+// used.  The staged kernel above loads a tile, synchronises, computes, stores: its workgroups' phases overlap only through
+// occupancy (4.4 TB/s of algorithmic bytes at C = 128).
+template <int C, int U>
+__global__ __launch_bounds__(256) void mixer_stream_kernel(const float* __restrict__ xin, float* __restrict__ xout,
+                                                           const float* __restrict__ norm_w, const float* __restrict__ w,
+                                                           const float* __restrict__ bias, const float* __restrict__ gamma,
+                                                           int T, int pad, float eps, int L, int segs_per_b, int nseg) {
+    constexpr int C4 = C / 4, GPW = 64 / C4;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c4 = lane % C4;
+    const int seg = (blockIdx.x * 4 + wave) * GPW + lane / C4;
+    if (seg >= nseg) return;   // (a whole group: the shuffles below stay inside a group)
+    const int b = seg / segs_per_b, t0 = (seg % segs_per_b) * L;
+    const int nfr = T - t0 < L ? T - t0 : L;
+    const long base = ((long)b * (pad + T) + pad + t0 - 6) * C + c4 * 4;   // first halo frame (the zero pad for t0 = 0)
+    float4 wv[7];
+#pragma unroll
+    for (int k = 0; k < 7; ++k) wv[k] = reinterpret_cast<const float4*>(w)[(long)k * C4 + c4];
+    const float4 g = reinterpret_cast<const float4*>(norm_w)[c4];
+    const float4 bb = reinterpret_cast<const float4*>(bias)[c4];
+    const float4 gm = reinterpret_cast<const float4*>(gamma)[c4];
+    float4 win[6];   // u of frames f - 6 .. f - 1
+#pragma unroll
+    for (int k = 0; k < 6; ++k) win[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int total = nfr + 6;   // frames walked: six of halo, then the segment
+#pragma unroll 1
+    for (int f0 = 0; f0 < total; f0 += U) {
+        float4 st[U];
+#pragma unroll
+        for (int i = 0; i < U; ++i) {
+            const int f = f0 + i;
+            st[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (f < total) st[i] = *reinterpret_cast<const float4*>(xin + base + (long)f * C);
+        }
+        float rmsv[U];
+#pragma unroll
+        for (int i = 0; i < U; ++i) {   // the eight reductions are independent chains
+            float ss = st[i].x * st[i].x + st[i].y * st[i].y + st[i].z * st[i].z + st[i].w * st[i].w;
+#pragma unroll
+            for (int o = C4 >> 1; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
+            rmsv[i] = sqrtf(ss / (float)C + eps);
+        }
+#pragma unroll
+        for (int i = 0; i < U; ++i) {
+            const int f = f0 + i;
+            const float r = 1.0f / rmsv[i];
+            const float4 u = make_float4(st[i].x * r, st[i].y * r, st[i].z * r, st[i].w * r);
+            if (f >= 6 && f < total) {
+                float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int k = 0; k < 6; ++k) {
+                    acc.x = fmaf(wv[k].x, win[k].x, acc.x); acc.y = fmaf(wv[k].y, win[k].y, acc.y);
+                    acc.z = fmaf(wv[k].z, win[k].z, acc.z); acc.w = fmaf(wv[k].w, win[k].w, acc.w);
+                }
+                acc.x = fmaf(wv[6].x, u.x, acc.x); acc.y = fmaf(wv[6].y, u.y, acc.y);
+                acc.z = fmaf(wv[6].z, u.z, acc.z); acc.w = fmaf(wv[6].w, u.w, acc.w);
+                float4 xv;
+                xv.x = fmaf(u.x, rmsv[i], gm.x * (g.x * acc.x + bb.x)); xv.y = fmaf(u.y, rmsv[i], gm.y * (g.y * acc.y + bb.y));
+                xv.z = fmaf(u.z, rmsv[i], gm.z * (g.z * acc.z + bb.z)); xv.w = fmaf(u.w, rmsv[i], gm.w * (g.w * acc.w + bb.w));
+                *reinterpret_cast<float4*>(xout + base + (long)f * C) = xv;
+            }
+#pragma unroll
+            for (int k = 0; k < 5; ++k) win[k] = win[k + 1];
+            win[5] = u;
+        }
+    }
+}
+
 // The same mixer for the WIDE stages (C = 512 / 1024 / 2048), plus the FFN's RMSNorm of the updated rows: one pass over the image
 //     x_mid = x + gamma * (norm_w * conv7(x * rstd(x)) + dw_b)            -> xout (fp32 image, out of place)
 //     n2    = x_mid * rstd(x_mid) * ffn_norm_w                            -> 16-bit operand rows of the first FFN product
@@ -1026,7 +1098,7 @@ __global__ __launch_bounds__(256) void mixer_fused_kernel(const float* __restric
 // the stage's rows) and a launch per block go.  A workgroup stages TT + 6 raw frames of one utterance in LDS, computes their
 // rstd (one wave per frame), then every thread owns 4 * CPT channels: conv over the seven staged rows, residual, partial sums of
 // squares per output frame (reduced over the waves that share a frame through LDS), and the two stores.  All global loads of the
-// tile are issued before the first use; stores only after the last load (shared vmcnt).
+// tile are issued before the first use; stores only after the last load (shared vmcnt, NOTEBOOK §5a).
 template <int C, int TT>
 __global__ __launch_bounds__(256) void mixer_wide_kernel(const float* __restrict__ xin, float* __restrict__ xout,
                                                          const float* __restrict__ norm_w, const float* __restrict__ w,
@@ -1181,6 +1253,18 @@ hipError_t launch_mixer_wide(const float* xin, float* xout, const float* norm_w,
 hipError_t launch_mixer_fused(const float* xin, float* xout, const float* norm_w, const float* w, const float* bias,
                               const float* gamma, int B, int T, int C, int K, int pad, float eps, hipStream_t st) {
     if (C % 4 || C > 256 || (256 % (C / 4)) || pad < K - 1 || xin == xout || K > 7) return hipErrorInvalidValue;
+    static const int stream_on = getenv("SMTTS_MIXER_STREAM") ? atoi(getenv("SMTTS_MIXER_STREAM")) : 1;   // A/B: 0 = the staged kernel
+    if (stream_on && (C == 128 || C == 256) && K == 7 && pad >= 6 && (long)B * T > 0) {
+        const int L = stream_on > 1 ? stream_on : 58;   // frames per segment: 6 halo + 58 = eight chunks of eight
+        const int segs = (T + L - 1) / L, nseg = B * segs, gpw = 64 / (C / 4);
+        const unsigned grid = (unsigned)((nseg + 4 * gpw - 1) / (4 * gpw));
+        ProfScope ps(st, "mixer_fused", 2.0 * B * T * C * (K + 4), 8.0 * B * T * C);
+        if (C == 128)
+            hipLaunchKernelGGL((mixer_stream_kernel<128, 8>), dim3(grid), dim3(256), 0, st, xin, xout, norm_w, w, bias, gamma, T, pad, eps, L, segs, nseg);
+        else
+            hipLaunchKernelGGL((mixer_stream_kernel<256, 8>), dim3(grid), dim3(256), 0, st, xin, xout, norm_w, w, bias, gamma, T, pad, eps, L, segs, nseg);
+        LAUNCH_CHECK();
+    }
     int TT = 8192 / C;
     if (TT < 8) TT = 8;
     if ((long)(TT + K - 1) * (C / 4) > 2560) return hipErrorInvalidValue;  // staging registers of the kernel (NI = 10)

@@ -167,7 +167,7 @@ class Batcher:
         self.tts, self.enc, self.eng = tts, encoder, tts.engine
         self.max_batch, self.window, self.in_flight, self.steps = int(max_batch), window_ms * 1e-3, max(1, int(in_flight)), num_steps
         # When the queue is deep the dispatcher packs more than max_batch utterances into one padded batch (the DiT's GEMMs run
-        # ~2.8x more efficiently at 1800 rows than at 600); it never WAITS for more than max_batch.
+        # ~2.8x more efficiently at 1800 rows than at 600, NOTEBOOK §5); it never WAITS for more than max_batch.
         self.max_pack = max(int(max_pack), self.max_batch)
         self.q: "queue.Queue[Optional[Request]]" = queue.Queue()
         self.done_q: "queue.Queue" = queue.Queue()

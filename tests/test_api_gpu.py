@@ -371,7 +371,7 @@ def test_wrong_shaped_checkpoint_is_a_clean_error_naming_the_tensor(tmp_path):
 def test_results_repeat_bit_for_bit_next_to_other_streams():
     """Bitwise repeatability with other HIP streams active — the two situations the product creates itself: the condition
     encoders on two streams (latency tuning) and three batches in flight on three streams (throughput tuning, bench.py's
-    headline mode).  A fused q / k-prep attention kernel that was bit-exact alone failed exactly here, so this
+    headline mode).  A fused q / k-prep attention kernel that was bit-exact alone failed exactly here (NOTEBOOK §13), so this
     runs the full-size bench shapes: 20 repeats of cond_encode, 6 rounds of three batches against the batches run alone."""
     import bench
     from smalltts_amd.engine import HipEngine

@@ -108,10 +108,12 @@ def _decode_in_subprocess(tmp_path, tag, env_extra, tuning="latency"):
 
 
 def test_alternative_paths_agree_with_the_default(tmp_path):
-    """Full-size decode (2 x 75 frames) on the A/B alternatives of the round-3 changes: scheduling-only switches (tile orders, the
-    persistent kernels' grid, ring depth) must not change a bit; the two-kernel wide-stage mixer differs by fp32 summation order."""
+    """Full-size decode (2 x 75 frames) on the A/B alternatives of the round-3 / round-4 changes: scheduling-only switches (tile orders,
+    the persistent kernels' grid, ring depth, the streaming form of the C = 128 / 256 mixer and its segment length) must not change a bit;
+    the two-kernel wide-stage mixer differs by fp32 summation order."""
     base = _decode_in_subprocess(tmp_path, "base", {})
-    for tag, env in (("tile_orders", {"SMTTS_GEMM_XCD": "0", "SMTTS_GEMM_GROUP": "1"}), ("shallow", {"SMTTS_GEMM_DEEP": "0"})):
+    for tag, env in (("tile_orders", {"SMTTS_GEMM_XCD": "0", "SMTTS_GEMM_GROUP": "1"}), ("shallow", {"SMTTS_GEMM_DEEP": "0"}),
+                     ("staged_mixer", {"SMTTS_MIXER_STREAM": "0"}), ("mixer_segments_of_122", {"SMTTS_MIXER_STREAM": "122"})):
         alt = _decode_in_subprocess(tmp_path, tag, env)
         assert np.array_equal(alt, base), tag
     tp = _decode_in_subprocess(tmp_path, "tp", {}, "throughput")

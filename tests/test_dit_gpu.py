@@ -170,7 +170,7 @@ def test_on_device_noise_is_seeded_and_reproducible(eng):
 
 
 def test_teacher_128_steps_vs_oracle_every_step(eng, dit_weights):
-    """BASELINE config 5's sampler at its real length: 128 chained ODE + CFG steps (distill.py:60-134 ingredients, DESIGN §6)
+    """BASELINE config 5's sampler at its real length: 128 chained ODE + CFG steps (distill.py:60-134 ingredients, DESIGN §7)
     against O.sample_teacher_ode, asserting the x0-hat of EVERY step so error growth along the chain is visible, not just
     the end point.  Small rows (B = 2, N = 20: 6 x 20 CFG rows) keep the CPU side to seconds."""
     gen = torch.Generator().manual_seed(51)

