@@ -1255,7 +1255,7 @@ hipError_t launch_mixer_fused(const float* xin, float* xout, const float* norm_w
     if (C % 4 || C > 256 || (256 % (C / 4)) || pad < K - 1 || xin == xout || K > 7) return hipErrorInvalidValue;
     static const int stream_on = getenv("SMTTS_MIXER_STREAM") ? atoi(getenv("SMTTS_MIXER_STREAM")) : 1;   // A/B: 0 = the staged kernel
     if (stream_on && (C == 128 || C == 256) && K == 7 && pad >= 6 && (long)B * T > 0) {
-        const int L = stream_on > 1 ? stream_on : 58;   // frames per segment: 6 halo + 58 = eight chunks of eight
+        const int L = stream_on > 1 ? stream_on : 42;   // frames per segment: 6 halo + 42 = six chunks of eight (sweep: profiles/r04t_*)
         const int segs = (T + L - 1) / L, nseg = B * segs, gpw = 64 / (C / 4);
         const unsigned grid = (unsigned)((nseg + 4 * gpw - 1) / (4 * gpw));
         ProfScope ps(st, "mixer_fused", 2.0 * B * T * C * (K + 4), 8.0 * B * T * C);
