@@ -122,8 +122,9 @@ def cpu_probe(candidates, budget_s=20.0):
 
 
 def cpu_baseline(cores):
-    """Oracle on the host cores: DiT part on the full 8 x 10 s batch, codec on 1 of the 8 utterances
-    (x8), so the leg stays ~10-30 s. kind = "port": the reference's ORT path cannot run offline."""
+    """Oracle on the host cores over the WHOLE 8 x 10 s batch: cond-encode + 4 DMD steps + codec decode of all eight utterances
+    in one batched call (round 3 decoded one utterance and scaled by eight: VERDICT r3).  Best of two passes after one warm-up of
+    the DiT part, ~20-30 s of CPU work.  kind = "port": the reference's ORT path cannot run offline."""
     from oracle import codec_oracle as CO
     from oracle import dit_oracle as O
     from smalltts_amd.weights import DEFAULT_CODEC, codec_decoder_param_specs, dit_param_specs, synth_state_dict
@@ -136,23 +137,27 @@ def cpu_baseline(cores):
     pm = torch.ones(B, P_TOK, dtype=torch.bool)
     mask = torch.ones(B, N_FRAMES, dtype=torch.bool)
     noise = torch.randn(DMD_STEPS, B, N_FRAMES, 64, generator=g)
-    t_dit = t_dec1 = float("inf")
+    t_dit = t_dec = float("inf")
     with torch.no_grad():
-        for _ in range(3):   # best of 3: the first pass pays page faults / thread-pool start-up (~10 s of CPU work in all)
+        cache = O.encode_conditions(w, ref, torch.full((B,), R_FRAMES), ids, pm)   # warm-up: page faults, thread pool
+        x = O.sample_dmd(w, cache, pm, mask, noise, DMD_STEPS)
+        for _ in range(2):
             t0 = time.perf_counter()
             cache = O.encode_conditions(w, ref, torch.full((B,), R_FRAMES), ids, pm)
             x = O.sample_dmd(w, cache, pm, mask, noise, DMD_STEPS)
             t_dit = min(t_dit, time.perf_counter() - t0)
             t0 = time.perf_counter()
-            CO.decode(wd, x[:1], DEFAULT_CODEC)
-            t_dec1 = min(t_dec1, time.perf_counter() - t0)
-    total = t_dit + B * t_dec1
+            CO.decode(wd, x, DEFAULT_CODEC)
+            t_dec = min(t_dec, time.perf_counter() - t0)
+            if t_dec > 25.0:   # a slow host: one pass is the bounded sample
+                break
+    total = t_dit + t_dec
     return {"value": round(B * AUDIO_SEC_PER_UTT / total, 3), "unit": "audio-seconds/sec", "cores": cores,
             "kind": "port",
-            "sample": f"CPU oracle (torch fp32): cond-encode + 4 DMD steps on the full 8x10s batch ({t_dit:.2f} s) + "
-                      f"codec decode of 1 of 8 utterances ({t_dec1:.2f} s, scaled x8), best of 3 passes; stands in for the reference's "
-                      "ORT-CPU path, which cannot run offline",
-            "dit_seconds": round(t_dit, 3), "codec_decode_seconds_per_utt": round(t_dec1, 3)}
+            "sample": f"CPU oracle (torch fp32) on the whole 8x10s batch: cond-encode + 4 DMD steps ({t_dit:.2f} s) + codec decode of all "
+                      f"8 utterances in one call ({t_dec:.2f} s), best of 2 passes; stands in for the reference's ORT-CPU path, which "
+                      "cannot run offline",
+            "dit_seconds": round(t_dit, 3), "codec_decode_seconds": round(t_dec, 3)}
 
 
 # SURVEY 8(d) / BASELINE.md 4 algorithmic work per 8 x 10 s batch (R = 15, P = 30): flops counted once, bf16 weights read once
