@@ -89,3 +89,15 @@ def test_null_handle_is_an_error_not_a_crash():
             assert rc == 1, name
         assert name.encode() in lib.smtts_last_error(None), name
     assert lib.smtts_destroy(None) == 0   # like free(NULL)
+
+
+def test_abi_version_matches_the_header_and_the_host_side():
+    """SMTTS_ABI_VERSION of include/smalltts_hip.h == smtts_abi_version() of the built library == what smalltts_amd/_lib.py was
+    written for (a stale .so must fail at load, not at the first mismatching call)."""
+    import re
+    _need_lib()
+    lib = _lib.load()
+    with open(_lib.HEADER_PATH) as f:
+        m = re.search(r"#define\s+SMTTS_ABI_VERSION\s+(\d+)", f.read())
+    assert m and int(m.group(1)) == lib.smtts_abi_version() == _lib.ABI_VERSION
+    assert b"0.4" in lib.smtts_version()
