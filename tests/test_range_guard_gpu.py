@@ -199,3 +199,27 @@ def test_fused_codec_ffn_blocks_are_certified_from_the_weights_or_demoted_at_fin
             assert 0 < worst <= 65504
         assert s > 60.0, f"decode SNR {s:.1f} dB with outlier rows x{factor:g}"
         eng.close()
+
+
+def test_calibration_leaves_the_seeded_weights_at_the_shipped_preset(tmp_path):
+    """The weights every bench / parity number of this build is measured on: the calibration that SmallTTS runs on a real weight file
+    must find nothing to demote (latents of the preset within 4e-4 of split-bf16, decode above 62 dB) — otherwise loading a file would
+    silently run a slower configuration than the one the bench reports."""
+    from smalltts_amd import api
+    from smalltts_amd.api import SmallTTS
+    from smalltts_amd.weights import codec_encoder_param_specs, save_weight_file
+    sd = synth_state_dict(dit_param_specs(), SEED)
+    sd.update(synth_state_dict(codec_decoder_param_specs(DEFAULT_CODEC) + codec_encoder_param_specs(DEFAULT_CODEC), SEED))
+    path = str(tmp_path / "seeded.smtts")
+    save_weight_file(path, sd, DEFAULT_CODEC)
+    try:
+        with warnings.catch_warnings(record=True) as rec:
+            warnings.simplefilter("always")
+            tts = SmallTTS(weights=path)          # a file, not "synthetic:": _load_weights_into calibrates
+        eng = tts.engine
+        assert eng.precision == "f16" and not eng._demoted and not [r for r in rec if "calibration" in str(r.message)]
+        rep = eng.calibrate()
+        print(f"\n[range guard] seeded weights: calibration {rep['latent_rel_l2']}, {rep['codec_snr_db']}")
+        assert not rep["demoted"] and rep["latent_rel_l2"][0][1] < 4e-4 and rep["codec_snr_db"][0][1] > 62.0
+    finally:
+        api._ENGINES.clear()
