@@ -75,8 +75,14 @@ struct FfnWaveArgs {
 // halo frames in front of the tile, loaded and normalised by the first 6 C / 8 lanes), then accumulates its own channels over
 // the seven rows fr .. fr + 6.  Requires a tile to lie inside one batch item (T % 32 == 0) and K = 7; the engine falls back
 // to the two-kernel path otherwise.
+// C = 32 at the single-array formats: with the packed-fp16 GELU the kernel is no longer VALU-bound (SQ counters, profiles/r04x_*: VALU
+// instructions -20 %, waiting 27 -> 43 % of wave cycles) and its 132 registers are four short of letting a second 8-wave
+// workgroup share the CU (LDS has room for two): asking for four waves per SIMD makes hipcc fit it into 128 (FW_MINW32=1 restores).
+#ifndef FW_MINW32
+#define FW_MINW32 4
+#endif
 template <int C, int SPLIT, int NWV, bool MIX = false>
-__global__ __launch_bounds__(NWV * 64, (C == 64 && SPLIT != 3 && NWV == 4) ? FW_MINW64 : 1) void codec_ffn_wave_kernel(FfnWaveArgs a) {
+__global__ __launch_bounds__(NWV * 64, (C == 64 && SPLIT != 3 && NWV == 4) ? FW_MINW64 : (C == 32 && SPLIT != 3) ? FW_MINW32 : 1) void codec_ffn_wave_kernel(FfnWaveArgs a) {
     constexpr int NT = NWV * 64;
     constexpr int F = 4 * C;
     constexpr int KK1 = C / 16;            // k16 steps of the first product
