@@ -163,11 +163,220 @@ def cpu_baseline(cores):
 # SURVEY 8(d) / BASELINE.md 4 algorithmic work per 8 x 10 s batch (R = 15, P = 30): flops counted once, bf16 weights read once
 # per use, activations negligible.  Codec: this build's CodecSpec: 13.5 GMAC per audio-second; bytes = weights
 # once (2 B / parameter) + one read and one write of every stage-boundary image.
+def codec_decode_algo_bytes(spec=None, batch=B, frames=N_FRAMES):
+    """SURVEY 8(d) bytes of one codec decode: one write + one read of every stage-boundary tensor (the fp32 image a stage hands
+    to the next: stem output, each ConvTranspose output, the waveform) + every decoder weight once at 2 B / parameter.
+    Derived from the CodecSpec in code; DEFAULT_CODEC at 8 x 75 frames: 2 x 0.94 GB + 0.69 GB = 2.57 GB."""
+    from smalltts_amd.weights import DEFAULT_CODEC, codec_decoder_param_specs
+    spec = spec or DEFAULT_CODEC
+    n_stage = len(spec.dec_depths)
+    t, boundary = frames, 0
+    for i in range(n_stage):
+        if i > 0:
+            t *= spec.ratios[i - 1]
+        boundary += batch * t * (spec.n_filters << (n_stage - 1 - i)) * 4
+    boundary += batch * t * 4                                   # the waveform
+    weights = sum(int(np.prod(shape)) for _, shape, *_ in codec_decoder_param_specs(spec)) * 2
+    return 2 * boundary + weights
+
+
 ALGO = {
     "dit_sampler": {"flops": 695e9, "bytes": 1.722e9},
     "cond_encoders": {"flops": 38e9, "bytes": 0.225e9},
-    "codec_decode": {"flops": 2.16e12, "bytes": None},   # bytes: measured sum of the kernels' algorithmic bytes (profiler)
+    "codec_decode": {"flops": 2.16e12, "bytes": None},   # bytes: codec_decode_algo_bytes() (filled in main: needs the package)
 }
+
+
+def ensure_world(n_gpus, argv):
+    """`--gpus N` must describe the job that runs.  Under a launcher (RANK / WORLD_SIZE set) a mismatch is an error; without one,
+    N > 1 re-executes this script under the driver's own command line (python -m torch.distributed.run --nnodes=1
+    --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py ...) — it never prints a world-1 line for N > 1."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    launched = "RANK" in os.environ and "WORLD_SIZE" in os.environ
+    if n_gpus < 1:
+        sys.exit("bench.py: --gpus must be >= 1")
+    if launched:
+        if world != n_gpus:
+            sys.exit(f"bench.py: --gpus {n_gpus} but the launcher started WORLD_SIZE={world} ranks; run\n  python -m "
+                     f"torch.distributed.run --nnodes=1 --nproc-per-node {n_gpus} --master-addr 127.0.0.1 --master-port 29500 "
+                     f"bench.py --gpus {n_gpus} ...")
+        return
+    if n_gpus == 1:
+        return
+    shared = os.environ.get("SMTTS_DIST_BACKEND") == "gloo"     # tests: several gloo ranks may share one GPU
+    ndev = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if ndev < n_gpus and not (shared and ndev >= 1):
+        sys.exit(f"bench.py: --gpus {n_gpus} needs {n_gpus} visible GPUs, found {ndev} (one process per GPU over RCCL); "
+                 f"refusing to print a line for fewer GPUs than asked")
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_gpus), "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    sys.stderr.write("bench.py: --gpus %d without a launcher: re-executing as\n  %s\n" % (n_gpus, " ".join(cmd)))
+    sys.stderr.flush()
+    os.execvpe(cmd[0], cmd, env)
+
+
+def _stamped(path_json, ksha):
+    """Committed rocprofv3 summaries are quoted only when they were measured on THESE kernel sources (hash stamp)."""
+    if not os.path.exists(path_json):
+        return None
+    with open(path_json) as f:
+        j = json.load(f)
+    return j if j.get("kernel_src_sha") == ksha else {"stale": j.get("kernel_src_sha")}
+
+
+def profile_block(eng, inp, args, tuning, shapes=True):
+    """Per-kernel HIP-event timing (events on the launch stream) of `reps` untimed passes of the workload under `tuning`,
+    one batch at a time -> {"roofline", "phase_roofline", "kernel_breakdown"} for that tuning."""
+    prev = eng.set_tuning(tuning)
+    try:
+        return _profile_block(eng, inp, args, tuning, shapes)
+    finally:
+        eng.set_tuning(prev)
+
+
+def _profile_block(eng, inp, args, tuning, shapes):
+    reps = min(args.steps, 5)
+    eng.profile(True, tagged=True)   # names come back as "<phase>/<kernel>" (enc, mod, dit, dec.s<i>, cenc.s<i>)
+    for i in range(reps):
+        one_step(eng, inp, 900 + i, None, None, args.workload)
+    torch.cuda.synchronize()
+    tagged = eng.profile_report()
+    eng.profile(False)
+    merged, phases, dec_launches = {}, {}, {}
+    for r in tagged:
+        ph, _, kname = r["name"].partition("/") if "/" in r["name"] else ("-", "", r["name"])
+        k = merged.setdefault(kname, {"name": kname, "ms": 0.0, "launches": 0, "flops": 0.0, "bytes": 0.0, "bytes8d": 0.0})
+        group = "dit_sampler" if ph in ("dit", "mod") else "cond_encoders" if ph == "enc" else \
+                "codec_encode" if ph.startswith("cenc") else "codec_decode"   # untagged: head conv / stem of the decoder
+        g_ = phases.setdefault(group, {"ms": 0.0, "flops": 0.0, "bytes": 0.0, "bytes8d": 0.0})
+        for d_ in (k, g_):
+            d_["ms"] += r["ms"]; d_["flops"] += r["flops"]; d_["bytes"] += r["bytes"]; d_["bytes8d"] += r.get("bytes8d", r["bytes"])
+        k["launches"] += r["launches"]
+        if group == "codec_decode":
+            dec_launches[kname] = dec_launches.get(kname, 0) + r["launches"]
+    rows = list(merged.values())
+    ksha = kernel_source_hash()
+    suffix = "" if tuning == "throughput" else "_latency"     # profiles/kernel_stats_latest.csv = the timed (throughput) tuning
+    traffic = _stamped(os.path.join(ROOT, "profiles", f"traffic{suffix}_latest.json"), ksha)
+    by_traffic = traffic.get("by_prof_name", {}) if traffic and "stale" not in traffic else {}
+    # SURVEY 8(d): DiT and codec roofline fractions separately.  "8d" = the survey's own accounting (ALGO: flops once, bf16
+    # weights once; codec: stage-boundary images once each way + weights once) over the sum of the phase's kernel times;
+    # "as_run" = the operand bytes the kernels are given in this precision (fp16 = 2 B, split-bf16 = 4 B per element, split-K
+    # partials included).
+    pr = {}
+    for g, v in sorted(phases.items(), key=lambda kv: -kv[1]["ms"]):
+        ms = v["ms"] / reps
+        a = ALGO.get(g, {})
+        fl8 = a.get("flops") if args.workload == "dmd4" and a.get("flops") else v["flops"] / reps
+        by8 = a.get("bytes") if args.workload == "dmd4" and a.get("bytes") else v["bytes8d"] / reps
+        pr[g] = {"ms_per_step": round(ms, 3),
+                 "8d": {"TFLOPs": round(fl8 / ms / 1e9, 2), "GBs": round(by8 / ms / 1e6, 1), "bytes": round(by8),
+                        "mfma_frac": round(fl8 / ms / 1e9 / MFMA_BF16_PEAK_TF, 5), "hbm_frac": round(by8 / ms / 1e6 / HBM_PEAK_GBS, 5)},
+                 "as_run": {"TFLOPs": round(v["flops"] / reps / ms / 1e9, 2), "GBs": round(v["bytes"] / reps / ms / 1e6, 1),
+                            "hbm_frac": round(v["bytes"] / reps / ms / 1e6 / HBM_PEAK_GBS, 5)}}
+    if "codec_decode" in pr and by_traffic and args.workload == "dmd4":
+        # counter traffic of the decoder's kernels per batch (per-class average x this phase's launches) / the 8(d) bytes
+        seen = {k: n for k, n in dec_launches.items() if k in by_traffic}
+        tr = sum(by_traffic[k] * n for k, n in seen.items()) / reps
+        pr["codec_decode"]["counter_traffic_bytes"] = round(tr)
+        pr["codec_decode"]["wasted_traffic"] = round(tr / ALGO["codec_decode"]["bytes"], 3)
+        pr["codec_decode"]["traffic_kernels_covered"] = f"{len(seen)} of {len(dec_launches)}"
+    rows.sort(key=lambda r: -r["ms"])
+    tot = sum(r["ms"] for r in rows)
+    top = rows[0]
+    per_ev = top["ms"] / top["launches"] * 1e-3
+    # rocprofv3 average of the same kernel class from the committed, hash-stamped summary measured under THIS tuning
+    # (tools/profile_round.sh); the HIP-event pair reads 1.5-3 us high on 10-20 us kernels
+    rocprof_us, rocprof_src = None, None
+    spath = os.path.join(ROOT, "profiles", f"kernel_stats{suffix}_latest.csv")
+    meta = _stamped(os.path.join(ROOT, "profiles", f"kernel_stats{suffix}_latest.meta.json"), ksha)
+    if meta and "stale" not in meta and os.path.exists(spath):
+        import csv
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        from prof_names import prof_name
+        us = calls = 0.0
+        with open(spath) as f:
+            for r in csv.DictReader(f):
+                if prof_name(r["kernel"]) == top["name"]:
+                    us += float(r["total_us"])
+                    calls += float(r["calls"])
+        if calls:
+            rocprof_us = us / calls
+            rocprof_src = f"profiles/kernel_stats{suffix}_latest.csv ({meta.get('tag', '')}: {meta.get('cmd', '')})"
+    elif meta and "stale" in meta:
+        rocprof_src = f"stale: profiles/kernel_stats{suffix}_latest.csv was measured on kernel sources {meta['stale']}, not quoted"
+
+    def fracs(per):
+        tf = top["flops"] / top["launches"] / per / 1e12
+        gbs8 = top["bytes8d"] / top["launches"] / per / 1e9
+        return tf, gbs8, tf / MFMA_BF16_PEAK_TF, gbs8 / HBM_PEAK_GBS
+    tf_e, gbs_e, mf_e, hf_e = fracs(per_ev)
+    per = rocprof_us * 1e-6 if rocprof_us else per_ev
+    tf, gbs8, mfma_frac, hbm_frac = fracs(per)
+    gbs_run = top["bytes"] / top["launches"] / per / 1e9
+    bound = "mfma" if mfma_frac >= hbm_frac else "hbm"
+    roof = {
+        "kernel": top["name"], "tuning": tuning, "bound": bound,
+        "achieved": round(tf if bound == "mfma" else gbs8, 3),
+        "peak": MFMA_BF16_PEAK_TF if bound == "mfma" else HBM_PEAK_GBS,
+        "unit": "TFLOP/s" if bound == "mfma" else "GB/s",
+        "frac": round(max(mfma_frac, hbm_frac), 5), "traffic": None,
+        "frac_source": "rocprofv3 average launch duration (" + rocprof_src + ")" if rocprof_us else
+                       "HIP events on the launch stream (no hash-matching rocprofv3 summary for this tuning under profiles/)",
+        "frac_events": round(max(mf_e, hf_e), 5), "avg_launch_us_events": round(per_ev * 1e6, 3),
+        "rocprof_avg_us": round(rocprof_us, 3) if rocprof_us else None,
+        "avg_launch_us": round(per * 1e6, 3), "launches_per_step": top["launches"] // reps,
+        "share_of_kernel_time": round(top["ms"] / tot, 4),
+        "flops_per_launch": round(top["flops"] / top["launches"]), "bytes8d_per_launch": round(top["bytes8d"] / top["launches"]),
+        "as_run_bytes_per_launch": round(top["bytes"] / top["launches"]), "as_run_GBs": round(gbs_run, 1),
+        "mfma_frac": round(mfma_frac, 5), "hbm_frac": round(hbm_frac, 5), "kernel_src_sha": ksha,
+        "note": "SURVEY 8(d) accounting: algorithmic flops (2MNK, counted once) and algorithmic bytes per launch / the kernel's "
+                "average launch duration; as_run_* = the operand + output bytes the launch is given",
+    }
+    if rocprof_src and not rocprof_us:
+        roof["rocprof_source"] = rocprof_src
+    # HBM bytes per launch of that kernel from the PMC passes of tools/profile_round.sh (committed under profiles/)
+    if traffic and "stale" not in traffic:
+        roof["traffic"] = by_traffic.get(top["name"])
+        roof["traffic_source"] = f"profiles/traffic{suffix}_latest.json (" + str(traffic.get("tag", "")) + ")"
+        if roof["traffic"] and top["bytes8d"]:
+            roof["traffic_over_algorithmic"] = round(roof["traffic"] / (top["bytes8d"] / top["launches"]), 3)
+    elif traffic:
+        roof["traffic_source"] = f"stale: profiles/traffic{suffix}_latest.json was measured on kernel sources {traffic['stale']}, not quoted"
+    if shapes:
+        # the dominant class broken down by product shape (profile mode 3: class names carry M x N x K): what its average hides
+        eng.profile(True, shapes=True)
+        for i in range(reps):
+            one_step(eng, inp, 950 + i, None, None, args.workload)
+        torch.cuda.synchronize()
+        shaped = eng.profile_report()
+        eng.profile(False)
+        by_shape = {}
+        for r in shaped:
+            kname = r["name"].partition("/")[2] if "/" in r["name"] else r["name"]
+            cls_, _, shp = kname.partition(" ")
+            if cls_ == top["name"] and shp:
+                a_ = by_shape.setdefault(shp, {"ms": 0.0, "launches": 0, "flops": 0.0})
+                a_["ms"] += r["ms"]; a_["launches"] += r["launches"]; a_["flops"] += r["flops"]
+        table = []
+        for shp, a_ in sorted(by_shape.items(), key=lambda kv: -kv[1]["ms"])[:3]:
+            us = a_["ms"] / a_["launches"] * 1e3
+            tfs = a_["flops"] / a_["launches"] / us / 1e6
+            table.append({"MxNxK": shp, "launches_per_step": a_["launches"] // reps, "avg_us_events": round(us, 2),
+                          "TFLOPs": round(tfs, 1), "mfma_frac": round(tfs / MFMA_BF16_PEAK_TF, 4)})
+        if table:
+            roof["by_shape"] = table
+    breakdown = [
+        {"name": r["name"], "launches_per_step": r["launches"] // reps, "ms_per_step": round(r["ms"] / reps, 4),
+         "TFLOPs": round(r["flops"] / max(r["ms"], 1e-9) / 1e9, 2), "GBs_8d": round(r["bytes8d"] / max(r["ms"], 1e-9) / 1e6, 1),
+         "GBs_as_run": round(r["bytes"] / max(r["ms"], 1e-9) / 1e6, 1)}
+        for r in rows[:16]]
+    return {"roofline": roof, "phase_roofline": pr, "kernel_breakdown": breakdown}
 
 
 def main():
@@ -189,12 +398,18 @@ def main():
     ap.add_argument("--max-repeats", type=int, default=50)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--tuning", default="auto", choices=["auto", "latency", "throughput"],
+                    help="engine tuning of the timed region: auto = throughput with batches in flight, latency with one at a time; "
+                         "forcing it lets tools/profile_round.sh trace the throughput-tuned kernels one batch at a time")
+    ap.add_argument("--no-sequential", action="store_true", help="skip the one-batch-at-a-time leg (value_sequential)")
     args = ap.parse_args()
+    ensure_world(args.gpus, sys.argv[1:])
 
     from smalltts_amd.parallel import ShardContext
     ctx = ShardContext.from_env()          # one process per GPU (torch.distributed.run); single process when WORLD_SIZE <= 1
     world, rank, device = ctx.world, ctx.rank, ctx.device
     n_gpus = world
+    assert n_gpus == args.gpus or os.environ.get("SMTTS_DIST_FORCE") == "1", (n_gpus, args.gpus)   # ensure_world() settled this
     torch.cuda.set_device(ctx.device_index)
 
     from smalltts_amd.engine import HipEngine
@@ -207,20 +422,25 @@ def main():
     samples = 3200 * N_FRAMES
     barrier = ctx.barrier
 
-    def run_steps(n, seed0, in_flight):
+    def run_steps(n, seed0, in_flight, tuning=None):
         """n full passes of the hot path, each over its own batch of 8.  With in_flight > 1 consecutive batches are issued
         round-robin to that many HIP streams (one workspace each): the latency-bound phases of one batch (condition
         encoders, DiT: grids of 30-190 workgroups on 256 CUs) fill the CUs another batch's kernels leave idle.  Every batch
         still goes through the whole path inside the timed region; nothing is shared between batches but the weights."""
         if in_flight <= 1:
             out = None
-            for i in range(n):
-                out = one_step(eng, inp, seed0 + i, ctx, gathers[0] if gathers else None, args.workload, pcm16)
+            prev = eng.set_tuning(tuning) if tuning else None
+            try:
+                for i in range(n):
+                    out = one_step(eng, inp, seed0 + i, ctx, gathers[0] if gathers else None, args.workload, pcm16)
+            finally:
+                if tuning:
+                    eng.set_tuning(prev)
             return out
         cur = torch.cuda.current_stream(device)
         for s_ in streams[:in_flight]:
             s_.wait_stream(cur)
-        prev = eng.set_tuning("throughput")   # unsplit GEMMs, shallow DMA rings, no engine side stream: fewest CU-us per kernel
+        prev = eng.set_tuning(tuning or "throughput")   # unsplit GEMMs, no engine side stream, capped persistent grids: fewest CU-us per kernel
         out = None
         try:
             for i in range(n):
@@ -235,9 +455,10 @@ def main():
         return out
 
     in_flight = max(1, args.in_flight)
+    timed_tuning = args.tuning if args.tuning != "auto" else ("throughput" if in_flight > 1 else "latency")
     streams = [torch.cuda.Stream(device) for _ in range(in_flight)] if in_flight > 1 else []
     gathers = [ctx.gather_buffer(world * B, samples, gdtype) for _ in range(in_flight)] if ctx.collective else []  # one per slot
-    run_steps(args.warmup, 0, in_flight)
+    run_steps(args.warmup, 0, in_flight, timed_tuning)
     # The timed region is EXACTLY K steps between barrier + device sync on both sides, MAX over ranks.  The driver fixes K (20
     # steps = 0.2 s here), so the region is REPEATED until >= --min-seconds have been timed in all (every rank takes the same
     # decision: the elapsed time it looks at is the max over ranks); the line reports the MEDIAN repeat, min / max beside it.
@@ -246,7 +467,7 @@ def main():
     while True:
         barrier()
         t0 = time.perf_counter()
-        out = run_steps(args.steps, 100 + 1000 * len(dts), in_flight)
+        out = run_steps(args.steps, 100 + 1000 * len(dts), in_flight, timed_tuning)
         barrier()
         dts.append(ctx.max_over_ranks(time.perf_counter() - t0))
         if sum(dts) >= args.min_seconds or len(dts) >= args.max_repeats:
@@ -254,12 +475,14 @@ def main():
     dt = sorted(dts)[len(dts) // 2]
     # the same K steps one batch at a time on one stream: the latency of a batch, and the strict reading of "at batch = 8"
     ns = max(3, min(args.steps, 100))
-    run_steps(2, 50, 1)
-    barrier()
-    t1 = time.perf_counter()
-    run_steps(ns, 60, 1)
-    barrier()
-    dt_seq = ctx.max_over_ranks(time.perf_counter() - t1)
+    dt_seq = None
+    if not args.no_sequential:
+        run_steps(2, 50, 1, "latency")
+        barrier()
+        t1 = time.perf_counter()
+        run_steps(ns, 60, 1, "latency")
+        barrier()
+        dt_seq = ctx.max_over_ranks(time.perf_counter() - t1)
     assert torch.isfinite(out.float()).all()
 
     audio_s = n_gpus * B * AUDIO_SEC_PER_UTT * args.steps
@@ -276,8 +499,9 @@ def main():
         "data": "synthetic (seeded inputs + seeded random weights; no released weights offline)",
         "rtf": round(dt / audio_s, 7),
         # one batch of 8 at a time on one stream (no batches in flight): the strict reading of the metric's "at batch = 8"
-        "value_sequential": round(audio_s_seq / dt_seq, 2), "sequential_ms_per_step": round(1e3 * dt_seq / ns, 3),
-        "rtf_sequential": round(dt_seq / audio_s_seq, 7),
+        "value_sequential": round(audio_s_seq / dt_seq, 2) if dt_seq else None,
+        "sequential_ms_per_step": round(1e3 * dt_seq / ns, 3) if dt_seq else None,
+        "rtf_sequential": round(dt_seq / audio_s_seq, 7) if dt_seq else None,
         # the K-step region repeated: value / ms_per_step are the median repeat
         "timed_seconds": round(sum(dts), 3), "repeats": len(dts), "ms_per_step_min": round(1e3 * min(dts) / args.steps, 3),
         "ms_per_step_max": round(1e3 * max(dts) / args.steps, 3), "spread": round((max(dts) - min(dts)) / dt, 4),
@@ -287,122 +511,25 @@ def main():
                    "global_batch": n_gpus * B, "utterance_seconds": AUDIO_SEC_PER_UTT, "sampler_steps": 128 if args.workload == "teacher128" else DMD_STEPS,
                    "parallelism": (f"dp{n_gpus}: one process per GPU, 8-utterance shard each, one {args.gather} waveform all-gather "
                                    f"({ctx.backend})") if n_gpus > 1 else "single GPU",
-                   "batches_in_flight": in_flight, "precision": args.precision},
+                   "batches_in_flight": in_flight, "tuning": timed_tuning, "precision": args.precision,
+                   # sites the fp16 range guard / calibration moved to split-bf16 on these weights (none on the seeded recipe):
+                   # a published number states the precision actually in force
+                   "precision_demoted_sites": eng.precision_in_force()["demoted"]},
     }
 
     if rank == 0 and not args.no_roofline:
-        # per-kernel HIP-event timing on the launch stream, separate (untimed) passes
-        eng.profile(True, tagged=True)   # names come back as "<phase>/<kernel>" (enc, mod, dit, dec.s<i>, cenc.s<i>)
-        reps = min(args.steps, 5)   # same workload as the timed region, events on the launch stream
-        for i in range(reps):
-            one_step(eng, inp, 900 + i, None, None, args.workload)
-        torch.cuda.synchronize()
-        tagged = eng.profile_report()
-        eng.profile(False)
-        merged, phases = {}, {}
-        for r in tagged:
-            ph, _, kname = r["name"].partition("/") if "/" in r["name"] else ("-", "", r["name"])
-            k = merged.setdefault(kname, {"name": kname, "ms": 0.0, "launches": 0, "flops": 0.0, "bytes": 0.0, "bytes8d": 0.0})
-            group = "dit_sampler" if ph in ("dit", "mod") else "cond_encoders" if ph == "enc" else \
-                    "codec_encode" if ph.startswith("cenc") else "codec_decode"   # untagged: head conv / stem of the decoder
-            g_ = phases.setdefault(group, {"ms": 0.0, "flops": 0.0, "bytes": 0.0, "bytes8d": 0.0})
-            for d_ in (k, g_):
-                d_["ms"] += r["ms"]; d_["flops"] += r["flops"]; d_["bytes"] += r["bytes"]; d_["bytes8d"] += r.get("bytes8d", r["bytes"])
-            k["launches"] += r["launches"]
-        rows = list(merged.values())
-        # DiT and codec roofline fractions separately.  "8d" = the survey's own accounting (ALGO above: flops once,
-        # bf16 weights once, activations negligible) over the sum of the phase's kernel times; "as_run" = the operand bytes the
-        # kernels are given in this precision (fp16 = 2 B, split-bf16 = 4 B per element, split-K partials included).
-        pr = {}
-        for g, v in sorted(phases.items(), key=lambda kv: -kv[1]["ms"]):
-            ms = v["ms"] / reps
-            a = ALGO.get(g, {})
-            fl8 = a.get("flops") if args.workload == "dmd4" and a.get("flops") else v["flops"] / reps
-            by8 = a.get("bytes") if args.workload == "dmd4" and a.get("bytes") else v["bytes8d"] / reps
-            pr[g] = {"ms_per_step": round(ms, 3),
-                     "8d": {"TFLOPs": round(fl8 / ms / 1e9, 2), "GBs": round(by8 / ms / 1e6, 1),
-                            "mfma_frac": round(fl8 / ms / 1e9 / MFMA_BF16_PEAK_TF, 5), "hbm_frac": round(by8 / ms / 1e6 / HBM_PEAK_GBS, 5)},
-                     "as_run": {"TFLOPs": round(v["flops"] / reps / ms / 1e9, 2), "GBs": round(v["bytes"] / reps / ms / 1e6, 1),
-                                "hbm_frac": round(v["bytes"] / reps / ms / 1e6 / HBM_PEAK_GBS, 5)}}
-        res["phase_roofline"] = pr
-        rows.sort(key=lambda r: -r["ms"])
-        tot = sum(r["ms"] for r in rows)
-        top = rows[0]
-        per = top["ms"] / top["launches"] * 1e-3
-        tf = top["flops"] / top["launches"] / per / 1e12
-        gbs8 = top["bytes8d"] / top["launches"] / per / 1e9
-        gbs_run = top["bytes"] / top["launches"] / per / 1e9
-        mfma_frac, hbm_frac = tf / MFMA_BF16_PEAK_TF, gbs8 / HBM_PEAK_GBS
-        bound = "mfma" if mfma_frac >= hbm_frac else "hbm"
-        res["roofline"] = {
-            "kernel": top["name"], "bound": bound,
-            "achieved": round(tf if bound == "mfma" else gbs8, 3),
-            "peak": MFMA_BF16_PEAK_TF if bound == "mfma" else HBM_PEAK_GBS,
-            "unit": "TFLOP/s" if bound == "mfma" else "GB/s",
-            "frac": round(max(mfma_frac, hbm_frac), 5), "traffic": None,
-            "avg_launch_us": round(per * 1e6, 3), "launches_per_step": top["launches"] // reps,
-            "share_of_kernel_time": round(top["ms"] / tot, 4),
-            "flops_per_launch": round(top["flops"] / top["launches"]), "bytes8d_per_launch": round(top["bytes8d"] / top["launches"]),
-            "as_run_bytes_per_launch": round(top["bytes"] / top["launches"]), "as_run_GBs": round(gbs_run, 1),
-            "mfma_frac": round(mfma_frac, 5), "hbm_frac": round(hbm_frac, 5),
-            "note": "SURVEY 8(d) accounting: algorithmic flops (2MNK, counted once) and weight bytes at 2 B / parameter read once, "
-                    "per launch / HIP-event time on the launch stream; as_run_* = the operand + output bytes the launch is given",
-        }
-        # HBM bytes per launch of that kernel from the PMC passes of tools/profile_round.sh (committed under profiles/); only
-        # quoted when the file was measured on THESE kernel sources (hash stamp), otherwise null + the reason
-        ksha = kernel_source_hash()
-        res["roofline"]["kernel_src_sha"] = ksha
-        tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
-        if os.path.exists(tpath):
-            with open(tpath) as f:
-                tj = json.load(f)
-            if tj.get("kernel_src_sha") == ksha:
-                res["roofline"]["traffic"] = tj.get("by_prof_name", {}).get(top["name"])
-                res["roofline"]["traffic_source"] = "profiles/traffic_latest.json (" + str(tj.get("tag", "")) + ")"
-            else:
-                res["roofline"]["traffic_source"] = ("stale: profiles/traffic_latest.json was measured on kernel sources "
-                                                     + str(tj.get("kernel_src_sha")) + ", not quoted")
-        # rocprofv3 average of the same kernel class from the committed summary (the HIP-event pair adds ~1.5-3 us per launch)
-        spath = os.path.join(ROOT, "profiles", "kernel_stats_latest.csv")
-        mpath = os.path.join(ROOT, "profiles", "kernel_stats_latest.meta.json")
-        if os.path.exists(spath) and os.path.exists(mpath) and json.load(open(mpath)).get("kernel_src_sha") == ksha:
-            import csv
-            sys.path.insert(0, os.path.join(ROOT, "tools"))
-            from prof_names import prof_name
-            us = calls = 0.0
-            with open(spath) as f:
-                for r in csv.DictReader(f):
-                    if prof_name(r["kernel"]) == top["name"]:
-                        us += float(r["total_us"])
-                        calls += float(r["calls"])
-            if calls:
-                res["roofline"]["rocprof_avg_us"] = round(us / calls, 3)
-        # the dominant class broken down by product shape (profile mode 3: class names carry M x N x K): what its average hides
-        eng.profile(True, shapes=True)
-        for i in range(reps):
-            one_step(eng, inp, 950 + i, None, None, args.workload)
-        torch.cuda.synchronize()
-        shaped = eng.profile_report()
-        eng.profile(False)
-        by_shape = {}
-        for r in shaped:
-            kname = r["name"].partition("/")[2] if "/" in r["name"] else r["name"]
-            cls_, _, shp = kname.partition(" ")
-            if cls_ == top["name"] and shp:
-                a_ = by_shape.setdefault(shp, {"ms": 0.0, "launches": 0, "flops": 0.0})
-                a_["ms"] += r["ms"]; a_["launches"] += r["launches"]; a_["flops"] += r["flops"]
-        table = []
-        for shp, a_ in sorted(by_shape.items(), key=lambda kv: -kv[1]["ms"])[:3]:
-            us = a_["ms"] / a_["launches"] * 1e3
-            tfs = a_["flops"] / a_["launches"] / us / 1e6
-            table.append({"MxNxK": shp, "launches_per_step": a_["launches"] // reps, "avg_us": round(us, 2), "TFLOPs": round(tfs, 1),
-                          "mfma_frac": round(tfs / MFMA_BF16_PEAK_TF, 4)})
-        res["roofline"]["by_shape"] = table
-        res["kernel_breakdown"] = [
-            {"name": r["name"], "launches_per_step": r["launches"] // reps, "ms_per_step": round(r["ms"] / reps, 4),
-             "TFLOPs": round(r["flops"] / max(r["ms"], 1e-9) / 1e9, 2), "GBs_8d": round(r["bytes8d"] / max(r["ms"], 1e-9) / 1e6, 1),
-             "GBs_as_run": round(r["bytes"] / max(r["ms"], 1e-9) / 1e6, 1)}
-            for r in rows[:16]]
+        ALGO["codec_decode"]["bytes"] = float(codec_decode_algo_bytes())
+        # The roofline block describes the configuration that was TIMED: its per-kernel passes run under the timed region's
+        # tuning (throughput when batches are in flight), one batch at a time on one stream (include/smalltts_hip.h: the
+        # profiler covers one call at a time).  A second block under latency tuning sits next to value_sequential.
+        res["roofline_tuning"] = timed_tuning
+        blk = profile_block(eng, inp, args, timed_tuning)
+        res["phase_roofline"], res["roofline"], res["kernel_breakdown"] = blk["phase_roofline"], blk["roofline"], blk["kernel_breakdown"]
+        if timed_tuning != "latency" and not args.no_sequential:
+            blk2 = profile_block(eng, inp, args, "latency", shapes=False)
+            res["roofline_sequential"] = blk2["roofline"]
+            res["phase_roofline_sequential"] = {k: {"ms_per_step": v["ms_per_step"], "mfma_frac_8d": v["8d"]["mfma_frac"],
+                                                    "hbm_frac_8d": v["8d"]["hbm_frac"]} for k, v in blk2["phase_roofline"].items()}
     if rank == 0 and n_gpus == 1 and not args.no_cpu_baseline and args.workload == "dmd4":
         try:
             avail = len(os.sched_getaffinity(0))

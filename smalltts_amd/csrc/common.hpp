@@ -2,6 +2,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
 #include <atomic>
 
 typedef __bf16 bf16_t;
@@ -211,6 +213,17 @@ __host__ __device__ __forceinline__ unsigned* sm_sat_counter(const bf16_t* lo) {
 }
 // lo pointer that tells a producer which format to write for a consumer of precision `prec` (fp16: + where to count clamps)
 static inline bf16_t* sm_lo_for(int prec, bf16_t* lo, unsigned* sat_counter = nullptr) {
+    // the tag lives in the low two address bits: a real lo array at an odd bf16 element offset (address = 2 mod 4) would be read as
+    // "fp16, count clamps into the word next to it" by every producer.  All callers pass 256-byte aligned carve-outs; this makes
+    // the invariant a check instead of a comment.
+    if (prec == PREC_BF16X3 && ((uintptr_t)lo & 3u) != 0) {
+        fprintf(stderr, "smalltts_hip: split-bf16 lo array %p is not 4-byte aligned (would alias the fp16 format tag)\n", (void*)lo);
+        abort();
+    }
+    if (((uintptr_t)sat_counter & 3u) != 0) {
+        fprintf(stderr, "smalltts_hip: saturation counter %p is not 4-byte aligned\n", (void*)sat_counter);
+        abort();
+    }
     return prec == PREC_BF16X3 ? lo
            : (prec == PREC_F16 || prec == PREC_F16X2) ? reinterpret_cast<bf16_t*>((uintptr_t)sat_counter | 2u)
                                                       : nullptr;

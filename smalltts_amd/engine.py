@@ -45,6 +45,7 @@ class HipEngine:
         self.codec_spec: CodecSpec = DEFAULT_CODEC
         self._banks: Dict[tuple, tuple] = {}   # (down, up) -> (polyphase bank on the device, width)
         self._demoted: Dict[str, str] = {}     # site -> why: sites the fp16 range guard moved to split-bf16 (sticky across set_precision)
+        self.calibration: Optional[Dict[str, object]] = None   # last calibrate() report on the loaded weights
         self.set_precision(precision)
 
     # ---- plumbing ------------------------------------------------------------------------------
@@ -69,6 +70,9 @@ class HipEngine:
     def use_workspace(self, slot: Optional[str]):
         """Select a named scratch buffer for subsequent calls (ops running concurrently on different streams must
         not share scratch). None = the default buffer."""
+        if slot is not None and getattr(self, "_profiling", False):
+            raise RuntimeError("per-kernel profiling is on: it pairs HIP events around every launch and assumes ONE call at a "
+                               "time — no batches in flight (include/smalltts_hip.h, threading rule 3)")
         self._ws_slot = slot
 
     def _workspace(self, nbytes: int) -> torch.Tensor:
@@ -101,8 +105,6 @@ class HipEngine:
     def set_tuning(self, mode: str) -> str:
         """"latency" (default) or "throughput" (several batches in flight on the caller's streams); returns the previous mode."""
         prev = getattr(self, "tuning", "latency")
-        if mode == "throughput" and getattr(self, "_profiling", False):
-            raise RuntimeError("per-kernel profiling is on: it assumes one call at a time (see HipEngine.profile)")
         self._ck(self.lib.smtts_set_tuning(self.h, {"latency": 0, "throughput": 1}[mode]), "set_tuning")
         self.tuning = mode
         return prev
@@ -186,8 +188,12 @@ class HipEngine:
                 self._demoted = saved
                 self.set_precision(keep)
             err = rel(latents(), want)
-            self.check_fp16_range("calibrate")
             rep["latent_rel_l2"] = [("as configured", err)]
+            hit = self.check_fp16_range("calibrate")
+            if hit:   # a site clamped and now runs split-bf16: the ladder below must start from what THAT configuration measures
+                err = rel(latents(), want)
+                rep["latent_rel_l2"].append((f"after the range guard moved {'+'.join(hit)}", err))
+                rep["demoted"] += hit
             for site in ("dit_block", "attn", "encoder", "cross_kv", "cond", "convpos"):
                 if err <= tol:
                     break
@@ -214,8 +220,12 @@ class HipEngine:
                 self._demoted = saved
                 self.set_precision(keep)
             s = snr()
-            self.check_fp16_range("calibrate")
             rep["codec_snr_db"] = [("as configured", s)]
+            hit = self.check_fp16_range("calibrate")
+            if hit:
+                s = snr()
+                rep["codec_snr_db"].append((f"after the range guard moved {'+'.join(hit)}", s))
+                rep["demoted"] += hit
             for site in ("codec_ffn", "codec_conv"):
                 if s >= codec_snr_db:
                     break
@@ -229,7 +239,13 @@ class HipEngine:
         if rep["demoted"]:
             warnings.warn(f"precision calibration: {', '.join(rep['demoted'])} moved to split-bf16 on these weights "
                           f"({rep.get('latent_rel_l2')}, {rep.get('codec_snr_db')})", RuntimeWarning, stacklevel=2)
+        rep["precision_in_force"] = self.precision_in_force()
+        self.calibration = rep          # kept for /stats and bench.py: published numbers state the precision actually in force
         return rep
+
+    def precision_in_force(self) -> Dict[str, object]:
+        """The preset plus every site the range guard / calibration moved to split-bf16 on the loaded weights (and why)."""
+        return {"preset": self.precision, "demoted": dict(self._demoted)}
 
     # ---- weights -------------------------------------------------------------------------------
     def set_codec_spec(self, spec: CodecSpec):
@@ -280,6 +296,12 @@ class HipEngine:
         return out
 
     def finalize(self):
+        # demotions were measured on the PREVIOUS weights (C++ resets its static counters and range report in smtts_finalize too):
+        # one bad checkpoint must not pin the engine at split-bf16 for its lifetime
+        if self._demoted:
+            self._demoted = {}
+            self.set_precision(self.precision)
+        self.calibration = None
         self._ck(self.lib.smtts_finalize(self.h), "finalize")
         self.check_fp16_range("finalize")   # static part: fused codec FFN blocks whose range the weights do not certify
 
@@ -431,10 +453,12 @@ class HipEngine:
 
     def profile(self, on, tagged: bool = False, shapes: bool = False):
         """on: False/True; tagged=True prefixes kernel names with the pipeline phase (enc, mod, dit, dec.s<i> ...); shapes=True
-        (implies tagged) also appends each GEMM product's shape to its class name ("gemm3<...> 600x3840x960")."""
-        if on and getattr(self, "tuning", "latency") == "throughput":
+        (implies tagged) also appends each GEMM product's shape to its class name ("gemm3<...> 600x3840x960").
+        Works under either tuning (bench.py profiles the throughput-tuned kernels it times) but only ONE call at a time: the
+        named per-batch workspaces of batches in flight are refused while it is on."""
+        if on and self._ws_slot is not None:
             raise RuntimeError("per-kernel profiling pairs HIP events around every launch and assumes ONE call at a time: "
-                               "leave throughput tuning / batches in flight first")
+                               "finish the batches in flight (use_workspace(None)) first")
         self._profiling = bool(on)
         self._ck(self.lib.smtts_profile_enable(self.h, (3 if shapes else 2 if tagged else 1) if on else 0), "profile_enable")
 

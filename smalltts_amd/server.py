@@ -36,6 +36,9 @@ from typing import List, Optional, Tuple
 
 import numpy as np
 
+RANGE_CHECK_BATCHES = 16      # the fp16 saturation counters are read at least this often (batches) ...
+RANGE_CHECK_SECONDS = 5.0     # ... and at least this often (seconds), also when the queue never runs dry
+
 BODY_LIMIT = 2 * 1024 * 1024     # main.rs:87 RequestBodyLimitLayer
 SAMPLE_RATE, HOP, LATENT = 24_000, 3_200, 64
 
@@ -235,6 +238,7 @@ class Batcher:
         streams = [torch.cuda.Stream(dev) for _ in range(self.in_flight)]
         prev = self.eng.set_tuning("throughput")
         i = 0
+        last_check_i, last_check_t = 0, time.monotonic()
         try:
             while True:
                 reqs = self._gather()
@@ -287,10 +291,16 @@ class Batcher:
                 # fp16 range guard (engine.check_fp16_range): the counters are read when the queue has run dry — a device
                 # synchronisation the busy path should not pay per batch.  A site that clamped runs split-bf16 from then on; the
                 # requests that hit it were answered with saturated (finite) operands, which is what the warning is for.
-                if self.q.empty():
+                # Under sustained load the queue is rarely empty — the regime where the guard matters most — so the counters are
+                # also read every RANGE_CHECK_BATCHES batches / RANGE_CHECK_SECONDS seconds whatever the queue holds.
+                now = time.monotonic()
+                if self.q.empty() or i - last_check_i >= RANGE_CHECK_BATCHES or now - last_check_t >= RANGE_CHECK_SECONDS:
+                    last_check_i, last_check_t = i, now
                     try:
+                        self.stats["range_checks"] = self.stats.get("range_checks", 0) + 1
                         if self.eng.check_fp16_range("server"):
                             self.stats["range_demotions"] = sorted(self.eng._demoted)
+                        self.stats["precision"] = self.eng.precision_in_force()
                     except Exception:
                         pass
         finally:

@@ -36,12 +36,28 @@ def test_bench_single_gpu_line_has_the_contract_fields_and_rooflines():
     # the K-step region is repeated until >= 2 s have been timed; value / ms_per_step are the median repeat
     assert r["timed_seconds"] >= 2.0 and r["repeats"] >= 2 and r["ms_per_step_min"] <= r["ms_per_step"] <= r["ms_per_step_max"]
     assert r["dist"] == {"backend": None, "collective": False, "world": 1}
-    rf = r["roofline"]
-    assert 1 <= len(rf["by_shape"]) <= 3 and all(t["avg_us"] > 0 and 0 < t["mfma_frac"] < 1 and "x" in t["MxNxK"] for t in rf["by_shape"])
-    assert rf["bound"] in ("hbm", "mfma") and 0 < rf["frac"] < 1 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-4
-    assert rf["unit"] in ("GB/s", "TFLOP/s") and "traffic" in rf and len(rf["kernel_src_sha"]) == 16
+    # the roofline block describes the TIMED configuration: three batches in flight = throughput tuning; the latency-tuned twin
+    # sits next to value_sequential
+    assert r["config"]["tuning"] == r["roofline_tuning"] == "throughput"
+    for rf, tuning in ((r["roofline"], "throughput"), (r["roofline_sequential"], "latency")):
+        assert rf["tuning"] == tuning
+        assert rf["bound"] in ("hbm", "mfma") and 0 < rf["frac"] < 1 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-4
+        assert 0 < rf["frac_events"] < 1 and rf["avg_launch_us_events"] > 0 and rf["frac_source"]
+        if rf["rocprof_avg_us"]:      # a hash-matching rocprofv3 summary is committed: frac follows from it
+            assert abs(rf["avg_launch_us"] - rf["rocprof_avg_us"]) < 1e-3 and "rocprofv3" in rf["frac_source"]
+        else:
+            assert rf["frac"] == rf["frac_events"]
+        assert rf["unit"] in ("GB/s", "TFLOP/s") and "traffic" in rf and len(rf["kernel_src_sha"]) == 16
+    by_shape = r["roofline"].get("by_shape", [])
+    assert all(t["avg_us_events"] > 0 and 0 < t["mfma_frac"] < 1 and "x" in t["MxNxK"] for t in by_shape) and len(by_shape) <= 3
+    # the headline never launches the split-K partial-product class for the N = 960 projections (throughput tuning runs them unsplit)
+    names = {k["name"] for k in r["kernel_breakdown"]}
+    assert "splitk_resid_ln" not in names
     for ph in ("dit_sampler", "cond_encoders", "codec_decode"):
         assert r["phase_roofline"][ph]["ms_per_step"] > 0 and 0 < r["phase_roofline"][ph]["8d"]["mfma_frac"] < 1
+        assert r["phase_roofline_sequential"][ph]["ms_per_step"] > 0
+    # SURVEY 8(d) bytes of the codec: stage-boundary images once each way + weights once, derived from the spec
+    assert abs(r["phase_roofline"]["codec_decode"]["8d"]["bytes"] - 2.57e9) < 0.02e9
     cb = r["cpu_baseline"]
     assert cb["kind"] == "port" and cb["value"] > 0 and cb["cores"] >= 1 and cb["cores_available"] >= cb["cores"] and cb["sample"]
     assert str(cb["cores"]) in cb["thread_probe_ms"]          # the thread count was chosen by the bounded probe
@@ -59,3 +75,17 @@ def test_bench_two_ranks_over_gloo_on_one_gpu(gather):
     assert abs(r["value"] - 160.0 / (r["ms_per_step"] * 1e-3)) / r["value"] < 1e-3       # both ranks' 8 x 10 s count
     assert "gloo" in r["config"]["parallelism"] and gather in r["config"]["parallelism"]
     assert "cpu_baseline" not in r                                                       # rank 0 at N = 1 only
+
+
+def test_bench_gpus_2_without_a_launcher_relaunches_itself_as_two_ranks():
+    """`python bench.py --gpus 2` with no torch.distributed.run around it must not print a world-1 line: it re-executes under the
+    driver's launcher command (here two gloo ranks sharing the box's GPU)."""
+    env = dict(os.environ, SMTTS_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--steps", "3", "--warmup", "1", "--no-roofline",
+                        "--no-cpu-baseline", "--min-seconds", "0"], capture_output=True, text=True, timeout=1200, cwd=ROOT, env=env)
+    assert p.returncode == 0, p.stderr[-3000:]
+    assert "re-executing" in p.stderr
+    r = _last_json(p.stdout)
+    assert r["n_gpus"] == 2 and r["dist"]["world"] == 2 and r["config"]["global_batch"] == 16

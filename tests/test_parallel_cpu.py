@@ -105,3 +105,69 @@ def test_forced_world_one_group_runs_every_collective_over_gloo():
     assert p.returncode == 0, p.stderr[-2000:]
     r = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
     assert r["backend"] == "gloo" and r["f32"] and r["pcm16"] and r["ragged"] and r["max"] == 1.25 and r["destroyed"]
+
+
+def _bench(args, env_extra=None, drop=("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")):
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    for k in drop:
+        env.pop(k, None)
+    env.update(env_extra or {})
+    return subprocess.run([sys.executable, os.path.join(root, "bench.py")] + args, capture_output=True, text=True, timeout=300,
+                          cwd=root, env=env)
+
+
+def test_bench_gpus_n_without_enough_gpus_is_a_hard_error_not_a_world_1_line():
+    """`python bench.py --gpus 8` outside a launcher used to benchmark ONE GPU and print n_gpus: 1.  Without N visible
+    GPUs (this container has none) it must exit non-zero and print no JSON line at all."""
+    p = _bench(["--gpus", "8", "--steps", "2", "--warmup", "1"])
+    assert p.returncode != 0
+    assert not [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert "--gpus 8" in p.stderr and "GPUs" in p.stderr
+
+
+def test_bench_gpus_n_disagreeing_with_the_launchers_world_is_a_hard_error():
+    p = _bench(["--gpus", "4", "--steps", "2", "--warmup", "1"], {"RANK": "0", "WORLD_SIZE": "2", "LOCAL_RANK": "0",
+                                                                  "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(_free_port())}, drop=())
+    assert p.returncode != 0
+    assert not [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert "WORLD_SIZE=2" in p.stderr and "--nproc-per-node 4" in p.stderr
+
+
+def test_bench_relaunch_command_is_the_drivers_launcher_line(monkeypatch):
+    """ensure_world() with enough devices execs `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr
+    127.0.0.1 --master-port P bench.py <same argv>` (the exec itself is stubbed out)."""
+    import bench
+    seen = {}
+    monkeypatch.setattr(bench.torch.cuda, "is_available", lambda: True)
+    monkeypatch.setattr(bench.torch.cuda, "device_count", lambda: 8)
+    monkeypatch.setattr(bench.os, "execvpe", lambda f, a, e: seen.update(file=f, argv=a, env=e))
+    for k in ("RANK", "WORLD_SIZE"):
+        monkeypatch.delenv(k, raising=False)
+    bench.ensure_world(8, ["--gpus", "8", "--steps", "20", "--warmup", "3"])
+    a = seen["argv"]
+    assert a[1:6] == ["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8"] and "--master-addr" in a
+    assert a[a.index("--master-addr") + 1] == "127.0.0.1" and a[-6:] == ["--gpus", "8", "--steps", "20", "--warmup", "3"]
+    assert a[-7].endswith("bench.py") and seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    seen.clear()
+    bench.ensure_world(1, ["--gpus", "1"])          # N = 1 outside a launcher: nothing to do
+    assert not seen
+
+
+def test_world_8_ranks_walk_the_bench_protocol_at_the_64_utterance_size():
+    """BASELINE.json configs[3] (64 x 10 s over 8 GPUs) without 8 GPUs: the driver's launcher line at --nproc-per-node 8 over
+    gloo, bench.py's ShardContext calls at the real sizes (8-utterance contiguous shards, 3 gather slots of 64 x 240000 fp32 =
+    184 MB per rank allocated once and reused, rows in global utterance order, MAX-over-ranks timing)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(root, "tests", "helpers", "shard_worker8.py")]
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert p.returncode == 0, p.stderr[-2000:]
+    res = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    assert res["ok"] and res["world"] == 8 and res["backend"] == "gloo"
+    assert res["gather_bytes_per_rank"] == 3 * 64 * 240000 * 4

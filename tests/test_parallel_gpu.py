@@ -53,3 +53,18 @@ def test_bench_under_the_drivers_launcher_with_the_rccl_gather_in_the_timed_regi
     r = _last_json(p.stdout)
     assert r["n_gpus"] == 1 and r["dist"] == {"backend": "nccl", "collective": True, "world": 1}
     assert r["value"] > 100 and abs(r["value"] - 80.0 / (r["ms_per_step"] * 1e-3)) / r["value"] < 1e-3
+
+
+def test_three_all_gathers_in_flight_on_three_streams_through_one_rccl_communicator():
+    """batches in flight x collective.  200 rounds of kernel -> all_gather_into_tensor on three streams sharing
+    the process group's single RCCL communicator; every slot's buffer is bit-checked before it is reused."""
+    env = dict(os.environ, SMTTS_DIST_BACKEND="nccl", SMTTS_DIST_FORCE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR"):
+        env.pop(k, None)
+    env["MASTER_PORT"] = str(_free_port())
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "helpers", "rccl_inflight.py")], capture_output=True, text=True,
+                       timeout=600, cwd=ROOT, env=env)
+    assert p.returncode == 0, p.stderr[-3000:]
+    r = _last_json(p.stdout)
+    assert r["backend"] == "nccl" and r["rounds"] == 200 and r["slots"] == 3
+    assert r["mismatches"] == 0 and r["buffers_reused"]

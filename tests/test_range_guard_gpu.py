@@ -201,6 +201,41 @@ def test_fused_codec_ffn_blocks_are_certified_from_the_weights_or_demoted_at_fin
         eng.close()
 
 
+def test_certificate_keeps_a_margin_below_the_fp16_maximum():
+    """the bound is evaluated on fp32 weights while the kernels multiply fp16-rounded operands, so the real hidden can
+    exceed it by ~1e-3 — and certified blocks convert WITHOUT a clamp.  A block whose bound lands just under 65504 (inside the
+    margin) must therefore be demoted; one safely below (65504 / 1.01) stays certified."""
+    from smalltts_amd.engine import HipEngine
+    spec = DEFAULT_CODEC
+    name = [k for k, *_ in codec_decoder_param_specs(spec) if k.endswith("ffn.w1.weight")][-1]   # a C = 32 block (one-pass kernel)
+    bname = name.replace("ffn.w1.weight", "ffn.w1.bias")
+
+    def build(factor):
+        sd = synth_state_dict(codec_decoder_param_specs(spec), SEED)
+        sd[name] = sd[name].copy()
+        sd[name][3] *= np.float32(factor)
+        if bname in sd:
+            sd[bname] = sd[bname].copy()
+            sd[bname][3] *= np.float32(factor)          # bias scaled with the row: the bound is exactly linear in `factor`
+        eng = HipEngine(0)
+        eng.set_codec_spec(spec)
+        eng.load_state_dict(sd)
+        with warnings.catch_warnings(record=True):
+            warnings.simplefilter("always")
+            eng.finalize()
+        return eng, float(eng.lib.smtts_range_worst_bound(eng.h))
+
+    eng, w0 = build(1000.0)
+    eng.close()
+    for target, expect_demotion in ((65480.0, True), (65504.0 / 1.01, False)):
+        eng, worst = build(1000.0 * target / w0)
+        print(f"\n[range guard] bound steered to {target:.1f}: worst {worst:.1f}, demoted {sorted(eng._demoted)}")
+        assert abs(worst - target) / target < 1e-4
+        assert ("codec_ffn" in eng._demoted) == expect_demotion, (worst, eng._demoted)
+        assert ("fused FFN hidden bound" in eng.lib.smtts_range_report(eng.h).decode()) == expect_demotion
+        eng.close()
+
+
 def test_calibration_leaves_the_seeded_weights_at_the_shipped_preset(tmp_path):
     """The weights every bench / parity number of this build is measured on: the calibration that SmallTTS runs on a real weight file
     must find nothing to demote (latents of the preset within 4e-4 of split-bf16, decode above 62 dB) — otherwise loading a file would

@@ -77,6 +77,8 @@ def test_concurrent_requests_get_their_own_audio(n_req, max_pack):
           f"largest {st['max_batch_seen']}")
     assert st["requests"] == n_req and st["batches"] < n_req and st["max_batch_seen"] > 1, st      # requests really shared batches
     assert st["max_batch_seen"] <= max_pack and (max_pack == 8 or st["max_batch_seen"] > 8), st   # a deep queue is packed beyond 8
+    # the fp16 range counters were read (whatever the queue held) and /stats states the precision actually in force
+    assert st["range_checks"] >= 1 and st["precision"]["preset"] and st["precision"]["demoted"] == {}, st
     for (wav, toks, dur, seed), (code, data) in zip(reqs, outs):
         assert code == 200, data[:200]
         n = S.frames_for(dur)
