@@ -357,7 +357,13 @@ enum Gemm3Cfg {
     G3_160x128 = 5,  // 10 waves 5x2, wave 32x64, 2 stages (146 KiB): M = 600 (4 row tiles, 6 % padding) x wide N in ONE round
     G3_128x128_W4 = 6,  // 4 waves 2x2, wave 64x64: 4 fragment reads per 4 MFMAs instead of 3 per 2 — for the single-array formats,
                         // where one MFMA per fragment pair leaves the k-loop bound by ds_read_b128 traffic; 2 workgroups per CU
+    G4_256x256 = 7,     // gemm4.hpp: 8 waves 2x4, wave 128x64, two 64-KiB k-tile buffers on the phase-split schedule (single-array formats)
 };
+static inline bool gemm3_ok(const Gemm3Operands& g) {
+    return g.K % 64 == 0 && g.K >= 64 && (g.amap.ld % 8) == 0 && (g.amap.off % 8) == 0 && (g.ldw % 8) == 0 &&
+           (g.amap.bstride % 8) == 0;
+}
+#include "gemm4.hpp"
 
 static inline int gemm3_pick_cfg(int M, int N, bool paired, bool single = false /* one array per operand (fp16 / bf16) */) {
     extern int g_gemm3_w4_minm;   // single-array formats: 128x128 with four 64x64 waves from this M up (0 = never); split-bf16 falls back
@@ -406,10 +412,6 @@ static inline int gemm3_pick_cfg(int M, int N, bool paired, bool single = false 
     return G3_64x64;
 }
 
-static inline bool gemm3_ok(const Gemm3Operands& g) {
-    return g.K % 64 == 0 && g.K >= 64 && (g.amap.ld % 8) == 0 && (g.amap.off % 8) == 0 && (g.ldw % 8) == 0 &&
-           (g.amap.bstride % 8) == 0;
-}
 
 // Ring depth per tile shape.  A single-array operand format (PREC_F16 / PREC_BF16) halves the bytes per stage, so the same LDS
 // budget can hold twice the k-tiles in flight.  Measured (profiles/r02b_ab_ring_depth.txt, f16, M = 600): deep rings cut one
@@ -423,7 +425,7 @@ static inline hipError_t gemm3_launch_split(const Gemm3Operands& g, const Epi& e
         // deep rings pay when the whole grid is resident at once (one latency-bound round); a grid of several rounds at the deep
         // ring's occupancy runs faster shallow with more workgroups per CU (teacher QKVG, 450 tiles of 128x128: 35.1 us deep — two
         // rounds at one workgroup per CU — against 27.5 shallow; B = 8 QKVG as 600 tiles of 64x64: 20.4 against 15.3)
-        const long bm = cfg == G3_64x128 || cfg == G3_64x64 ? 64 : cfg == G3_160x128 ? 160 : 128, bn = cfg == G3_64x64 ? 64 : 128;
+        const long bm = cfg == G4_256x256 ? 256 : cfg == G3_64x128 || cfg == G3_64x64 ? 64 : cfg == G3_160x128 ? 160 : 128, bn = cfg == G4_256x256 ? 256 : cfg == G3_64x64 ? 64 : 128;
         const long tiles = ((g.M + bm - 1) / bm) * ((g.N + bn - 1) / bn) * (Z > 0 ? Z : 1);
         const long deep_slots = cfg == G3_64x64 ? 512 : 256;
         if (g_gemm3_deep && tiles <= deep_slots) {
@@ -444,6 +446,9 @@ static inline hipError_t gemm3_launch_split(const Gemm3Operands& g, const Epi& e
         }
     }
     switch (cfg) {
+        case G4_256x256:
+            if constexpr (SPLIT == PREC_BF16 || SPLIT == PREC_F16) return gemm4_launch_cfg<SPLIT, Epi>(g, epi, Z, st);
+            break;
         case G3_128x128:
             return gemm3_launch_cfg<128, 128, 4, 2, SPLIT, 2, Epi>(g, epi, Z, st);
         case G3_64x128:
@@ -482,6 +487,7 @@ static inline hipError_t gemm3_launch(const Gemm3Operands& g_in, const Epi& epi,
     extern int g_gemm3_group;
     const double wbytes = (double)g.N * g.K * (split == PREC_BF16X3 ? 4.0 : 2.0);
     g.nfast = g_gemm3_nfast && (long)g.M > (long)g.N ? (g_gemm3_group > 1 && wbytes > 3e6 && g.M >= 1024 ? g_gemm3_group : 1) : 0;
+    if (cfg == G4_256x256 && (split == PREC_BF16X3 || !gemm4_ok(g) || !gemm4_enabled<Epi>::value)) cfg = G3_128x128;   // (no such instantiation)
     if (split == PREC_BF16X3) return gemm3_launch_split<3, Epi>(g, epi, Z, cfg == G3_128x128_W4 ? G3_128x128 : cfg, st);
     if (split == PREC_F16) return gemm3_launch_split<2, Epi>(g, epi, Z, cfg, st);
     return gemm3_launch_split<1, Epi>(g, epi, Z, cfg, st);

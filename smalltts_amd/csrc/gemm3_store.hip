@@ -32,3 +32,14 @@ extern "C" int smtts_debug_clear_timeline(void) {
     return (int)hipMemset(p, 0, sizeof(unsigned long long) * 1024 * 160);
 }
 #endif
+
+#ifdef G4_TIMELINE   // debug build only (tools/gemm4_timeline.py): the phase stamps of this translation unit's gemm4 instantiations
+extern "C" int smtts_debug_read_timeline4(unsigned long long* host, int n) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g4_tl_buf), (size_t)n * 8);
+}
+extern "C" int smtts_debug_clear_timeline4(void) {
+    void* p = nullptr;
+    if (hipGetSymbolAddress(&p, HIP_SYMBOL(g4_tl_buf)) != hipSuccess) return 1;
+    return (int)hipMemset(p, 0, sizeof(unsigned long long) * (256 * 2 * 2 * 16 + 8));
+}
+#endif

@@ -33,8 +33,9 @@ hipError_t gemm_convpos(const GemmOperands& g, bool final, const EpiConvPos<0>& 
 // ---- v3 (split-A, DMA ring, 8 waves) entry points: definitions in gemm3_ops.hip --------------------------
 static inline std::string gemm3_prof_name(const Gemm3Operands& g, bool paired, int cfg, int split, const char* epi) {
     if (cfg < 0) cfg = gemm3_pick_cfg(g.M, g.N, paired, split != PREC_BF16X3);
-    static const char* tiles[] = {"64x128", "128x128", "64x64", "128x64", "128x32", "160x128", "128x128w4"};
-    std::string n = std::string("gemm3<") + tiles[cfg] + ",s" + std::to_string(split) + "," + epi + ">";
+    static const char* tiles[] = {"64x128", "128x128", "64x64", "128x64", "128x32", "160x128", "128x128w4", "256x256"};
+    if (cfg == G4_256x256 && (split == PREC_BF16X3 || !gemm4_ok(g))) cfg = G3_128x128;   // (gemm3_launch's fallback)
+    std::string n = std::string(cfg == G4_256x256 ? "gemm4<" : "gemm3<") + tiles[cfg] + ",s" + std::to_string(split) + "," + epi + ">";
     extern thread_local int g_prof_shapes;   // profile mode 3: the product's shape behind the class name ("... 600x3840x960[/k3]")
     if (g_prof_shapes) {
         n += " " + std::to_string(g.M) + "x" + std::to_string(g.N) + "x" + std::to_string(g.K);

@@ -13,6 +13,9 @@ def prof_name(kernel: str):
     m = re.match(r"gemm3_kernel<(\d+), (\d+), \d+, \d+, (\d), \d+, (Epi\w+(?:<\d>)?) ?>", k)
     if m:
         return f"gemm3<{m.group(1)}x{m.group(2)},s{m.group(3)},{_EPI3.get(m.group(4), m.group(4))}>"
+    m = re.match(r"gemm4_kernel<(\d), (Epi\w+(?:<\d>)?) ?>", k)
+    if m:
+        return f"gemm4<256x256,s{m.group(1)},{_EPI3.get(m.group(2), m.group(2))}>"
     m = re.match(r"gemm_kernel<(\d+), (\d+), (\d+), \d+, \d+, (\d), (Epi\w+(?:<\d>)?) ?>", k)
     if m:
         return f"gemm<{m.group(1)}x{m.group(2)}x{m.group(3)},s{m.group(4)},{_EPI3.get(m.group(5), m.group(5))}>"
