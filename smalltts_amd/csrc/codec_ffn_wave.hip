@@ -34,6 +34,15 @@ __device__ __forceinline__ void split_pair(float a, float b, unsigned& hi, unsig
     lo = cvt_pk_bf16(a - __uint_as_float(hi << 16), b - __uint_as_float(hi & 0xffff0000u));
 }
 
+// Sum of squares of four values on top of `acc`, spelled out (one multiply, three FMAs, one add; nothing left for the compiler to
+// contract): every instantiation of the kernel body (strided one-pass block, stage chain of 1 / 2 / 3 blocks) must perform the SAME
+// fp32 operations.  With `a * a + b * b + ...`, `sum / C + eps` and `x += g * (acc + b)` left to -ffp-contract=fast the chain's
+// blocks differed from the one-pass block by an ulp here and there (which the fp16 operand roundings then amplify to 1e-4), and
+// "one launch per stage" must not change a bit — those three places are written with fmaf now.
+__device__ __forceinline__ float ssq4(const float4& v, float acc) {
+    return acc + fmaf(v.w, v.w, fmaf(v.z, v.z, fmaf(v.y, v.y, v.x * v.x)));
+}
+
 struct FfnWaveArgs {
     float* x;
     RowMap img;            // row m of x
@@ -55,6 +64,13 @@ struct FfnWaveArgs {
     const float* dw_w;     // [7][C]
     const float* dw_b;     // [C]
     const float* mgamma;   // [C]
+};
+
+// Stage chain (round 5): the NB blocks of one codec stage back to back on every 32-frame tile, the image read once and written once
+// per STAGE instead of once per block.  b[i] = block i's weights / vectors; b[0].xin / b[0].x = the stage's input / output image.
+struct FfnChainArgs {
+    FfnWaveArgs b[3];
+    int tpu;               // 32-frame tiles per utterance (img.rpb / 32): the blocks' causal halos restart there
 };
 
 // NWV = waves per workgroup.  The waves never synchronise after the weights are in LDS, so the workgroup size only sets how many
@@ -81,8 +97,16 @@ struct FfnWaveArgs {
 #ifndef FW_MINW32
 #define FW_MINW32 4
 #endif
-template <int C, int SPLIT, int NWV, bool MIX = false>
-__global__ __launch_bounds__(NWV * 64, (C == 64 && SPLIT != 3 && NWV == 4) ? FW_MINW64 : (C == 32 && SPLIT != 3) ? FW_MINW32 : 1) void codec_ffn_wave_kernel(FfnWaveArgs a) {
+// NB > 1 (MIX only) = the stage chain.  A wave then walks a CONTIGUOUS run of tiles of one utterance in time order and runs block
+// 0 .. NB - 1 on each tile before the next: block i + 1's input tile is block i's output, still in registers (accumulator layout ->
+// B-fragment layout by v_permlane32_swap, the inverse of KEEPX's rearrangement), and the six causal halo frames block i + 1's mixer
+// needs in front of the tile are the last six frames of block i's output on the PREVIOUS tile, which the same wave parked in LDS
+// (raw: they are normalised where they are used, by the code that normalises block 0's halo from the image — bit-identical
+// arithmetic to one launch per block).  A run that does not start at an utterance start first runs the tile in front of it without
+// storing: block i's output there is right from frame 6 i on, in particular on the last six frames (the next tile's halos).
+template <int C, int SPLIT, int NWV, bool MIX, int NB, bool CHAIN = (NB > 1)>
+__device__ __forceinline__ void codec_ffn_wave_body(const FfnWaveArgs& a, const FfnWaveArgs* blks, int tpu) {
+    static_assert(NB == 1 || MIX, "the stage chain is built on the one-pass block");
     constexpr int NT = NWV * 64;
     constexpr int F = 4 * C;
     constexpr int KK1 = C / 16;            // k16 steps of the first product
@@ -108,6 +132,8 @@ __global__ __launch_bounds__(NWV * 64, (C == 64 && SPLIT != 3 && NWV == 4) ? FW_
     constexpr bool PK16 = FFN_GELU_PK16 && Q5 && SPLIT == PREC_F16;
     constexpr int W_ARR = F * RB1;         // = C * RB2 = 8 C^2
     constexpr int OFF_W1 = 0, OFF_W2 = NARR * W_ARR, OFF_V = 2 * NARR * W_ARR;  // then b1[F] b2[C] gamma[C] norm_w[C] (fp32)
+    constexpr int VEC_F = F + 3 * C + (MIX ? 10 * C : 0);   // ... and, MIX, the mixer's norm weight, conv bias, layer scale [C] and taps [7][C]
+    constexpr int BLKB = OFF_V + VEC_F * 4;                 // bytes of ONE block's weights + vectors; block b lives at smem + b * BLKB
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -115,37 +141,51 @@ __global__ __launch_bounds__(NWV * 64, (C == 64 && SPLIT != 3 && NWV == 4) ? FW_
 
     auto swz1 = [](int r) { return RB1 == 128 ? ((r >> 1) & 7) : ((r >> 2) & 3); };
     // ---- one-time: weight images into LDS (16-B chunks XOR-swizzled so every fragment read is conflict free) ----
-    for (int i = tid; i < F * (C / 8); i += NT) {
-        const int r = i / (C / 8), ch = i % (C / 8);
-        const int dst = r * RB1 + ((ch ^ swz1(r)) << 4);
-        *reinterpret_cast<uint4*>(smem + OFF_W1 + dst) = *reinterpret_cast<const uint4*>(a.w1hi + (long)r * a.ld1 + ch * 8);
-        if (SPLIT == 3)
-            *reinterpret_cast<uint4*>(smem + OFF_W1 + W_ARR + dst) = *reinterpret_cast<const uint4*>(a.w1lo + (long)r * a.ld1 + ch * 8);
+#pragma unroll 1
+    for (int b = 0; b < NB; ++b) {
+        const FfnWaveArgs& ab = blks[b];
+        char* const wdst = smem + b * BLKB;
+        for (int i = tid; i < F * (C / 8); i += NT) {
+            const int r = i / (C / 8), ch = i % (C / 8);
+            const int dst = r * RB1 + ((ch ^ swz1(r)) << 4);
+            *reinterpret_cast<uint4*>(wdst + OFF_W1 + dst) = *reinterpret_cast<const uint4*>(ab.w1hi + (long)r * ab.ld1 + ch * 8);
+            if (SPLIT == 3)
+                *reinterpret_cast<uint4*>(wdst + OFF_W1 + W_ARR + dst) = *reinterpret_cast<const uint4*>(ab.w1lo + (long)r * ab.ld1 + ch * 8);
+        }
+        for (int i = tid; i < C * (F / 8); i += NT) {
+            const int r = i / (F / 8), ch = i % (F / 8);
+            const int dst = r * RB2 + (((ch & ~15) | ((ch ^ r) & 15)) << 4);
+            *reinterpret_cast<uint4*>(wdst + OFF_W2 + dst) = *reinterpret_cast<const uint4*>(ab.w2hi + (long)r * F + ch * 8);
+            if (SPLIT == 3)
+                *reinterpret_cast<uint4*>(wdst + OFF_W2 + W_ARR + dst) = *reinterpret_cast<const uint4*>(ab.w2lo + (long)r * F + ch * 8);
+        }
+        float* const v = reinterpret_cast<float*>(wdst + OFF_V);
+        for (int i = tid; i < F; i += NT) v[i] = ab.b1[i];
+        for (int i = tid; i < C; i += NT) { v[F + i] = ab.b2[i]; v[F + C + i] = ab.gamma[i]; v[F + 2 * C + i] = ab.norm_w[i]; }
+        if (MIX) {
+            for (int i = tid; i < C; i += NT) { v[F + 3 * C + i] = ab.mnorm_w[i]; v[F + 4 * C + i] = ab.dw_b[i]; v[F + 5 * C + i] = ab.mgamma[i]; }
+            for (int i = tid; i < 7 * C; i += NT) v[F + 6 * C + i] = ab.dw_w[i];
+        }
     }
-    for (int i = tid; i < C * (F / 8); i += NT) {
-        const int r = i / (F / 8), ch = i % (F / 8);
-        const int dst = r * RB2 + (((ch & ~15) | ((ch ^ r) & 15)) << 4);
-        *reinterpret_cast<uint4*>(smem + OFF_W2 + dst) = *reinterpret_cast<const uint4*>(a.w2hi + (long)r * F + ch * 8);
-        if (SPLIT == 3)
-            *reinterpret_cast<uint4*>(smem + OFF_W2 + W_ARR + dst) = *reinterpret_cast<const uint4*>(a.w2lo + (long)r * F + ch * 8);
-    }
-    float* vb1 = reinterpret_cast<float*>(smem + OFF_V);
-    float* vb2 = vb1 + F;
-    float* vga = vb2 + C;
-    float* vnw = vga + C;
-    // MIX: mixer vectors behind them, then one n-tile per wave
-    float* vmn = vnw + C;        // mixer norm weight [C]
-    float* vdb = vmn + C;        // conv bias [C]
-    float* vmg = vdb + C;        // mixer layer scale [C]
-    float* vdw = vmg + C;        // conv taps [7][C]
+    // the block whose weights the lambdas below address: a compile-time constant for NB == 1, advanced per block by the chain
+    const char* wsm = smem;
+    const float *vb1, *vb2, *vga, *vnw, *vmn, *vdb, *vmg, *vdw;
+    auto select_block = [&](int b) {
+        wsm = smem + (NB > 1 ? b * BLKB : 0);
+        vb1 = reinterpret_cast<const float*>(wsm + OFF_V);
+        vb2 = vb1 + F;
+        vga = vb2 + C;
+        vnw = vga + C;
+        vmn = vnw + C;        // mixer norm weight [C]
+        vdb = vmn + C;        // conv bias [C]
+        vmg = vdb + C;        // mixer layer scale [C]
+        vdw = vmg + C;        // conv taps [7][C]
+    };
+    select_block(0);
     constexpr int RSN = C + 4;   // n-tile row stride in floats: 16 B of padding -> the 32 frames of a ds_read_b128 hit 32 different bank quads
-    float* ntile = vdw + 7 * C + (size_t)wave * (38 * RSN);
-    for (int i = tid; i < F; i += NT) vb1[i] = a.b1[i];
-    for (int i = tid; i < C; i += NT) { vb2[i] = a.b2[i]; vga[i] = a.gamma[i]; vnw[i] = a.norm_w[i]; }
-    if (MIX) {
-        for (int i = tid; i < C; i += NT) { vmn[i] = a.mnorm_w[i]; vdb[i] = a.dw_b[i]; vmg[i] = a.mgamma[i]; }
-        for (int i = tid; i < 7 * C; i += NT) vdw[i] = a.dw_w[i];
-    }
+    // per wave: the n-tile (6 halo rows + 32 frames) and, chain, the raw halo rows of blocks 1 .. NB - 1 parked for the next tile
+    constexpr int TILE_F = (38 + (NB > 1 ? 6 * (NB - 1) : 0)) * RSN;
+    float* const ntile = reinterpret_cast<float*>(smem + NB * BLKB) + (size_t)wave * TILE_F;
     __syncthreads();
 
     // fragment byte offsets (constant for the kernel)
@@ -164,6 +204,17 @@ __global__ __launch_bounds__(NWV * 64, (C == 64 && SPLIT != 3 && NWV == 4) ? FW_
 
     const int ntiles = (a.M + 31) / 32;
     const int wg = blockIdx.x * NWV + wave, nwg = gridDim.x * NWV;
+    // tile walk: NB == 1 strides over the image (tile wg, wg + nwg, ...); the chain takes a contiguous run [seg0, seg1) in time order,
+    // preceded by one warm-up tile (computed, not stored) unless the run starts where an utterance starts
+    int t_first = wg, t_last = ntiles, t_step = nwg;
+    if (CHAIN) {
+        const int per = (ntiles + nwg - 1) / nwg;
+        const int seg0 = wg * per;
+        t_last = seg0 + per < ntiles ? seg0 + per : ntiles;
+        t_first = seg0 < t_last && (seg0 % tpu) != 0 ? seg0 - 1 : seg0;
+        t_step = 1;
+    }
+    const int t_store0 = CHAIN ? wg * ((ntiles + nwg - 1) / nwg) : 0;   // chain: tiles before this one are warm-up
 
     // channel of element e (0..7) of k16 step kk in this lane's B fragment: 16 kk + 8 fh + e
     float4 xa[KK1][2];  // raw x of the tile being prefetched / computed
@@ -186,10 +237,48 @@ __global__ __launch_bounds__(NWV * 64, (C == 64 && SPLIT != 3 && NWV == 4) ? FW_
             hv[1] = *reinterpret_cast<const float4*>(hr_ + 4);
         }
     };
-    if (wg < ntiles) load_tile(wg);
+    if (t_first < t_last) load_tile(t_first);
 
 #pragma unroll 1
-    for (int wt = wg; wt < ntiles; wt += nwg) {
+    for (int wt = t_first; wt < t_last; wt += t_step) {
+      float4 xo[NOT][4];   // a block's output tile in the accumulator layout (chain: the next block's input)
+#pragma unroll 1
+      for (int blk = 0; blk < NB; ++blk) {
+        if (NB > 1) {
+            select_block(blk);
+            if (blk > 0) {
+                // input tile = the previous block's output: accumulator layout (4-channel groups q of channel tile ot) -> B-fragment
+                // layout (8 consecutive channels per lane half), the inverse of KEEPX's swap (it is an involution)
+#pragma unroll
+                for (int kk = 0; kk < KK1; ++kk) {
+                    const float4 e4 = xo[kk / 2][2 * (kk % 2)], o4 = xo[kk / 2][2 * (kk % 2) + 1];
+                    const float ev[4] = {e4.x, e4.y, e4.z, e4.w}, ov[4] = {o4.x, o4.y, o4.z, o4.w};
+                    float a0[4], a1[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(ev[e]), __float_as_uint(ov[e]), false, false);
+                        a0[e] = __uint_as_float(r[0]); a1[e] = __uint_as_float(r[1]);
+                    }
+                    xa[kk][0] = make_float4(a0[0], a0[1], a0[2], a0[3]);
+                    xa[kk][1] = make_float4(a1[0], a1[1], a1[2], a1[3]);
+                }
+                // its halo: the last six frames of this block's input on the previous tile (zeros where an utterance / the run starts)
+                float* const hs = ntile + (38 + 6 * (blk - 1)) * RSN;
+                const bool fresh = wt == t_first || (wt % tpu) == 0;
+                const int l = lane < 6 * LPF ? lane : 0;
+                const float4 h0 = *reinterpret_cast<const float4*>(hs + (l / LPF) * RSN + 8 * (l % LPF));
+                const float4 h1 = *reinterpret_cast<const float4*>(hs + (l / LPF) * RSN + 8 * (l % LPF) + 4);
+                hv[0] = fresh ? make_float4(0.f, 0.f, 0.f, 0.f) : h0;
+                hv[1] = fresh ? make_float4(0.f, 0.f, 0.f, 0.f) : h1;
+                if (fr >= 26) {   // ... and park this tile's last six input frames for the next tile (same wave: LDS operations stay in order)
+#pragma unroll
+                    for (int kk = 0; kk < KK1; ++kk) {
+                        *reinterpret_cast<float4*>(hs + (fr - 26) * RSN + 16 * kk + 8 * fh) = xa[kk][0];
+                        *reinterpret_cast<float4*>(hs + (fr - 26) * RSN + 16 * kk + 8 * fh + 4) = xa[kk][1];
+                    }
+                }
+            }
+        }
         if (MIX) {
             // ---- mixer: u = x * rstd (no affine) of the 32 + 6 frames -> LDS, conv over the seven rows, LayerScale residual ----
             float ms = 0.f;
@@ -197,14 +286,13 @@ __global__ __launch_bounds__(NWV * 64, (C == 64 && SPLIT != 3 && NWV == 4) ? FW_
             for (int kk = 0; kk < KK1; ++kk)
 #pragma unroll
                 for (int h2 = 0; h2 < 2; ++h2)
-                    ms += xa[kk][h2].x * xa[kk][h2].x + xa[kk][h2].y * xa[kk][h2].y + xa[kk][h2].z * xa[kk][h2].z + xa[kk][h2].w * xa[kk][h2].w;
+                    ms = ssq4(xa[kk][h2], ms);
             ms += __shfl_xor(ms, 32, 64);
-            const float mr = 1.0f / sqrtf(ms / (float)C + a.eps);
-            float hs = hv[0].x * hv[0].x + hv[0].y * hv[0].y + hv[0].z * hv[0].z + hv[0].w * hv[0].w +
-                       hv[1].x * hv[1].x + hv[1].y * hv[1].y + hv[1].z * hv[1].z + hv[1].w * hv[1].w;
+            const float mr = 1.0f / sqrtf(fmaf(ms, 1.0f / (float)C, a.eps));
+            float hs = ssq4(hv[1], ssq4(hv[0], 0.f));
 #pragma unroll
             for (int o = LPF >> 1; o > 0; o >>= 1) hs += __shfl_xor(hs, o, 64);
-            const float hrs = 1.0f / sqrtf(hs / (float)C + a.eps);
+            const float hrs = 1.0f / sqrtf(fmaf(hs, 1.0f / (float)C, a.eps));
             float* own = ntile + (6 + fr) * RSN + 8 * fh;
 #pragma unroll
             for (int kk = 0; kk < KK1; ++kk) {
@@ -252,9 +340,9 @@ __global__ __launch_bounds__(NWV * 64, (C == 64 && SPLIT != 3 && NWV == 4) ? FW_
         for (int kk = 0; kk < KK1; ++kk)
 #pragma unroll
             for (int h2 = 0; h2 < 2; ++h2)
-                ss += xa[kk][h2].x * xa[kk][h2].x + xa[kk][h2].y * xa[kk][h2].y + xa[kk][h2].z * xa[kk][h2].z + xa[kk][h2].w * xa[kk][h2].w;
+                ss = ssq4(xa[kk][h2], ss);
         ss += __shfl_xor(ss, 32, 64);
-        const float rstd = 1.0f / sqrtf(ss / (float)C + a.eps);
+        const float rstd = 1.0f / sqrtf(fmaf(ss, 1.0f / (float)C, a.eps));
         bf16x8 nh[KK1], nl[KK1];
 #pragma unroll
         for (int kk = 0; kk < KK1; ++kk) {
@@ -286,7 +374,7 @@ __global__ __launch_bounds__(NWV * 64, (C == 64 && SPLIT != 3 && NWV == 4) ? FW_
 #pragma unroll
             for (int kk = 0; kk < KK1; ++kk) { xk[kk][0] = xa[kk][0]; xk[kk][1] = xa[kk][1]; }
         }
-        if (wt + nwg < ntiles) load_tile(wt + nwg);  // next tile's x arrives under this tile's MFMA / GELU work
+        if ((NB == 1 || blk == NB - 1) && wt + t_step < t_last) load_tile(wt + t_step);  // next tile's x arrives under this tile's MFMA / GELU work
 
         floatx16 acc2[NOT];
 #pragma unroll
@@ -323,8 +411,8 @@ __global__ __launch_bounds__(NWV * 64, (C == 64 && SPLIT != 3 && NWV == 4) ? FW_
             const int w1t = (t + 1) * 32 * RB1;
             const int w2t = (((t - 1) & 3) ^ rsw) * 64 + ((t - 1) >> 2) * 256;
             if (P1) {
-                w1f[0][0] = *reinterpret_cast<const bf16x8*>(smem + OFF_W1 + w1t + w1_off[0]);
-                if (SPLIT == 3) w1f[0][1] = *reinterpret_cast<const bf16x8*>(smem + OFF_W1 + W_ARR + w1t + w1_off[0]);
+                w1f[0][0] = *reinterpret_cast<const bf16x8*>(wsm + OFF_W1 + w1t + w1_off[0]);
+                if (SPLIT == 3) w1f[0][1] = *reinterpret_cast<const bf16x8*>(wsm + OFF_W1 + W_ARR + w1t + w1_off[0]);
             }
             if (P1) bias_init(accn, t + 1);  // the accumulators start from b1: no separate bias add
             // ---- A (packed): exponent argument ----
@@ -361,15 +449,15 @@ __global__ __launch_bounds__(NWV * 64, (C == 64 && SPLIT != 3 && NWV == 4) ? FW_
                 }
             };
             if (P1) {
-                constexpr int NB = KK1 * NPASS;
+                constexpr int NMB = KK1 * NPASS;
 #pragma unroll
                 for (int kk = 0; kk < KK1; ++kk) {
                     if (kk + 1 < KK1) {
-                        w1f[(kk + 1) & 1][0] = *reinterpret_cast<const bf16x8*>(smem + OFF_W1 + w1t + w1_off[kk + 1]);
-                        if (SPLIT == 3) w1f[(kk + 1) & 1][1] = *reinterpret_cast<const bf16x8*>(smem + OFF_W1 + W_ARR + w1t + w1_off[kk + 1]);
+                        w1f[(kk + 1) & 1][0] = *reinterpret_cast<const bf16x8*>(wsm + OFF_W1 + w1t + w1_off[kk + 1]);
+                        if (SPLIT == 3) w1f[(kk + 1) & 1][1] = *reinterpret_cast<const bf16x8*>(wsm + OFF_W1 + W_ARR + w1t + w1_off[kk + 1]);
                     } else if (P2) {
-                        w2f[0][0] = *reinterpret_cast<const bf16x8*>(smem + OFF_W2 + w2_b[0] + w2t);
-                        if (SPLIT == 3) w2f[0][1] = *reinterpret_cast<const bf16x8*>(smem + OFF_W2 + W2LO + w2_b[0] + w2t);
+                        w2f[0][0] = *reinterpret_cast<const bf16x8*>(wsm + OFF_W2 + w2_b[0] + w2t);
+                        if (SPLIT == 3) w2f[0][1] = *reinterpret_cast<const bf16x8*>(wsm + OFF_W2 + W2LO + w2_b[0] + w2t);
                     }
 #pragma unroll
                     for (int ps = 0; ps < NPASS; ++ps) {
@@ -377,13 +465,13 @@ __global__ __launch_bounds__(NWV * 64, (C == 64 && SPLIT != 3 && NWV == 4) ? FW_
                         __builtin_amdgcn_sched_barrier(0);
                         mfma3(accn, w1f[kk & 1], nh[kk], nl[kk], ps);
 #pragma unroll
-                        for (int v = 16 * j / NB; v < 16 * (j + 1) / NB; ++v) trans(v);
+                        for (int v = 16 * j / NMB; v < 16 * (j + 1) / NMB; ++v) trans(v);
                     }
                 }
             } else {
                 if (P2) {
-                    w2f[0][0] = *reinterpret_cast<const bf16x8*>(smem + OFF_W2 + w2_b[0] + w2t);
-                    if (SPLIT == 3) w2f[0][1] = *reinterpret_cast<const bf16x8*>(smem + OFF_W2 + W2LO + w2_b[0] + w2t);
+                    w2f[0][0] = *reinterpret_cast<const bf16x8*>(wsm + OFF_W2 + w2_b[0] + w2t);
+                    if (SPLIT == 3) w2f[0][1] = *reinterpret_cast<const bf16x8*>(wsm + OFF_W2 + W2LO + w2_b[0] + w2t);
                 }
 #pragma unroll
                 for (int v = 0; v < 16; ++v) trans(v);
@@ -447,7 +535,7 @@ __global__ __launch_bounds__(NWV * 64, (C == 64 && SPLIT != 3 && NWV == 4) ? FW_
                     const int s2 = g / NOT, ot = g % NOT;
                     if (g + 1 < 2 * NOT) {
                         const int s3 = (g + 1) / NOT, ot3 = (g + 1) % NOT;
-                        const char* nx = smem + OFF_W2 + w2_b[s3] + w2t + ot3 * 32 * RB2;
+                        const char* nx = wsm + OFF_W2 + w2_b[s3] + w2t + ot3 * 32 * RB2;
                         w2f[(g + 1) & 1][0] = *reinterpret_cast<const bf16x8*>(nx);
                         if (SPLIT == 3) w2f[(g + 1) & 1][1] = *reinterpret_cast<const bf16x8*>(nx + W2LO);
                     }
@@ -479,13 +567,13 @@ __global__ __launch_bounds__(NWV * 64, (C == 64 && SPLIT != 3 && NWV == 4) ? FW_
         {   // pipeline fill: first product of hidden tile 0
             bias_init(hA, 0);
             bf16x8 w1f[2][2];
-            w1f[0][0] = *reinterpret_cast<const bf16x8*>(smem + OFF_W1 + w1_off[0]);
-            if (SPLIT == 3) w1f[0][1] = *reinterpret_cast<const bf16x8*>(smem + OFF_W1 + W_ARR + w1_off[0]);
+            w1f[0][0] = *reinterpret_cast<const bf16x8*>(wsm + OFF_W1 + w1_off[0]);
+            if (SPLIT == 3) w1f[0][1] = *reinterpret_cast<const bf16x8*>(wsm + OFF_W1 + W_ARR + w1_off[0]);
 #pragma unroll
             for (int kk = 0; kk < KK1; ++kk) {
                 if (kk + 1 < KK1) {
-                    w1f[(kk + 1) & 1][0] = *reinterpret_cast<const bf16x8*>(smem + OFF_W1 + w1_off[kk + 1]);
-                    if (SPLIT == 3) w1f[(kk + 1) & 1][1] = *reinterpret_cast<const bf16x8*>(smem + OFF_W1 + W_ARR + w1_off[kk + 1]);
+                    w1f[(kk + 1) & 1][0] = *reinterpret_cast<const bf16x8*>(wsm + OFF_W1 + w1_off[kk + 1]);
+                    if (SPLIT == 3) w1f[(kk + 1) & 1][1] = *reinterpret_cast<const bf16x8*>(wsm + OFF_W1 + W_ARR + w1_off[kk + 1]);
                 }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -503,14 +591,14 @@ __global__ __launch_bounds__(NWV * 64, (C == 64 && SPLIT != 3 && NWV == 4) ? FW_
         {   // pipeline drain: second product of the last hidden tile
             const int w2t = (((NT1 - 1) & 3) ^ rsw) * 64 + ((NT1 - 1) >> 2) * 256;
             bf16x8 w2f[2][2];
-            w2f[0][0] = *reinterpret_cast<const bf16x8*>(smem + OFF_W2 + w2_b[0] + w2t);
-            if (SPLIT == 3) w2f[0][1] = *reinterpret_cast<const bf16x8*>(smem + OFF_W2 + W2LO + w2_b[0] + w2t);
+            w2f[0][0] = *reinterpret_cast<const bf16x8*>(wsm + OFF_W2 + w2_b[0] + w2t);
+            if (SPLIT == 3) w2f[0][1] = *reinterpret_cast<const bf16x8*>(wsm + OFF_W2 + W2LO + w2_b[0] + w2t);
 #pragma unroll
             for (int g = 0; g < 2 * NOT; ++g) {
                 const int s2 = g / NOT, ot = g % NOT;
                 if (g + 1 < 2 * NOT) {
                     const int s3 = (g + 1) / NOT, ot3 = (g + 1) % NOT;
-                    const char* nx = smem + OFF_W2 + w2_b[s3] + w2t + ot3 * 32 * RB2;
+                    const char* nx = wsm + OFF_W2 + w2_b[s3] + w2t + ot3 * 32 * RB2;
                     w2f[(g + 1) & 1][0] = *reinterpret_cast<const bf16x8*>(nx);
                     if (SPLIT == 3) w2f[(g + 1) & 1][1] = *reinterpret_cast<const bf16x8*>(nx + W2LO);
                 }
@@ -522,7 +610,7 @@ __global__ __launch_bounds__(NWV * 64, (C == 64 && SPLIT != 3 && NWV == 4) ? FW_
         // ---- epilogue: x[frame][c] += gamma[c] (out + b2[c]); channel(r) = 32 ot + (r & 3) + 8 (r >> 2) + 4 fh -------
         if (m_cur < a.M) {
             float* xr = a.x + a.img.at(m_cur);
-            float4 xo[NOT][4];
+            const bool store = blk == NB - 1 && wt >= t_store0;   // chain: the last block of a tile that is not warm-up
             if (KEEPX) {
                 // xk[kk][h2] holds channels 16 kk + 8 fh + 4 h2 + (0..3); the accumulator rows 4 q .. 4 q + 3 of channel tile ot are
                 // channels 32 ot + 8 q + 4 fh + (0..3) = 16 kk' + 8 (q & 1) + 4 fh + (0..3), kk' = 2 ot + q / 2.  Swapping the upper lane
@@ -561,14 +649,27 @@ __global__ __launch_bounds__(NWV * 64, (C == 64 && SPLIT != 3 && NWV == 4) ? FW_
                     const float4 bv = *reinterpret_cast<const float4*>(vb2 + c0);
                     const float4 gv = *reinterpret_cast<const float4*>(vga + c0);
                     float4 o = xo[ot][q];
-                    o.x += gv.x * (acc2[ot][4 * q + 0] + bv.x);
-                    o.y += gv.y * (acc2[ot][4 * q + 1] + bv.y);
-                    o.z += gv.z * (acc2[ot][4 * q + 2] + bv.z);
-                    o.w += gv.w * (acc2[ot][4 * q + 3] + bv.w);
-                    *reinterpret_cast<float4*>(xr + c0) = o;
+                    o.x = fmaf(gv.x, acc2[ot][4 * q + 0] + bv.x, o.x);
+                    o.y = fmaf(gv.y, acc2[ot][4 * q + 1] + bv.y, o.y);
+                    o.z = fmaf(gv.z, acc2[ot][4 * q + 2] + bv.z, o.z);
+                    o.w = fmaf(gv.w, acc2[ot][4 * q + 3] + bv.w, o.w);
+                    if (store) *reinterpret_cast<float4*>(xr + c0) = o;
+                    if (NB > 1) xo[ot][q] = o;
                 }
         }
+      }
     }
+}
+
+template <int C, int SPLIT, int NWV, bool MIX = false>
+__global__ __launch_bounds__(NWV * 64, (C == 64 && SPLIT != 3 && NWV == 4) ? FW_MINW64 : (C == 32 && SPLIT != 3) ? FW_MINW32 : 1) void codec_ffn_wave_kernel(FfnWaveArgs a) {
+    codec_ffn_wave_body<C, SPLIT, NWV, MIX, 1>(a, &a, 0);
+}
+
+// the stage chain: NB one-pass blocks per tile (C = 32: all three blocks' fp16 weights are LDS-resident, 48 KiB)
+template <int C, int SPLIT, int NWV, int NB>
+__global__ __launch_bounds__(NWV * 64) void codec_chain_wave_kernel(FfnChainArgs c) {
+    codec_ffn_wave_body<C, SPLIT, NWV, true, NB, true>(c.b[0], c.b, c.tpu);
 }
 
 #ifndef FW_NWV32
@@ -629,4 +730,51 @@ hipError_t launch_codec_block_wave(const float* xin, float* xout, RowMap img, co
                  8.0 * M * C + 8.0 * (double)C * F);
     if (C == 64) return split == PREC_F16 ? ffn_wave_go<64, 2, true>(a, st) : ffn_wave_go<64, 1, true>(a, st);
     return split == 3 ? ffn_wave_go<32, 3, true>(a, st) : split == PREC_F16 ? ffn_wave_go<32, 2, true>(a, st) : ffn_wave_go<32, 1, true>(a, st);
+}
+
+// ---- stage chain: all NB blocks of a C = 32 stage in one launch (single-array operand formats) ---------------------------------------
+#ifndef FW_CHAIN_NWV
+#define FW_CHAIN_NWV 12   // waves per workgroup = per CU: 3 x 18.1 KiB of weights + vectors and 7.9 KiB of tiles per wave -> 149 KiB at 12
+#endif
+bool codec_chain_wave_ok(int C, int F, int K, int T, int split, int nb) {
+    return C == 32 && nb >= 1 && nb <= 3 && split != 3 && codec_block_wave_ok(C, F, K, T, split);
+}
+template <int C, int SPLIT, int NB>
+static hipError_t chain_wave_go(const FfnChainArgs& c, hipStream_t st) {
+    constexpr int NWV = FW_CHAIN_NWV, F = 4 * C;
+    constexpr size_t blkb = (size_t)2 * (8 * C * C) + (size_t)(F + 3 * C + 10 * C) * 4;
+    constexpr size_t lds = NB * blkb + (size_t)NWV * (38 + 6 * (NB - 1)) * (C + 4) * 4;
+    static_assert(lds <= 160 * 1024, "chain: weights + tiles must fit LDS");
+    auto kern = codec_chain_wave_kernel<C, SPLIT, NWV, NB>;
+    static DevOnce once;
+    int cus = 256;
+    hipError_t e = once.ensure([&] {
+        return hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    }, &cus);
+    if (e != hipSuccess) return e;
+    if (!(g_persist_mask & 2)) cus = once.real_cus();
+    const int ntiles = c.b[0].M / 32;
+    int grid = (ntiles + NWV - 1) / NWV;
+    grid = grid < cus ? grid : cus;   // persistent: one workgroup per CU, every wave one contiguous run of tiles
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(NWV * 64), lds, st, c);
+    return hipGetLastError();
+}
+// xout = block[nb - 1](... block[0](xin)); xin != xout, both images with zero pad frames; blocks: {mixer norm, taps, conv bias, mixer
+// layer scale, FFN norm, W1, b1, W2, b2, FFN layer scale} each
+hipError_t launch_codec_chain_wave(const float* xin, float* xout, RowMap img, const CodecChainBlock* blocks, int nb, int M, int C, int F, int K,
+                                   float eps, int split, hipStream_t st) {
+    if (!codec_chain_wave_ok(C, F, K, img.rpb, split, nb) || xin == xout || img.ld != C || img.off % 4 || img.bstride % 4 || M % 32)
+        return hipErrorInvalidValue;
+    if (M <= 0) return hipSuccess;
+    FfnChainArgs c{};
+    for (int i = 0; i < nb; ++i) {
+        const CodecChainBlock& b = blocks[i];
+        if (b.ld1 % 8) return hipErrorInvalidValue;
+        c.b[i] = FfnWaveArgs{xout, img, b.norm_w, b.w1, nullptr, b.ld1, b.b1, b.w2, nullptr, b.b2, b.gamma, M, eps, xin, b.mnorm_w, b.dw_w, b.dw_b, b.mgamma};
+    }
+    c.tpu = img.rpb / 32;
+    ProfScope ps(st, "codec_chain_wave<32>", nb * (4.0 * M * (double)C * F + 2.0 * M * C * (K + 4)), 8.0 * M * C + nb * 8.0 * (double)C * F);
+    if (nb == 1) return split == PREC_F16 ? chain_wave_go<32, 2, 1>(c, st) : chain_wave_go<32, 1, 1>(c, st);
+    if (nb == 2) return split == PREC_F16 ? chain_wave_go<32, 2, 2>(c, st) : chain_wave_go<32, 1, 2>(c, st);
+    return split == PREC_F16 ? chain_wave_go<32, 2, 3>(c, st) : chain_wave_go<32, 1, 3>(c, st);
 }

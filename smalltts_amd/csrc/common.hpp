@@ -157,6 +157,16 @@ __device__ __forceinline__ unsigned cvt_pk_f16_raw(float a, float b) {
     v.x = a; v.y = b;
     return __builtin_bit_cast(unsigned, __builtin_convertvector(v, half2_t));
 }
+// The PACKED-fp16 evaluation (gelu_q5_pk_front / _back: the fused codec FFN kernels at the fp16 operand format) is limited by its own
+// fp16 Horner steps, not by the fit: over x ~ N(0, 1.5) the rms error of the fp16 result against exact GELU is 3.10e-4 with the
+// degree-5 exponent, 3.19e-4 with degree 3 — and 2.12e-4 for the correctly rounded fp16 of the exact value (tests/studies/
+// gelu_f16_packed.py, round 5).  Degree 3 saves two of eleven VALU instructions per value pair in kernels that are VALU-bound.
+#ifndef GELU_PK_DEG
+#define GELU_PK_DEG 3
+#endif
+struct GeluQ3 {   // minimax fit of a Phi(-a) = a 2^q(a) over a in [0, 9] (tests/studies/gelu_q5_fit.py fit(3)): |error| <= 1.2e-4 in exact arithmetic
+    static constexpr float Q0 = -1.008443832397461f, Q1 = -1.113277792930603f, Q2 = -0.5132908821105957f, Q3 = -0.02108863927423954f;
+};
 __device__ __forceinline__ void gelu_q5_pk_front(float a, float b, unsigned& hp, unsigned& axp, unsigned& ep) {
     f32x2_t v;
     v.x = a; v.y = b;
@@ -164,11 +174,17 @@ __device__ __forceinline__ void gelu_q5_pk_front(float a, float b, unsigned& hp,
     hp = __builtin_bit_cast(unsigned, h);
     axp = hp & 0x7fff7fffu;
     const half2_t ax = __builtin_bit_cast(half2_t, axp);
+#if GELU_PK_DEG == 5
     half2_t q = __builtin_elementwise_fma(h2_splat(GeluQ5::Q5), ax, h2_splat(GeluQ5::Q4));
     q = __builtin_elementwise_fma(q, ax, h2_splat(GeluQ5::Q3));
     q = __builtin_elementwise_fma(q, ax, h2_splat(GeluQ5::Q2));
     q = __builtin_elementwise_fma(q, ax, h2_splat(GeluQ5::Q1));
     q = __builtin_elementwise_fma(q, ax, h2_splat(GeluQ5::Q0));
+#else
+    half2_t q = __builtin_elementwise_fma(h2_splat(GeluQ3::Q3), ax, h2_splat(GeluQ3::Q2));
+    q = __builtin_elementwise_fma(q, ax, h2_splat(GeluQ3::Q1));
+    q = __builtin_elementwise_fma(q, ax, h2_splat(GeluQ3::Q0));
+#endif
     ep = exp2_pk_f16(__builtin_bit_cast(unsigned, q));
 }
 __device__ __forceinline__ unsigned gelu_q5_pk_back(unsigned hp, unsigned axp, unsigned ep) {

@@ -61,6 +61,8 @@ Engine::Engine(int device) : device_(device) {
     const char* s = getenv("SMTTS_SINGLE_STREAM");
     if (s && *s == '1') dual_stream_ = false;
     if ((s = getenv("SMTTS_BLOCK_WAVE"))) block_wave_ = atoi(s) != 0;
+    if ((s = getenv("SMTTS_STAGE_CHAIN"))) stage_chain_ = atoi(s) != 0;
+    if ((s = getenv("SMTTS_CHAIN_MIN"))) chain_min_blocks_ = atoi(s);
     if ((s = getenv("SMTTS_SMALLM_SPLITK"))) g_small_m_splitk = atoi(s);
     if ((s = getenv("SMTTS_CONVPOS_BY_GROUP"))) convpos_by_group_ = atoi(s) != 0;
     if ((s = getenv("SMTTS_ATTN_EPI"))) attn_epi_ = atoi(s) != 0;
@@ -1456,6 +1458,31 @@ int Engine::sample(hipStream_t st, int mode, int n_steps, int cfg, float s_text,
 // front of each batch item implement the causal left padding of every conv, so strided / transposed /
 // k-tap convs all become plain GEMMs over overlapping rows.
 // ---------------------------------------------------------------------------------------------
+// Stage chain (codec_ffn_wave.hip): every block of a C = 32 stage on each 32-frame tile back to back — the stage's image is read once
+// and written once instead of once per block.  Returns 1 when the stage was enqueued (images swapped); 0 = not eligible, the
+// caller runs the blocks one by one (bit-identical results either way: tests/test_codec_gpu.py::test_alternative_paths_*).
+int Engine::codec_stage_chain(hipStream_t st, const CodecStageW& sg, float** xp, float** xaltp, int B, int T, int C) {
+    const int F = cspec_.ffn_mult * C, nb = (int)sg.blocks.size();
+    if (!stage_chain_ || !fused_ffn_ || !block_wave_ || nb < chain_min_blocks_ || nb > 3) return 0;
+    int pf = prec_[SITE_CODEC_FFN];
+    for (const CodecBlockW& b : sg.blocks) {
+        if (pf == PREC_F16 && !b.f16_ok) return 0;   // an uncertified block runs split-bf16: per-block path
+        if (b.w1.K != C || b.w2.K != F) return 0;
+    }
+    if (!codec_chain_wave_ok(C, F, cspec_.kernel, T, pf, nb)) return 0;
+    CodecChainBlock cb[3];
+    for (int i = 0; i < nb; ++i) {
+        const CodecBlockW& b = sg.blocks[i];
+        cb[i] = CodecChainBlock{b.norm_w, b.dw_w, b.dw_b, b.gamma, b.ffn_norm_w, pf == PREC_F16 ? b.w1.h16 : b.w1.hi, b.w1.K, b.b1,
+                                pf == PREC_F16 ? b.w2.h16 : b.w2.hi, b.b2, b.ffn_gamma};
+    }
+    const RowMap img = rowmap_batched(C, T, (long)(kCodecPad + T) * C, (long)kCodecPad * C);
+    const hipError_t e = launch_codec_chain_wave(*xp, *xaltp, img, cb, nb, B * T, C, F, cspec_.kernel, cspec_.eps, pf, st);
+    if (e != hipSuccess) { fail_hip(e, "codec stage chain"); return -1; }
+    float* t = *xp; *xp = *xaltp; *xaltp = t;
+    return 1;
+}
+
 int Engine::codec_block(hipStream_t st, const CodecBlockW& w, float** xp, float** xaltp, float* nbuf, bf16_t* n2hi,
                         bf16_t* n2lo, bf16_t* hhi, bf16_t* hlo, int B, int T, int C, size_t n2_elems) {
     const int M = B * T, pad = kCodecPad;
@@ -1676,6 +1703,10 @@ int Engine::codec_decode(hipStream_t st, const float* latents, int B, int T, flo
             // input (now the ping-pong partner) is free to be overwritten from here on
             HIPC(launch_zero_pad_frames3(x, xn, w.nb, B, Ti, C, pad, st));
         }
+        if (const int ch = codec_stage_chain(st, sg, &x, &xn, B, Ti, C)) {   // > 0: the whole stage went out as one launch
+            if (ch < 0) return 1;
+            continue;
+        }
         for (const CodecBlockW& b : sg.blocks)
             if (codec_block(st, b, &x, &xn, w.nb, w.n2hi, w.n2lo, w.hhi, w.hlo, B, Ti, C, max_img)) return 1;
     }
@@ -1771,6 +1802,10 @@ int Engine::codec_encode(hipStream_t st, const float* audio, int B, int S_, floa
             Ti = Tn;
             C = Cn;
             HIPC(launch_zero_pad_frames3(x, xn, w.nb, B, Ti, C, pad, st));   // (behind the product, as in the decoder)
+        }
+        if (const int ch = codec_stage_chain(st, sg, &x, &xn, B, Ti, C)) {
+            if (ch < 0) return 1;
+            continue;
         }
         for (const CodecBlockW& b : sg.blocks)
             if (codec_block(st, b, &x, &xn, w.nb, w.n2hi, w.n2lo, w.hhi, w.hlo, B, Ti, C, max_img)) return 1;

@@ -220,6 +220,7 @@ class Engine {
                      int N, int R, int P, float* velocity, char* ws, const CrossImg& ci);
     size_t denoise_core_bytes(int B, int N) const;
     // runs one block; the result lives in *x on return (the fused mixer ping-pongs *x <-> *xalt)
+    int codec_stage_chain(hipStream_t st, const CodecStageW& sg, float** x, float** xalt, int B, int T, int C);
     int codec_block(hipStream_t st, const CodecBlockW& w, float** x, float** xalt, float* nbuf, bf16_t* n2hi, bf16_t* n2lo,
                     bf16_t* hhi, bf16_t* hlo, int B, int T, int C, size_t n2_elems /* capacity of n2hi (bf16 elements) */);
     int check_shape(const std::string& name, std::initializer_list<long> want);
@@ -250,6 +251,8 @@ class Engine {
     int preset_ = kDefaultPrecision;   // set_precision(kDefaultPrecision) in the constructor fills prec_
     int prec_[SITE_COUNT] = {3, 3, 3, 3, 3, 3, 3, 3};
     bool fused_ffn_ = true;  // test hook: smtts_test_set_fused_ffn
+    int chain_min_blocks_ = 2; // ... for stages of at least this many blocks (a single block gains nothing from the chain's contiguous walk; SMTTS_CHAIN_MIN=1: debugging)
+    bool stage_chain_ = true; // codec stages with C = 32: all blocks of the stage in ONE launch (SMTTS_STAGE_CHAIN=0: one launch per block)
     bool block_wave_ = true;  // codec stages with C = 32 / 64: mixer + FFN in one kernel (SMTTS_BLOCK_WAVE=0: mixer_fused + codec_ffn_wave)
     bool mixer_wide_ = true;   // codec blocks of the wide stages: mixer + FFN norm in one pass (SMTTS_MIXER_WIDE=0: rmsnorm + dwconv_resid_rms)
     int x2_mink_ = 512, x2_maxk_ = 1024;   // PREC_F16X2 on SITE_CODEC_CONV: the ConvTranspose stages with K in this range (SMTTS_X2_MINK / _MAXK)

@@ -165,6 +165,15 @@ hipError_t launch_codec_ffn_wave(float* x, RowMap img, const float* norm_w, cons
                                  const float* b1, const bf16_t* w2hi, const bf16_t* w2lo, const float* b2, const float* gamma,
                                  int M, int C, int F, float eps, int split, hipStream_t st);
 // C in {32, 64}: mixer + FFN of one codec block in ONE pass over the image (codec_ffn_wave.hip, MIX kernels): xout = block(xin)
+// all blocks of a C = 32 codec stage in one launch (codec_ffn_wave.hip, stage chain): per block the one-pass block's operands
+struct CodecChainBlock {
+    const float *mnorm_w, *dw_w, *dw_b, *mgamma, *norm_w;
+    const bf16_t* w1; int ld1; const float* b1;
+    const bf16_t* w2; const float *b2, *gamma;
+};
+bool codec_chain_wave_ok(int C, int F, int K, int T, int split, int nb);
+hipError_t launch_codec_chain_wave(const float* xin, float* xout, RowMap img, const CodecChainBlock* blocks, int nb, int M, int C, int F, int K,
+                                   float eps, int split, hipStream_t st);
 bool codec_block_wave_ok(int C, int F, int K, int T, int split);
 hipError_t launch_codec_block_wave(const float* xin, float* xout, RowMap img, const float* mnorm_w, const float* dw_w, const float* dw_b,
                                    const float* mgamma, const float* norm_w, const bf16_t* w1hi, const bf16_t* w1lo, int ld1,

@@ -62,7 +62,26 @@ def gelu_q5_mixed(x):
     return torch.clamp_min(x, 0) - a * torch.exp2(q)
 
 
-GELUS = {"fp32": gelu_q5_fp32, "f16": gelu_q5_f16, "f16/32": gelu_q5_mixed, "in16": lambda x: gelu_q5_fp32(h16(x))}
+# round 5: the packed-fp16 evaluation is limited by its own Horner roundings, so a SHORTER exponent polynomial costs next to nothing:
+# degree-3 / degree-4 minimax fits of the same form (tests/studies/gelu_q5_fit.py fit(3), fit(4)), evaluated in fp16 like "f16"
+Q3 = [-1.008443832397461, -1.113277792930603, -0.5132908821105957, -0.02108863927423954]
+Q4 = [-1.0013247728347778, -1.1435197591781616, -0.47347283363342285, -0.04111006110906601, 0.0033284714445471764]
+
+
+def gelu_pk_f16_deg(coef):
+    def g(x):
+        x = h16(x)
+        a = x.abs()
+        q = torch.full_like(a, float(np.float16(coef[-1])))
+        for k in range(len(coef) - 2, -1, -1):
+            q = fma16(q, a, float(np.float16(coef[k])))
+        e = h16(torch.exp2(q))
+        return fma16(-a, e, torch.clamp_min(x, 0))
+    return g
+
+
+GELUS = {"fp32": gelu_q5_fp32, "f16": gelu_q5_f16, "f16/32": gelu_q5_mixed, "in16": lambda x: gelu_q5_fp32(h16(x)),
+         "f16 d4": gelu_pk_f16_deg(Q4), "f16 d3": gelu_pk_f16_deg(Q3)}
 
 
 def block(w, p, x, spec, gelu, max_c):

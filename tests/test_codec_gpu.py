@@ -116,8 +116,15 @@ def test_alternative_paths_agree_with_the_default(tmp_path):
                      ("staged_mixer", {"SMTTS_MIXER_STREAM": "0"}), ("mixer_segments_of_122", {"SMTTS_MIXER_STREAM": "122"})):
         alt = _decode_in_subprocess(tmp_path, tag, env)
         assert np.array_equal(alt, base), tag
+    # round 5, the stage chain (all three blocks of the C = 32 stage per tile in one launch, halos carried in LDS, one warm-up tile per
+    # run of tiles): the same arithmetic per frame as one launch per block -> not a bit may change.  Latency tuning: runs of 5 tiles,
+    # utterance starts coincide with run starts; throughput tuning (192 workgroups): runs of 7 tiles, the second utterance starts in
+    # the MIDDLE of a run (7500 tiles per utterance); 100 workgroups: runs of 13
+    assert np.array_equal(_decode_in_subprocess(tmp_path, "no_chain", {"SMTTS_STAGE_CHAIN": "0"}), base), "stage chain"
     tp = _decode_in_subprocess(tmp_path, "tp", {}, "throughput")
     assert snr_db(tp, base) > 80.0     # throughput tuning is held to the latency-tuned decode, not only to its own variants
+    assert np.array_equal(_decode_in_subprocess(tmp_path, "tp_no_chain", {"SMTTS_STAGE_CHAIN": "0"}, "throughput"), tp), "stage chain (tp)"
+    assert np.array_equal(_decode_in_subprocess(tmp_path, "tp_chain_100", {"SMTTS_PERSIST_CUS": "100"}, "throughput"), tp), "stage chain, 100 workgroups"
     for tag, env in (("grid_all_cus", {"SMTTS_PERSIST_CUS": "0"}), ("grid_half", {"SMTTS_PERSIST_CUS": "128"}),
                      ("tp_shallow", {"SMTTS_GEMM_DEEP_TP": "0"})):
         alt = _decode_in_subprocess(tmp_path, tag, env, "throughput")
