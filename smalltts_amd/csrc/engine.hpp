@@ -258,7 +258,11 @@ class Engine {
     int x2_mink_ = 512, x2_maxk_ = 1024;   // PREC_F16X2 on SITE_CODEC_CONV: the ConvTranspose stages with K in this range (SMTTS_X2_MINK / _MAXK)
     int up_g3_mink_ = 2048;  // codec ConvTranspose-as-GEMM: gemm3 on a converted copy of the image from this K up (SMTTS_UP_G3_MINK; below: fp32-A kernel)
     int ksplit_enc_ = 4;  // split-K of the encoders' residual projections (1 = fused-epilogue GEMM + separate RMSNorm)
-    int ksplit_out_ = 3, ksplit_ff2_ = 3;  // (<= kSplitK; 150 tiles x 3 = 450 workgroups = one round at 2 per CU) split-K factors of the two N = 960 DiT projections (1 = fused epilogue)
+    int ksplit_out_ = 2, ksplit_ff2_ = 2;  // (<= kSplitK) split-K factors of the two N = 960 DiT projections in latency tuning (1 = fused epilogue).  Round 5
+                                           // (profiles/r05h_splitk_table.txt, three interleaved repeats on one box): 2 slices 11.75-11.79 ms per batch one at a
+                                           // time, 3 slices (rounds 1-4: 450 workgroups = one round at 2 per CU) 11.86-11.87, unsplit + ln_modulate 11.90-11.98 —
+                                           // a launch of these 600-row products is ~8 us of fixed cost whatever its k-loop (5 k-tiles at 3 slices), so the third
+                                           // slice only adds a partial slab (a third of the fp32 slab traffic of the reduce kernel)
     bool dual_stream_ = true;  // cond_encode: text encoder on a side stream (SMTTS_SINGLE_STREAM=1 turns it off)
     hipStream_t aux_ = nullptr;
     hipEvent_t ev_fork_ = nullptr, ev_join_ = nullptr;
