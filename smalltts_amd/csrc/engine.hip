@@ -473,8 +473,10 @@ int Engine::finalize_dit() {
     for (int i = 0; i < kBlocks; ++i) {
         std::string p = sidx(T, i, "");
         DitBlockW b;
-        b.qkvg = pack_rows({p + ".attn.to_q.weight", p + ".attn.to_k_self.weight", p + ".attn.to_v_self.weight",
-                            p + ".attn.gate.weight"});
+        b.name = p;
+        if (!(attn_img_ && attn_epi_))   // (the default path reads the head-padded pack only: ensure_qkvg_unpadded builds this one on demand)
+            b.qkvg = pack_rows({p + ".attn.to_q.weight", p + ".attn.to_k_self.weight", p + ".attn.to_v_self.weight",
+                                p + ".attn.gate.weight"});
         b.b_qkvg = concat_vec({p + ".attn.to_q.bias", p + ".attn.to_k_self.bias", p + ".attn.to_v_self.bias", ""},
                               {kHidden});
         b.qkvgp = pack_rows({p + ".attn.to_q.weight", p + ".attn.to_k_self.weight", p + ".attn.to_v_self.weight",
@@ -491,7 +493,7 @@ int Engine::finalize_dit() {
         b.ff2 = pack_rows({p + ".ff.w2.weight"}, nullptr, kFFp);
         b.b1 = rawp(p + ".ff.w1.bias"); b.b3 = rawp(p + ".ff.w3.bias"); b.b2 = rawp(p + ".ff.w2.bias");
         b.qn = rawp(p + ".attn.q_norm.weight"); b.kn = rawp(p + ".attn.k_norm.weight");
-        if (!b.qkvg.N || !b.qkvgp.N || !b.b_qkvg || !b.b_qkvgp || !b.out.N || !b.ff13.N || !b.ff2.N || !b.b1 || !b.b3 || !b.b2 || !b.qn || !b.kn)
+        if ((!(attn_img_ && attn_epi_) && !b.qkvg.N) || !b.qkvgp.N || !b.b_qkvg || !b.b_qkvgp || !b.out.N || !b.ff13.N || !b.ff2.N || !b.b1 || !b.b3 || !b.b2 || !b.qn || !b.kn)
             return fail("DiT block incomplete: " + p + " (" + err_ + ")");
         blocks_.push_back(b);
     }
@@ -1167,6 +1169,7 @@ int Engine::denoise_core(hipStream_t st, const float* x_t, const uint8_t* mask, 
     static const bool splitk_tp = getenv("SMTTS_SPLITK_TP") && atoi(getenv("SMTTS_SPLITK_TP")) != 0;   // (A/B only)
     const bool unsplit = M > 1024 || (tuning_ == TUNE_THROUGHPUT && !splitk_tp);
     const int ks_out = unsplit ? 1 : ksplit_out_, ks_ff2 = unsplit ? 1 : ksplit_ff2_;
+    if (!(attn_img_ && attn_epi_) && ensure_qkvg_unpadded()) return 1;
     for (int l = 0; l < kBlocks; ++l) {
         const DitBlockW& b = blocks_[l];
         const float* m = mod + (long)l * kModPerBlock;
@@ -1254,6 +1257,21 @@ int Engine::denoise_core(hipStream_t st, const float* x_t, const uint8_t* mask, 
     // velocity head (model.py:100) on the final AdaLN output
     HIPC(gemm3_store(ops3(w.y, rh, velocity_, M, pc), ACT_NONE, store_to(velocity, rowmap_plain(kLatent), rawp("velocity.bias")),
                      1, pc, st));
+    return 0;
+}
+
+// The unpadded QKVG pack of the DiT blocks, read by the A/B attention paths only: packed when one of them first runs (a test hook
+// can flip the path after finalize), from the fp32 tensors that stay resident.  Synchronises the device: never on the product path.
+int Engine::ensure_qkvg_unpadded() {
+    if (blocks_.empty() || blocks_[0].qkvg.N) return 0;
+    HIPC(hipDeviceSynchronize());
+    struct PackMode { bool& f; bool old; explicit PackMode(bool& b) : f(b), old(b) { f = true; } ~PackMode() { f = old; } } pm(packing_);
+    for (DitBlockW& b : blocks_) {
+        b.qkvg = pack_rows({b.name + ".attn.to_q.weight", b.name + ".attn.to_k_self.weight", b.name + ".attn.to_v_self.weight",
+                            b.name + ".attn.gate.weight"});
+        if (!b.qkvg.N) return fail("DiT block " + b.name + ": unpadded QKVG pack failed (" + err_ + ")");
+    }
+    HIPC(hipDeviceSynchronize());
     return 0;
 }
 

@@ -43,7 +43,10 @@ struct EncoderW {
     float* rope_sin;
 };
 struct DitBlockW {
-    PW qkvg, out, ff13, ff2;
+    std::string name;  // tensor-name prefix of the block ("dit.transformer_blocks.<i>")
+    PW qkvg;           // [to_q; to_k_self; to_v_self; gate] unpadded (3840 x 960): only the A/B paths read it (SMTTS_ATTN_IMG=0 / SMTTS_ATTN_EPI=0,
+                       // smtts_test_set_attention_mfma) — built on first use (Engine::ensure_qkvg_unpadded), N == 0 until then: 280 MB less resident
+    PW out, ff13, ff2;
     PW qkvgp;          // the same rows with every head padded 120 -> 128 (zero rows): [4 x 8 x 128][960], gemm3 EpiQKV's column layout
     float* b_qkvgp;    // bias in that layout (pad and gate entries zero)
     float* b_qkvg;
@@ -220,6 +223,7 @@ class Engine {
                      int N, int R, int P, float* velocity, char* ws, const CrossImg& ci);
     size_t denoise_core_bytes(int B, int N) const;
     // runs one block; the result lives in *x on return (the fused mixer ping-pongs *x <-> *xalt)
+    int ensure_qkvg_unpadded();   // packs DitBlockW::qkvg of every block on first use of an A/B attention path
     int codec_stage_chain(hipStream_t st, const CodecStageW& sg, float** x, float** xalt, int B, int T, int C);
     int codec_block(hipStream_t st, const CodecBlockW& w, float** x, float** xalt, float* nbuf, bf16_t* n2hi, bf16_t* n2lo,
                     bf16_t* hhi, bf16_t* hlo, int B, int T, int C, size_t n2_elems /* capacity of n2hi (bf16 elements) */);
