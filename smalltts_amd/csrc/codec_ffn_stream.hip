@@ -428,14 +428,23 @@ __global__ __launch_bounds__(NW * 64) void codec_ffn_stream_kernel(FfnStreamArgs
                         hpP[j] = __builtin_bit_cast(unsigned, __builtin_convertvector(v, half2_t));
                         axP[j] = hpP[j] & 0x7fff7fffu;
                         const half2_t ax = __builtin_bit_cast(half2_t, axP[j]);
+#if GELU_PK_DEG == 5
                         half2_t q = __builtin_elementwise_fma(h2_splat(GeluQ5::Q5), ax, h2_splat(GeluQ5::Q4));
                         q = __builtin_elementwise_fma(q, ax, h2_splat(GeluQ5::Q3));
+#else               // degree-3 exponent (common.hpp GeluQ3): the packed evaluation's own fp16 roundings, not the fit, set its error
+                        half2_t q = __builtin_elementwise_fma(h2_splat(GeluQ3::Q3), ax, h2_splat(GeluQ3::Q2));
+#endif
                         qP[j] = __builtin_bit_cast(unsigned, q);
                     } else if (ph == 1) {
                         const half2_t ax = __builtin_bit_cast(half2_t, axP[j]);
+#if GELU_PK_DEG == 5
                         half2_t q = __builtin_elementwise_fma(__builtin_bit_cast(half2_t, qP[j]), ax, h2_splat(GeluQ5::Q2));
                         q = __builtin_elementwise_fma(q, ax, h2_splat(GeluQ5::Q1));
                         q = __builtin_elementwise_fma(q, ax, h2_splat(GeluQ5::Q0));
+#else
+                        half2_t q = __builtin_elementwise_fma(__builtin_bit_cast(half2_t, qP[j]), ax, h2_splat(GeluQ3::Q1));
+                        q = __builtin_elementwise_fma(q, ax, h2_splat(GeluQ3::Q0));
+#endif
                         qP[j] = __builtin_bit_cast(unsigned, q);
                     } else if (ph == 2) {
                         qP[j] = exp2_pk_f16(qP[j]);
