@@ -19,6 +19,12 @@ def prof_name(kernel: str):
     m = re.match(r"gemm_kernel<(\d+), (\d+), (\d+), \d+, \d+, (\d), (Epi\w+(?:<\d>)?) ?>", k)
     if m:
         return f"gemm<{m.group(1)}x{m.group(2)}x{m.group(3)},s{m.group(4)},{_EPI3.get(m.group(5), m.group(5))}>"
+    m = re.match(r"codec_chain_wave_kernel<(\d+),", k)
+    if m:
+        return f"codec_chain_wave<{m.group(1)}>"
+    m = re.match(r"codec_ffn_wave_kernel<(\d+), \d+, \d+, (true|false)", k)
+    if m:   # MIX = true is the one-pass block (mixer + FFN), profiled as codec_block_wave
+        return f"codec_{'block' if m.group(2) == 'true' else 'ffn'}_wave<{m.group(1)}>"
     m = re.match(r"codec_ffn_(stream|wave)_kernel<(\d+),", k)
     if m:
         return f"codec_ffn_{m.group(1)}<{m.group(2)}>"
@@ -38,5 +44,7 @@ def prof_name(kernel: str):
         return "splitk_resid_rms" if "Lb1E" in k or ", true>" in k else "splitk_resid_ln"
     m = re.match(r"([a-z0-9_]+)_kernel\b", k)
     if m:
-        return m.group(1)
+        # the profiler's class names where they differ from the kernel's: the streaming mixer runs under launch_mixer_fused's scope,
+        # the 32-channel head conv under head_conv
+        return {"mixer_stream": "mixer_fused", "head_conv32": "head_conv"}.get(m.group(1), m.group(1))
     return None
