@@ -303,3 +303,31 @@ def test_optional_codec_tensor_switched_off_by_the_spec_is_an_error_not_a_silent
     assert 0 < len(_validated(kept, "t", off)) == len(kept) < len(tensors)
     extra = dict(kept, **{"optimizer.state.step": np.zeros(1, np.float32)})      # unrelated keys are still just ignored
     assert len(_validated(extra, "t", off)) == len(kept)
+
+
+def test_bench_codec_bytes_follow_the_spec_and_profiler_names_map_back():
+    """SURVEY 8(d) bytes of the codec decode are derived from the CodecSpec in code (2 x stage-boundary images + weights at 2 B), and
+    the rocprofv3 kernel names of the kernels bench.py may crown as `roofline.kernel` map back to the in-process profiler's class
+    names — otherwise the stamped averages / traffic under profiles/ could not be quoted for them."""
+    import importlib, sys, os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root); sys.path.insert(0, os.path.join(root, "tools"))
+    bench = importlib.import_module("bench")
+    from smalltts_amd.weights import DEFAULT_CODEC, CodecSpec
+    b = bench.codec_decode_algo_bytes()
+    imgs = sum(8 * 75 * int(np.prod(DEFAULT_CODEC.ratios[:i])) * (32 << (6 - i)) * 4 for i in range(7)) + 8 * 240000 * 4
+    assert 2.55e9 < b < 2.59e9 and b > 2 * imgs and (b - 2 * imgs) % 2 == 0           # the rest = weights at 2 B / parameter
+    small = bench.codec_decode_algo_bytes(CodecSpec(n_filters=8, dec_depths=(1,) * 7), batch=1, frames=2)
+    assert 0 < small < b / 100
+    from prof_names import prof_name
+    for k, want in {
+        "void gemm3_kernel<64, 64, 2, 2, 2, 4, EpiResid<1> >(Gemm3Operands, EpiResid<1>)": "gemm3<64x64,s2,resid_gate>",
+        "void gemm4_kernel<2, EpiStore<2> >(Gemm3Operands, EpiStore<2>)": "gemm4<256x256,s2,store_gelu>",
+        "void codec_chain_wave_kernel<32, 2, 12, 3>(FfnChainArgs)": "codec_chain_wave<32>",
+        "void codec_ffn_wave_kernel<64, 2, 8, true>(FfnWaveArgs)": "codec_block_wave<64>",
+        "void codec_ffn_wave_kernel<32, 2, 8, false>(FfnWaveArgs)": "codec_ffn_wave<32>",
+        "void codec_ffn_stream_kernel<128, 2, 8, 4>(FfnStreamArgs)": "codec_ffn_stream<128>",
+        "void mixer_stream_kernel<128>(MixerArgs)": "mixer_fused",
+        "void (anonymous namespace)::attention_img_kernel<128, 2>(AttnImg, int)": "attention_img<128>",
+    }.items():
+        assert prof_name(k) == want, (k, prof_name(k))
