@@ -34,12 +34,12 @@ HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8 TB/s spec
 MFMA_BF16_PEAK_TF = 2500.0   # dense bf16
 
 
-def make_inputs(device, rank):
+def make_inputs(device, rank, r_frames=R_FRAMES, p_tok=P_TOK):
     g = torch.Generator().manual_seed(1000 + rank)
-    ref = torch.randn(B, R_FRAMES, 64, generator=g)
-    ids = torch.arange(1, P_TOK + 1)[None].repeat(B, 1)
-    d = dict(ref=ref, ref_len=torch.full((B,), R_FRAMES, dtype=torch.int64), ids=ids,
-             ph_mask=torch.ones(B, P_TOK, dtype=torch.bool), mask=torch.ones(B, N_FRAMES, dtype=torch.bool))
+    ref = torch.randn(B, r_frames, 64, generator=g)
+    ids = (torch.arange(p_tok) % 197 + 1)[None].repeat(B, 1)                     # bench.rs:6: tokens 1..P (wrapped into the 198-symbol table)
+    d = dict(ref=ref, ref_len=torch.full((B,), r_frames, dtype=torch.int64), ids=ids,
+             ph_mask=torch.ones(B, p_tok, dtype=torch.bool), mask=torch.ones(B, N_FRAMES, dtype=torch.bool))
     t = torch.arange(48000, dtype=torch.float32) / 24000.0                       # bench.rs:8-13: 2 s, 440 Hz unit sine
     d["ref_wav"] = torch.sin(2 * np.pi * 440.0 * t)[None, None].repeat(B, 1, 1)
     d["ref3"] = torch.cat([ref, ref, torch.zeros_like(ref)], 0)                   # CFG rows (distill.py:76-99)
@@ -402,6 +402,9 @@ def main():
                     help="engine tuning of the timed region: auto = throughput with batches in flight, latency with one at a time; "
                          "forcing it lets tools/profile_round.sh trace the throughput-tuned kernels one batch at a time")
     ap.add_argument("--no-sequential", action="store_true", help="skip the one-batch-at-a-time leg (value_sequential)")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="skip the `secondary` block (the other single-GPU configurations timed behind the headline in the same run: "
+                         "clone = BASELINE configs[2], teacher128 = configs[4], dmd4 at R = 38 / P = 128 = SURVEY 8(d)'s secondary point)")
     args = ap.parse_args()
     ensure_world(args.gpus, sys.argv[1:])
 
@@ -414,25 +417,29 @@ def main():
 
     from smalltts_amd.engine import HipEngine
     eng = HipEngine(ctx.device_index, args.precision)
-    eng.load_synthetic(SEED, parts=("dit", "decoder", "encoder") if args.workload == "clone" else ("dit", "decoder"))
+    secondary = not args.no_secondary and args.workload == "dmd4" and n_gpus == 1
+    eng.load_synthetic(SEED, parts=("dit", "decoder", "encoder") if args.workload == "clone" or secondary else ("dit", "decoder"))
     eng.finalize()
-    inp = make_inputs(device, rank)
+    # (tests: a world-1 run can stand in for rank r of a larger job — same inputs as that rank's shard)
+    inp = make_inputs(device, int(os.environ.get("SMTTS_BENCH_RANK_SEED", rank)))
     pcm16 = args.gather == "pcm16"
     gdtype = torch.int16 if pcm16 else torch.float32
     samples = 3200 * N_FRAMES
     barrier = ctx.barrier
 
-    def run_steps(n, seed0, in_flight, tuning=None):
+    def run_steps(n, seed0, in_flight, tuning=None, workload=None, inp_=None):
         """n full passes of the hot path, each over its own batch of 8.  With in_flight > 1 consecutive batches are issued
         round-robin to that many HIP streams (one workspace each): the latency-bound phases of one batch (condition
         encoders, DiT: grids of 30-190 workgroups on 256 CUs) fill the CUs another batch's kernels leave idle.  Every batch
         still goes through the whole path inside the timed region; nothing is shared between batches but the weights."""
+        workload = workload or args.workload
+        inp_ = inp if inp_ is None else inp_
         if in_flight <= 1:
             out = None
             prev = eng.set_tuning(tuning) if tuning else None
             try:
                 for i in range(n):
-                    out = one_step(eng, inp, seed0 + i, ctx, gathers[0] if gathers else None, args.workload, pcm16)
+                    out = one_step(eng, inp_, seed0 + i, ctx, gathers[0] if gathers else None, workload, pcm16)
             finally:
                 if tuning:
                     eng.set_tuning(prev)
@@ -446,7 +453,7 @@ def main():
             for i in range(n):
                 with torch.cuda.stream(streams[i % in_flight]):
                     eng.use_workspace(f"batch{i % in_flight}")
-                    out = one_step(eng, inp, seed0 + i, ctx, gathers[i % in_flight] if gathers else None, args.workload, pcm16)
+                    out = one_step(eng, inp_, seed0 + i, ctx, gathers[i % in_flight] if gathers else None, workload, pcm16)
         finally:
             eng.use_workspace(None)
             eng.set_tuning(prev)
@@ -485,6 +492,41 @@ def main():
         dt_seq = ctx.max_over_ranks(time.perf_counter() - t1)
     assert torch.isfinite(out.float()).all()
 
+    # ---- the other single-GPU configurations, timed in the same run behind the headline ----------------
+    # Same protocol per leg: warm-up, then K steps between barrier + device sync, in flight (throughput tuning) and one batch at a
+    # time (latency tuning).  K is small (the whole block takes a few seconds): these are driver-clocked points, not the headline.
+    sec = None
+    if secondary:
+        sec = {}
+        legs = [("clone", "clone", inp, max(3, min(args.steps, 12))),
+                ("dmd4_R38_P128", "dmd4", make_inputs(device, rank, 38, 128), max(3, min(args.steps, 12))),
+                ("teacher128", "teacher128", inp, 3)]
+        for name, wl, inp2, k in legs:
+            torch.cuda.synchronize()
+            eng.release_workspaces()          # shapes differ per leg: fresh per-slot scratch, nothing in flight while it is swapped
+            run_steps(min(in_flight, k) if in_flight > 1 else 1, 7000, in_flight, timed_tuning, wl, inp2)
+            barrier()
+            t2 = time.perf_counter()
+            o2 = run_steps(k, 7100, in_flight, timed_tuning, wl, inp2)
+            barrier()
+            d_if = ctx.max_over_ranks(time.perf_counter() - t2)
+            ks = 2 if wl == "teacher128" else k
+            run_steps(1, 7200, 1, "latency", wl, inp2)
+            barrier()
+            t2 = time.perf_counter()
+            o2 = run_steps(ks, 7300, 1, "latency", wl, inp2)
+            barrier()
+            d_sq = ctx.max_over_ranks(time.perf_counter() - t2)
+            assert torch.isfinite(o2.float()).all()
+            a_s = B * AUDIO_SEC_PER_UTT
+            r_, p_ = (38, 128) if name == "dmd4_R38_P128" else (R_FRAMES, P_TOK)
+            sec[name] = {"workload": WORKLOADS[wl] + f", B=8 x 10 s (N=75, R={r_}, P={p_})", "steps": k, "steps_sequential": ks,
+                         "batches_in_flight": in_flight, "ms_per_step": round(1e3 * d_if / k, 3), "value": round(a_s * k / d_if, 2),
+                         "rtf": round(d_if / (a_s * k), 7), "sequential_ms_per_step": round(1e3 * d_sq / ks, 3),
+                         "value_sequential": round(a_s * ks / d_sq, 2), "unit": "audio-seconds/sec"}
+        torch.cuda.synchronize()
+        eng.release_workspaces()
+
     audio_s = n_gpus * B * AUDIO_SEC_PER_UTT * args.steps
     audio_s_seq = n_gpus * B * AUDIO_SEC_PER_UTT * ns
     res = {
@@ -517,6 +559,14 @@ def main():
                    "precision_demoted_sites": eng.precision_in_force()["demoted"]},
     }
 
+    if sec is not None:
+        res["secondary"] = sec
+    if os.environ.get("SMTTS_BENCH_DUMP_ROWS") == "1":
+        # tests: one checksum per utterance of the last timed step's (gathered) batch — int64 sum of the fp32 bit patterns — so
+        # that a world-N line can be compared row block by row block with world-1 runs (tests/test_bench_gpu.py)
+        o_ = out.reshape(out.shape[0], -1)
+        bits = o_.view(torch.int16 if o_.dtype == torch.int16 else torch.int32).to(torch.int64)
+        res["row_checksums"] = [int(v) for v in bits.sum(dim=1).cpu()]
     if rank == 0 and not args.no_roofline:
         ALGO["codec_decode"]["bytes"] = float(codec_decode_algo_bytes())
         # The roofline block describes the configuration that was TIMED: its per-kernel passes run under the timed region's

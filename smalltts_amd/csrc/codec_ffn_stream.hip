@@ -431,7 +431,10 @@ __global__ __launch_bounds__(NW * 64) void codec_ffn_stream_kernel(FfnStreamArgs
 #if GELU_PK_DEG == 5
                         half2_t q = __builtin_elementwise_fma(h2_splat(GeluQ5::Q5), ax, h2_splat(GeluQ5::Q4));
                         q = __builtin_elementwise_fma(q, ax, h2_splat(GeluQ5::Q3));
-#else               // degree-3 exponent (common.hpp GeluQ3): the packed evaluation's own fp16 roundings, not the fit, set its error
+#elif GELU_PK_DEG == 4  // the default (common.hpp: degree-5 accuracy in the packed evaluation, one instruction fewer)
+                        half2_t q = __builtin_elementwise_fma(h2_splat(GeluQ4::Q4), ax, h2_splat(GeluQ4::Q3));
+                        q = __builtin_elementwise_fma(q, ax, h2_splat(GeluQ4::Q2));
+#else
                         half2_t q = __builtin_elementwise_fma(h2_splat(GeluQ3::Q3), ax, h2_splat(GeluQ3::Q2));
 #endif
                         qP[j] = __builtin_bit_cast(unsigned, q);
@@ -441,6 +444,9 @@ __global__ __launch_bounds__(NW * 64) void codec_ffn_stream_kernel(FfnStreamArgs
                         half2_t q = __builtin_elementwise_fma(__builtin_bit_cast(half2_t, qP[j]), ax, h2_splat(GeluQ5::Q2));
                         q = __builtin_elementwise_fma(q, ax, h2_splat(GeluQ5::Q1));
                         q = __builtin_elementwise_fma(q, ax, h2_splat(GeluQ5::Q0));
+#elif GELU_PK_DEG == 4
+                        half2_t q = __builtin_elementwise_fma(__builtin_bit_cast(half2_t, qP[j]), ax, h2_splat(GeluQ4::Q1));
+                        q = __builtin_elementwise_fma(q, ax, h2_splat(GeluQ4::Q0));
 #else
                         half2_t q = __builtin_elementwise_fma(__builtin_bit_cast(half2_t, qP[j]), ax, h2_splat(GeluQ3::Q1));
                         q = __builtin_elementwise_fma(q, ax, h2_splat(GeluQ3::Q0));

@@ -61,6 +61,16 @@ def test_bench_single_gpu_line_has_the_contract_fields_and_rooflines():
     cb = r["cpu_baseline"]
     assert cb["kind"] == "port" and cb["value"] > 0 and cb["cores"] >= 1 and cb["cores_available"] >= cb["cores"] and cb["sample"]
     assert str(cb["cores"]) in cb["thread_probe_ms"]          # the thread count was chosen by the bounded probe
+    # the other single-GPU configurations are clocked in the same run (BASELINE configs[2], configs[4], SURVEY 8(d) secondary point)
+    sec = r["secondary"]
+    assert set(sec) == {"clone", "teacher128", "dmd4_R38_P128"}
+    for name, leg in sec.items():
+        assert leg["ms_per_step"] > 0 and leg["sequential_ms_per_step"] > 0 and leg["unit"] == "audio-seconds/sec"
+        assert abs(leg["value"] - 80.0 / (leg["ms_per_step"] * 1e-3)) / leg["value"] < 1e-3
+        assert abs(leg["value_sequential"] - 80.0 / (leg["sequential_ms_per_step"] * 1e-3)) / leg["value_sequential"] < 1e-3
+    assert sec["clone"]["ms_per_step"] > r["ms_per_step_min"] * 0.98          # + the codec encode of 8 x 2 s
+    assert sec["teacher128"]["sequential_ms_per_step"] > 10 * r["sequential_ms_per_step"]   # 128 steps x 3B rows against 4 x B
+    assert "R=38, P=128" in sec["dmd4_R38_P128"]["workload"]
 
 
 @pytest.mark.parametrize("gather", ["f32", "pcm16"])
@@ -75,6 +85,38 @@ def test_bench_two_ranks_over_gloo_on_one_gpu(gather):
     assert abs(r["value"] - 160.0 / (r["ms_per_step"] * 1e-3)) / r["value"] < 1e-3       # both ranks' 8 x 10 s count
     assert "gloo" in r["config"]["parallelism"] and gather in r["config"]["parallelism"]
     assert "cpu_baseline" not in r                                                       # rank 0 at N = 1 only
+
+
+def test_bench_eight_ranks_share_the_gpu_over_gloo_with_the_real_engine():
+    """Config 4 first light (BASELINE configs[3]: 64 utterances over 8 ranks) as far as a 1-GPU box allows: `bench.py --gpus 8`
+    outside a launcher re-executes under the driver's launcher line, eight ranks with the REAL engine share the box's GPU
+    (8 x ~6.4 GB of weights + workspaces), the collective is gloo.  The line must say n_gpus 8 / global_batch 64, and the gathered
+    waveform must hold the ranks' shards in global order: every rank draws its sampler noise from Philox(seed = step seed), its
+    inputs from seed 1000 + rank, so row block r of the gathered batch equals what a world-1 run with rank r's inputs produces."""
+    env = dict(os.environ, SMTTS_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0", SMTTS_BENCH_DUMP_ROWS="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    common = ["--steps", "2", "--warmup", "1", "--no-roofline", "--no-cpu-baseline", "--min-seconds", "0", "--no-sequential",
+              "--in-flight", "1", "--no-secondary"]
+    p = subprocess.run([sys.executable, "bench.py", "--gpus", "8"] + common, capture_output=True, text=True, timeout=2400, cwd=ROOT,
+                       env=env)
+    assert p.returncode == 0, p.stderr[-3000:]
+    assert "re-executing" in p.stderr
+    r = _last_json(p.stdout)
+    assert r["n_gpus"] == 8 and r["dist"] == {"backend": "gloo", "collective": True, "world": 8}
+    assert r["config"]["global_batch"] == 64 and r["scaling"] == "weak" and "dp8" in r["config"]["parallelism"]
+    assert abs(r["value"] - 640.0 / (r["ms_per_step"] * 1e-3)) / r["value"] < 1e-3       # all eight ranks' 8 x 10 s count
+    rows8 = r["row_checksums"]                                # one checksum per utterance of the LAST step's gathered batch
+    assert len(rows8) == 64
+    # world-1 runs standing in for rank 0, 3 and 7: same per-rank input seed, same step seeds -> the same 8 rows, bit for bit
+    for rank in (0, 3, 7):
+        env1 = dict(env, SMTTS_BENCH_RANK_SEED=str(rank))
+        p1 = subprocess.run([sys.executable, "bench.py", "--gpus", "1"] + common, capture_output=True, text=True, timeout=900,
+                            cwd=ROOT, env=env1)
+        assert p1.returncode == 0, p1.stderr[-3000:]
+        r1 = _last_json(p1.stdout)
+        assert r1["n_gpus"] == 1 and len(r1["row_checksums"]) == 8
+        assert r1["row_checksums"] == rows8[8 * rank: 8 * rank + 8], rank
 
 
 def test_bench_gpus_2_without_a_launcher_relaunches_itself_as_two_ranks():

@@ -286,6 +286,32 @@ def test_gelu_q5_constants_in_the_kernel_header_meet_their_error_bound():
     assert fp32_error(c) < 2.2e-6
 
 
+def test_packed_fp16_gelu_of_the_default_degree_is_relatively_accurate_at_small_activations():
+    """the packed-fp16 GELU of the fused codec FFN kernels (csrc/common.hpp gelu_q5_pk_*) must be accurate RELATIVE to the
+    value for small activations too — a fit whose 2^Q0 is not ~0.5 biases every small hidden value by a fixed fraction (degree 3:
+    +0.29 %).  The constants of the degree the header selects are parsed from it and evaluated with every step rounded to fp16, as
+    the device's v_pk_fma_f16 chain does (tests/studies/gelu_f16_packed.py)."""
+    import os
+    import re
+    import torch
+    from tests.studies.gelu_f16_packed import gelu_pk_f16_deg
+    src = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "smalltts_amd", "csrc", "common.hpp")).read()
+    deg = int(re.search(r"#ifndef GELU_PK_DEG\n#define GELU_PK_DEG (\d)", src).group(1))
+    body = re.search(r"struct GeluQ%d \{(.*?)\};" % deg, src, re.S).group(1)
+    c = [float(v) for v in re.findall(r"Q\d = (-?[0-9.e-]+)f", body)]
+    assert len(c) == deg + 1 and abs(2.0 ** c[0] - 0.5) < 5e-4          # gelu(x) -> x / 2 at small |x|: no fixed-fraction bias
+    g = gelu_pk_f16_deg(c)
+    x = torch.linspace(-12, 12, 400001)
+    exact = 0.5 * x.double() * (1 + torch.erf(x.double() / np.sqrt(2)))
+    err = (g(x).double() - exact).abs()
+    small = (x.abs() < 0.25) & (x.abs() > 1e-3)
+    assert float((err[small] / exact[small].abs()).max()) < 2.5e-3       # degree 3 reads 7.2e-3 here, degree 5 1.3e-3
+    assert float((err / exact.abs().clamp_min(1e-3)).max()) < 1.2e-2      # degree 3: 2.3e-2
+    xn = torch.randn(1000000, generator=torch.Generator().manual_seed(0)) * 1.5
+    en = 0.5 * xn.double() * (1 + torch.erf(xn.double() / np.sqrt(2)))
+    assert float(((g(xn).double() - en) ** 2).mean().sqrt()) < 3.2e-4    # the fp16 Horner steps' own floor is 3.1e-4
+
+
 def test_optional_codec_tensor_switched_off_by_the_spec_is_an_error_not_a_silent_drop():
     """_validated() filters a source down to the inventory of the CodecSpec in force; a final-norm weight or a bias
     that the spec says is absent would have vanished without a word although the engine applies such tensors when present."""
