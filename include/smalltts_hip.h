@@ -174,6 +174,10 @@ int smtts_test_gemm3(smtts_handle h, void* stream, const float* A, const float* 
                      int act, int split, int cfg, float* C);
 /* codec blocks: 1 (default) = fused mixer and fused FFN kernels (C <= 256), 0 = separate norm / conv / two-GEMM path */
 int smtts_test_set_fused_ffn(smtts_handle h, int on);
+/* fused sampler: 1 (default) = the AdaLN between two DiT block GEMMs folded into their epilogues (reference dit.py:19-25,197-212
+ * restated as rstd (x (1 + scale) W^T - mu W (1 + scale)) + W shift + b), 0 = split-K reduce + norm (latency) / ln_modulate (throughput) launches.
+ * Workspace sizes depend on it: query them after the call. */
+int smtts_test_set_ln_fold(smtts_handle h, int on);
 int smtts_test_gemm(smtts_handle h, void* stream, const float* A, int lda, const float* W, const float* bias, int M,
                     int N, int K, int act, int split, int cfg, float* C, int ldc);
 int smtts_test_swiglu(smtts_handle h, void* stream, const float* A, const float* W1, const float* W3, const float* b1,

@@ -62,6 +62,7 @@ SIGNATURES: Dict[str, Tuple[object, List[object]]] = {
     "smtts_bench_gemm": (i32, [vp, i32, i32, i32, i32, i32, i32, i32, i32, C.POINTER(f32)]),
     "smtts_test_gemm3": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
     "smtts_test_set_fused_ffn": (i32, [vp, i32]),
+    "smtts_test_set_ln_fold": (i32, [vp, i32]),
     "smtts_test_gemm": (i32, [vp, vp, vp, i32, vp, vp, i32, i32, i32, i32, i32, i32, vp, i32]),
     "smtts_test_swiglu": (i32, [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]),
     "smtts_test_set_attention_mfma": (i32, [vp, i32]),

@@ -167,6 +167,7 @@ int smtts_test_gemm3(smtts_handle h, void* stream, const float* A, const float* 
     return E.test_gemm3(ST(stream), A, W, bias, M, N, K, act, split, cfg, C);
 }
 int smtts_test_set_fused_ffn(smtts_handle h, int on) { NULLCHK; E.set_fused_ffn(on != 0); return 0; }
+int smtts_test_set_ln_fold(smtts_handle h, int on) { NULLCHK; E.set_ln_fold(on != 0); return 0; }
 int smtts_test_set_attention_mfma(smtts_handle h, int mode) { NULLCHK;   // 0: fp32 projection + qk_prep + the fp32 VALU reference kernel; else (default): producer-written operand images + the DMA / MFMA kernel
     E.set_attn_img(mode != 0);
     return 0;

@@ -67,6 +67,7 @@ Engine::Engine(int device) : device_(device) {
     if ((s = getenv("SMTTS_CONVPOS_BY_GROUP"))) convpos_by_group_ = atoi(s) != 0;
     if ((s = getenv("SMTTS_ATTN_EPI"))) attn_epi_ = atoi(s) != 0;
     if ((s = getenv("SMTTS_ATTN_IMG"))) attn_img_ = atoi(s) != 0;
+    if ((s = getenv("SMTTS_LN_FOLD"))) ln_fold_ = atoi(s) != 0;
     if ((s = getenv("SMTTS_UP_G3_MINK")) && atoi(s) >= 64) up_g3_mink_ = atoi(s);
     if ((s = getenv("SMTTS_MIXER_WIDE"))) mixer_wide_ = atoi(s) != 0;
     if ((s = getenv("SMTTS_X2_MINK")) && atoi(s) >= 64) x2_mink_ = atoi(s);
@@ -1023,7 +1024,7 @@ int Engine::cond_encode(hipStream_t st, const float* ref, const int64_t* ref_len
 // instead of per output element in the residual epilogues)
 // ---------------------------------------------------------------------------------------------
 int Engine::modulation(hipStream_t st, const float* t_dev, int rows, float* sinb, float* t1, float* temb, float* e1,
-                       float* semb, float* mod) {
+                       float* semb, float* mod, float* ftab) {
     ProfTag ptag("mod");
     const int pc = prec_[SITE_COND];  // tiny-M chain on the fp32-A kernel: always split-bf16 unless the preset is plain bf16
     HIPC(launch_time_sinusoid(t_dev, sinb, rows, st));
@@ -1039,13 +1040,36 @@ int Engine::modulation(hipStream_t st, const float* t_dev, int rows, float* sinb
     HIPC(gemm_store(ops(semb, rowmap_plain(kHidden), modall_, rows), ACT_NONE,
                     store_to(mod, rowmap_plain(kModLd), modall_b_), 1, pc, st));
     HIPC(launch_tanh_gates(mod, rows, kModLd, kBlocks, kModPerBlock, kHidden, st));
+    if (ftab) {   // LN-fold tables of every (step, block, site): W shift and W (1 + scale) on the weights the block GEMMs multiply
+        const int pb = prec_[SITE_DIT_BLOCK];
+        FoldSites fs{};
+        fs.n = 0;
+        fs.NF = kFoldNF;
+        for (int l = 0; l < kBlocks; ++l) {
+            const DitBlockW& b = blocks_[l];
+            for (int site = 0; site < 2; ++site) {
+                const PW& w = site ? b.ff13 : b.qkvgp;
+                if (w.K != kHidden || w.N != (site ? 2 * kFF : 4 * kHeads * 128)) return fail("LN-fold: unexpected weight pack shape");
+                FoldSite& f = fs.s[fs.n++];
+                f.w = pb == PREC_F16 ? w.h16 : w.hi;
+                f.wlo = pb == PREC_BF16X3 ? w.lo : nullptr;
+                f.fmt = pb == PREC_F16 ? 0 : 1;
+                f.N = w.N;
+                f.shift_off = l * kModPerBlock + (site ? 3 : 0) * kHidden;
+                f.scale_off = l * kModPerBlock + (site ? 4 : 1) * kHidden;
+                f.out_off = l * kFoldPerBlock + (site ? 4L * kHeads * 128 : 0);
+            }
+        }
+        HIPC(launch_fold_vectors(fs, mod, kModLd, rows, ftab, st));
+    }
     return 0;
 }
 
 namespace {
 struct ModWs {
-    float *sinb, *t1, *temb, *e1, *semb, *mod;
-    void plan(Bump& b, int rows) {
+    float *sinb, *t1, *temb, *e1, *semb, *mod, *ftab = nullptr;
+    void plan(Bump& b, int rows, bool fold = false) {
+        if (fold) ftab = b.take<float>((size_t)rows * 2 * kFoldNF);
         sinb = b.take<float>((size_t)rows * 256);
         t1 = b.take<float>((size_t)rows * kHidden);
         temb = b.take<float>((size_t)rows * kHidden);
@@ -1055,7 +1079,7 @@ struct ModWs {
     }
 };
 struct CoreWs {
-    float *h, *x, *qkvg, *part;
+    float *h, *x, *qkvg, *part, *lnpart;
     float *rope_c, *rope_s;  // cos / sin of a caller-supplied angle table: per call (several calls may be in flight on different streams)
     SplitBuf gm1, gm2, y, o, ffh;
     SplitBuf qi, ki, vti, gi;   // attention operand images of the self part: [B][8][N][128] x 2, [B][8][128][pad8(N)], [M][960]
@@ -1072,6 +1096,7 @@ struct CoreWs {
         x = b.take<float>(M * kHidden);
         qkvg = b.take<float>(M * 4 * kHidden);
         part = b.take<float>(M * kHidden * kSplitK);
+        lnpart = b.take<float>(M * kLnGroups * 2);
         rope_c = b.take<float>((size_t)N * 64);
         rope_s = b.take<float>((size_t)N * 64);
         gm1 = take_split(b, gm_elems);
@@ -1096,7 +1121,7 @@ size_t Engine::denoise_core_bytes(int B, int N) const {
 int Engine::denoise_core(hipStream_t st, const float* x_t, const uint8_t* mask, const float* mod, int mod_row0,
                          int mod_rstride, const float* k_ref, const float* v_ref, const uint8_t* ref_mask,
                          const float* k_text, const float* v_text, const uint8_t* ph_mask, const float* rope, int B,
-                         int N, int R, int P, float* velocity, char* wsp, const CrossImg& ci) {
+                         int N, int R, int P, float* velocity, char* wsp, const CrossImg& ci, const float* ftab) {
     ProfTag ptag("dit");
     Bump bump(wsp);
     CoreWs w;
@@ -1170,6 +1195,20 @@ int Engine::denoise_core(hipStream_t st, const float* x_t, const uint8_t* mask, 
     const bool unsplit = M > 1024 || (tuning_ == TUNE_THROUGHPUT && !splitk_tp);
     const int ks_out = unsplit ? 1 : ksplit_out_, ks_ff2 = unsplit ? 1 : ksplit_ff2_;
     if (!(attn_img_ && attn_epi_) && ensure_qkvg_unpadded()) return 1;
+    // LN-fold (gemm.hpp LnFoldIn): inside the fused sampler — one modulation row for the whole batch, tables from modulation() —
+    // the AdaLN between two block GEMMs lives in their epilogues; the first AdaLN of a step (above) and the final one (velocity
+    // head, SITE_COND precision) keep their ln_modulate
+    const bool fold = ln_fold_ && ftab && mod_rstride == 0 && attn_img_ && attn_epi_;
+    const float* const mrow = mod + (long)mod_row0 * kModLd;            // this step's modulation row (fold path only)
+    const float* const frow = fold ? ftab + (long)mod_row0 * 2 * kFoldNF : nullptr;   // [0]: W shift, [1]: W (1 + scale)
+    auto fold_in = [&](int l, int site) {
+        LnFoldIn f;
+        f.part = w.lnpart; f.NP = kLnGroups; f.inv_c = 1.0f / kHidden; f.eps = 1e-6f;
+        const long off = (long)l * kFoldPerBlock + (site ? 4L * kHeads * 128 : 0);
+        f.wsh = frow + off;
+        f.wc = frow + kFoldNF + off;
+        return f;
+    };
     for (int l = 0; l < kBlocks; ++l) {
         const DitBlockW& b = blocks_[l];
         const float* m = mod + (long)l * kModPerBlock;
@@ -1204,6 +1243,7 @@ int Engine::denoise_core(hipStream_t st, const float* x_t, const uint8_t* mask, 
             if (epi) {
                 EpiQKV eq{b.b_qkvgp, pk.qw, pk.kw, pk.rope_cos, pk.rope_sin, pk.eps, pk.q_scale, pk.rot_dim, pa,
                           pk.q, pk.q_lo, pk.k, pk.k_lo, pk.vt, pk.vt_lo, pk.g, pk.g_lo, N, kHeads, kDh, 128, Np};
+                if (fold && l > 0) eq.fold = fold_in(l, 0);   // w.y = x (1 + scale_msa), written by the previous block's FF2 epilogue
                 HIPC(gemm3_qkv(ops3(w.y, rh, b.qkvgp, M, pb), eq, pb, st));
             } else {
                 HIPC(launch_qkv_pack(pk, st));
@@ -1229,7 +1269,11 @@ int Engine::denoise_core(hipStream_t st, const float* x_t, const uint8_t* mask, 
         // to_out + mask + gated residual (dit.py:117-118,198), then the MLP AdaLN (dit.py:199)
         EpiResid<0> r1{w.x, rh, nullptr, m + 2 * kHidden, kModLd, mod_row0, mod_rstride, N, mask};
         NextLN ln1{m + 3 * kHidden, m + 4 * kHidden, yb.hi, yb.lo};
-        if (ks_out > 1) {
+        const float* const mr = mrow + (long)l * kModPerBlock;
+        if (fold) {
+            EpiResidLN e1{w.x, rh, nullptr, mr + 2 * kHidden, mask, mr + 4 * kHidden, yb.hi, yb.lo, kHidden, w.lnpart, kLnGroups};
+            HIPC(gemm3_resid_ln(ops3(w.o, rh, b.out, M, pb), e1, pb, st));
+        } else if (ks_out > 1) {
             HIPC(gemm3_resid_splitk(ops3(w.o, rh, b.out, M, pb), r1, w.part, ks_out, pb, st, ln1));
         } else {
             HIPC(gemm3_resid(ops3(w.o, rh, b.out, M, pb), 1, r1, pb, st));
@@ -1238,6 +1282,7 @@ int Engine::denoise_core(hipStream_t st, const float* x_t, const uint8_t* mask, 
         }
         // D7 feed-forward (dit.py:199-201)
         EpiSwiGLU sw{nullptr, kFFp, b.b1, b.b3, ffh.hi, ffh.lo};
+        if (fold) sw.fold = fold_in(l, 1);
         HIPC(gemm3_swiglu(ops3(w.y, rh, b.ff13, M, pb), sw, pb, st));
         // w2 + gated residual, then the next block's attention AdaLN — or D8's final AdaLN (chunk order scale, shift:
         // dit.py:37) after the last block
@@ -1246,7 +1291,10 @@ int Engine::denoise_core(hipStream_t st, const float* x_t, const uint8_t* mask, 
         const SplitBuf yv = w.y.as(pc, satp(SITE_COND));  // the final AdaLN feeds the velocity head (SITE_COND)
         NextLN ln2 = l + 1 < kBlocks ? NextLN{mn + 0 * kHidden, mn + 1 * kHidden, yb.hi, yb.lo}
                                      : NextLN{mn + kHidden, mn, yv.hi, yv.lo};
-        if (ks_ff2 > 1) {
+        if (fold && l + 1 < kBlocks) {
+            EpiResidLN e2{w.x, rh, b.b2, mr + 5 * kHidden, nullptr, mr + kModPerBlock + kHidden, yb.hi, yb.lo, kHidden, w.lnpart, kLnGroups};
+            HIPC(gemm3_resid_ln(ops3(w.ffh, rowmap_plain(kFFp), b.ff2, M, pb), e2, pb, st));
+        } else if (ks_ff2 > 1) {
             HIPC(gemm3_resid_splitk(ops3(w.ffh, rowmap_plain(kFFp), b.ff2, M, pb), r2, w.part, ks_ff2, pb, st, ln2));
         } else {
             HIPC(gemm3_resid(ops3(w.ffh, rowmap_plain(kFFp), b.ff2, M, pb), 1, r2, pb, st));
@@ -1373,7 +1421,7 @@ size_t Engine::sample_ws_bytes(int B, int N, int R, int P, int n_steps, int cfg)
     SampleWs s;
     s.plan(b, B, N, n_steps, cfg);
     ModWs m;
-    m.plan(b, n_steps);
+    m.plan(b, n_steps, ln_fold_);
     return b.off + 256 + denoise_core_bytes(cfg ? 3 * B : B, N) + cross_img_bytes(cfg ? 3 * B : B, R, P);
 }
 
@@ -1391,7 +1439,7 @@ int Engine::sample(hipStream_t st, int mode, int n_steps, int cfg, float s_text,
     SampleWs s;
     s.plan(bump, B, N, n_steps, cfg);
     ModWs m;
-    m.plan(bump, n_steps);
+    m.plan(bump, n_steps, ln_fold_);
     char* core = static_cast<char*>(ws) + ((bump.off + 255) & ~size_t(255));
     const long e = (long)B * N * kLatent;
 
@@ -1418,11 +1466,11 @@ int Engine::sample(hipStream_t st, int mode, int n_steps, int cfg, float s_text,
         if (ensure_aux()) return 1;
         HIPC(hipEventRecord(ev_fork_, st));
         HIPC(hipStreamWaitEvent(aux_, ev_fork_, 0));
-        const int mod_rc = modulation(aux_, s.ts, n_steps, m.sinb, m.t1, m.temb, m.e1, m.semb, m.mod);
+        const int mod_rc = modulation(aux_, s.ts, n_steps, m.sinb, m.t1, m.temb, m.e1, m.semb, m.mod, m.ftab);
         HIPC(hipEventRecord(ev_join_, aux_));   // recorded even when the chain failed half-way: the guard joins what was enqueued
         join_pending_ = true;
         if (mod_rc) return 1;
-    } else if (modulation(st, s.ts, n_steps, m.sinb, m.t1, m.temb, m.e1, m.semb, m.mod)) {
+    } else if (modulation(st, s.ts, n_steps, m.sinb, m.t1, m.temb, m.e1, m.semb, m.mod, m.ftab)) {
         return 1;
     }
 
@@ -1435,11 +1483,11 @@ int Engine::sample(hipStream_t st, int mode, int n_steps, int cfg, float s_text,
     auto eval_velocity = [&](int step) -> int {
         if (!cfg)
             return denoise_core(st, s.xt, mask, m.mod, step, 0, k_ref, v_ref, ref_mask, k_text, v_text, ph_mask, nullptr,
-                                B, N, R, P, s.v, core, ci);
+                                B, N, R, P, s.v, core, ci, m.ftab);
         for (int r = 0; r < 3; ++r)
             HIPC(hipMemcpyAsync(s.xt3 + r * e, s.xt, e * sizeof(float), hipMemcpyDeviceToDevice, st));
         if (denoise_core(st, s.xt3, mask, m.mod, step, 0, k_ref, v_ref, ref_mask, k_text, v_text, ph_mask, nullptr, Bd,
-                         N, R, P, s.v3, core, ci))
+                         N, R, P, s.v3, core, ci, m.ftab))
             return 1;
         HIPC(launch_cfg_combine(s.v3, s.v, s_text, s_spk, e, st));
         return 0;
@@ -1922,6 +1970,13 @@ int Engine::bench_gemm(int M, int N, int K, int epi, int split, int cfg, int ite
     HIPC(hipMalloc(&gate, (size_t)N * 4));
     HIPC(hipMalloc(&hi, (size_t)N * K * 2));
     HIPC(hipMalloc(&lo, (size_t)N * K * 2));
+    uint8_t* maskb = nullptr;
+    float* partb = nullptr;
+    HIPC(hipMalloc(&maskb, (size_t)M));
+    bf16_t* yimg = nullptr;
+    HIPC(hipMalloc(&yimg, (size_t)M * N * 2));
+    HIPC(hipMalloc(&partb, (size_t)M * ((N + 31) / 32) * 2 * 4));
+    HIPC(hipMemset(maskb, 1, (size_t)M));
     HIPC(launch_synth(A, (long)M * K, 1, 0.f, 1.f, 0));
     HIPC(launch_synth(Wf, (long)N * K, 2, 0.f, 0.05f, 0));
     HIPC(launch_synth(bias, N, 3, 0.f, 0.1f, 0));
@@ -1945,6 +2000,11 @@ int Engine::bench_gemm(int M, int N, int K, int epi, int split, int cfg, int ite
                 }
                 case 5: { EpiResid<0> r{C, rowmap_plain(N), bias, gate, 0, 0, 0, M, nullptr}; return gemm3_resid(g3, 2, r, split, 0, cfg); }   // LayerScale residual (codec FF2)
                 case 6: return gemm3_store(g3, ACT_NONE, store_to(C, rowmap_plain(N), nullptr), 1, split, 0, cfg);   // no bias: what a split-K slice stores
+                case 7: case 9: {   // LN-fold producer (the DiT's out-proj with a row mask / FF2 without): residual + next operand image + row partials
+                    EpiResidLN r{C, rowmap_plain(N), bias, gate, epi == 7 ? maskb : nullptr, bias, yimg, sm_lo_for(split == PREC_BF16X3 ? PREC_F16 : split, nullptr), N, partb, N / 32};
+                    return gemm3_resid_ln(g3, r, split, 0, cfg);
+                }
+                case 8: { EpiResid<0> r{C, rowmap_plain(N), bias, gate, 0, 0, 0, M, maskb}; return gemm3_resid(g3, 1, r, split, 0, cfg); }   // tanh-gated residual with a row mask
                 default: { EpiResid<0> r{C, rowmap_plain(N), bias, gate, 0, 0, 0, M, nullptr}; return gemm3_resid(g3, 1, r, split, 0, cfg); }
             }
         }
@@ -1967,7 +2027,7 @@ int Engine::bench_gemm(int M, int N, int K, int epi, int split, int cfg, int ite
     HIPC(hipEventElapsedTime(&ms, e0, e1));
     *avg_us = ms * 1000.f / iters;
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
-    for (void* p : {(void*)A, (void*)Wf, (void*)C, (void*)bias, (void*)gate, (void*)hi, (void*)lo, (void*)ahi, (void*)alo})
+    for (void* p : {(void*)A, (void*)Wf, (void*)C, (void*)bias, (void*)gate, (void*)hi, (void*)lo, (void*)ahi, (void*)alo, (void*)maskb, (void*)partb, (void*)yimg})
         (void)hipFree(p);
     return 0;
 }

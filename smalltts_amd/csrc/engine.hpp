@@ -140,6 +140,8 @@ class Engine {
     int tuning() const { return tuning_; }
     void set_fused_ffn(bool on) { fused_ffn_ = on; }
     void set_attn_img(bool on) { attn_img_ = on; }
+    void set_ln_fold(bool on) { ln_fold_ = on; }   // test hook (smtts_test_set_ln_fold): LN-fold on / off, see ln_fold_
+    bool ln_fold() const { return ln_fold_; }
     bool attn_img() const { return attn_img_; }
     int site_precision(int site) const { return site >= 0 && site < SITE_COUNT ? prec_[site] : 0; }
     void set_dual_stream(bool on) { dual_stream_ = on; }
@@ -210,7 +212,7 @@ class Engine {
     int run_encoder(hipStream_t st, const EncoderW& e, void* enc_ws, int B, int S, const uint8_t* key_mask);
     int make_rope(int dim, float** cos_out, float** sin_out);
     int modulation(hipStream_t st, const float* t_dev, int rows, float* sinb, float* t1, float* temb, float* e1,
-                   float* semb, float* mod);
+                   float* semb, float* mod, float* ftab = nullptr);
     struct DenoiseWs;
     // cross-KV cache of all layers in the attention kernel's operand format (attention_img.hip), built once per sampler call
     struct CrossImg { bf16_t *kc = nullptr, *kc_lo = nullptr, *vtc = nullptr, *vtc_lo = nullptr; int Rp = 0, Cp = 0; };
@@ -220,7 +222,7 @@ class Engine {
     int denoise_core(hipStream_t st, const float* x_t, const uint8_t* mask, const float* mod, int mod_row0,
                      int mod_rstride, const float* k_ref, const float* v_ref, const uint8_t* ref_mask,
                      const float* k_text, const float* v_text, const uint8_t* ph_mask, const float* rope, int B,
-                     int N, int R, int P, float* velocity, char* ws, const CrossImg& ci);
+                     int N, int R, int P, float* velocity, char* ws, const CrossImg& ci, const float* ftab = nullptr);
     size_t denoise_core_bytes(int B, int N) const;
     // runs one block; the result lives in *x on return (the fused mixer ping-pongs *x <-> *xalt)
     int ensure_qkvg_unpadded();   // packs DitBlockW::qkvg of every block on first use of an A/B attention path
@@ -276,6 +278,11 @@ class Engine {
     int num_cus_ = 256;
     bool convpos_by_group_ = true;  // grouped conv pos-embed as one product per group over the batch's rows (false: per (utterance, group))
     bool attn_img_ = true;   // attention on producer-written operand images (attention_img.hip: DMA + MFMA only); false (SMTTS_ATTN_IMG=0, test hook) = fp32 projection + qk_prep + the fp32 VALU reference kernel (attention.hip)
+    // LN-fold (round 6; gemm.hpp LnFoldIn): inside the fused sampler (one modulation row per step for the whole batch) the AdaLN in front
+    // of the QKVG / FF1 products is folded into the producing out-proj / FF2 epilogue (operand image + row partials) and the consuming
+    // epilogue (mean / rstd correction): no ln_modulate launch in throughput tuning, no split-K partials + reduce in latency tuning —
+    // 5 launches per DiT block instead of 7 (SMTTS_LN_FOLD=0 / smtts_test_set_ln_fold restore the norm launches)
+    bool ln_fold_ = true;
     bool attn_epi_ = true;   // ... written by the QKVG GEMM's own epilogue (gemm3 EpiQKV); false (SMTTS_ATTN_EPI=0): fp32 projection + qkv_pack kernel
     Profiler prof_;
     bool prof_on_ = false;
@@ -305,3 +312,6 @@ static constexpr int kModPerBlock = 6 * kHidden;
 static constexpr long kModLd = (long)kBlocks * kModPerBlock + 2 * kHidden;  // 71040
 static constexpr int kConvK = 31, kConvG = 16, kConvCpg = 60, kConvPad = 15, kConvGs = 64;
 static constexpr int kCodecPad = 8;
+static constexpr long kFoldPerBlock = 4L * kHeads * 128 + 2L * kFF;   // LN-fold table columns of one block: padded QKVG rows | interleaved [w1 | w3] rows
+static constexpr long kFoldNF = kBlocks * kFoldPerBlock;              // 106752
+static constexpr int kLnGroups = kHidden / 32;                        // row partials per residual row

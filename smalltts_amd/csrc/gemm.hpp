@@ -39,6 +39,12 @@ __device__ __forceinline__ void split4(const float4& v, uint2& hi, uint2& lo) {
 }
 
 
+#ifdef G3_TIMELINE   // debug build (tools/gemm3_timeline.py): wave 0 of every workgroup stamps the shader clock; one buffer per translation unit
+static __device__ unsigned long long g3_tl_buf[1024 * 160];
+#define EPI_STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x < 1024) g3_tl_buf[blockIdx.x * 160 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define EPI_STAMP(i) do { } while (0)
+#endif
 struct RowCtx;
 // Shared accumulator write-out for gemm_kernel / gemm3_kernel.  mw0 / nw0 = first row / column of this wave.
 template <int TM, int TN, class Epi>
@@ -207,7 +213,38 @@ struct RowCtx {
     long off[16];
     int aux[16];
     unsigned valid;  // bit r: row in range (and not masked out, where the epilogue skips masked rows)
+    int mb;          // first row of the lane's 16 (LN-fold producer: where the row partials go)
+    float mu[16], rs[16];   // LN-fold consumers: mean / rstd of the lane's rows (unused, hence no registers, everywhere else)
 };
+
+// ------------------------------------------------------------------------------------------
+// LN-fold (round 6): the AdaLN in front of a DiT GEMM without a norm launch (reference dit.py:19-25,197-212).
+//   y = LN(x) (1 + scale) + shift,  out = y W^T + b
+//     = rstd (x (1 + scale) W^T - mu W (1 + scale)) + W shift + b
+// The PRODUCER of the residual row (EpiResidLN, the out-proj / FF2 epilogue) writes the operand image fp16(x (1 + scale)) and, per
+// row and 32-column group, the partial sums (sum x, sum x^2); the CONSUMER (EpiQKV / EpiSwiGLU) reduces a row's NP partials in a
+// fixed order when its workgroup starts (gemm3_kernel -> an LDS table of (mu, rstd) per tile row) and applies
+//   rstd (acc - mu wc[n]) + wsh[n] + b[n],     wc = W (1 + scale),  wsh = W shift
+// with the two per-(step, block, site) vectors from fold_vectors_kernel (kernels.hip: one launch per sampler call, t is shared by
+// the batch).  Deterministic: fixed butterfly in the producer, fixed order in the consumer.
+// ------------------------------------------------------------------------------------------
+struct LnFoldIn {
+    const float* part = nullptr;   // [M][NP][2] (sum, sum of squares) per row and 32-column group; null = fold off (plain bias epilogue)
+    int NP = 0;                    // groups per row (hidden / 32)
+    float inv_c = 0.f, eps = 0.f;  // 1 / hidden, LayerNorm eps
+    const float* wc = nullptr;     // [N] W (1 + scale)
+    const float* wsh = nullptr;    // [N] W shift
+    const float* lstat = nullptr;  // set by the kernel: LDS table [BM][2] = (mu, rstd) of the tile's rows
+    int m0 = 0;                    // set by the kernel: first row of the tile
+};
+template <class E, class = void>
+struct epi_small_n { static constexpr bool value = false; };   // epilogues of the DiT's N = 960 residual projections: extra tile shapes / ring depths are instantiated for them only
+template <class E>
+struct epi_small_n<E, decltype((void)E::SMALL_N)> { static constexpr bool value = E::SMALL_N; };
+template <class E, class = void>
+struct epi_fold_in { static constexpr bool value = false; };
+template <class E>
+struct epi_fold_in<E, decltype((void)E::FOLD_IN)> { static constexpr bool value = E::FOLD_IN; };
 // Every value an epilogue LOADED must be complete, as far as the compiler's wait-count pass can tell, before its first STORE is
 // issued: loads and stores share vmcnt on gfx9 and complete out of order with respect to each other, so a load that is still
 // (or only "possibly": a skipped branch arm) pending once stores are in flight costs an `s_waitcnt vmcnt(0)` in front of EVERY
@@ -216,6 +253,23 @@ struct RowCtx {
 __device__ __forceinline__ void epi_settle(float& v) { asm volatile("" : "+v"(v)); }
 __device__ __forceinline__ void epi_settle(int& v) { asm volatile("" : "+v"(v)); }
 __device__ __forceinline__ int epi_row(int mb, int r) { return mb + (r & 3) + 8 * (r >> 2); }
+// The sixteen row-mask bytes of a lane's rows.  ONE uniform branch on the pointer, then sixteen unconditional loads of clamped rows:
+// written as `rowmask ? rowmask[m] : 1` per row, hipcc emitted sixteen branch diamonds with an `s_waitcnt vmcnt(0)` at every join —
+// sixteen dependent round trips in front of the residual loads of every masked N = 960 projection (round 6, found in the ISA).
+__device__ __forceinline__ void epi_row_masks(const uint8_t* __restrict__ rowmask, int mb, int M, int (&mk)[16]) {
+    if (rowmask) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = epi_row(mb, r);
+            mk[r] = (int)rowmask[m < M ? m : 0];
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) epi_settle(mk[r]);
+    } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mk[r] = 1;
+    }
+}
 
 // out[omap(m) + n] = mask(m) * act((acc + bias[n]) * scale)
 template <int ACT>
@@ -239,12 +293,9 @@ struct EpiStore {
             const int m = epi_row(mb, r);
             const bool ok = m < M;
             rc.off[r] = (long)z * o_z + omap.at(ok ? m : 0);
-            rc.aux[r] = (ok && rowmask) ? rowmask[m] : 1;
             rc.valid |= (ok ? 1u : 0u) << r;
         }
-        if (rowmask)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) epi_settle(rc.aux[r]);
+        epi_row_masks(rowmask, mb, M, rc.aux);   // (rows past M read row 0's byte: never stored)
     }
     __device__ __forceinline__ void col(int z, int n, const RowCtx& rc, const floatx16& acc) const {
         float b = bias ? bias[(long)z * bias_z + n] : 0.f;
@@ -313,6 +364,8 @@ struct EpiSwiGLU {
     const float* b3;
     bf16_t* ohi;      // optional split output (see EpiStore)
     bf16_t* olo;
+    static constexpr bool FOLD_IN = true;
+    LnFoldIn fold;    // (gemm3 only) the operand is x (1 + scale), not LN(x) (1 + scale) + shift: see LnFoldIn
     __device__ __forceinline__ void rows(int, int mb, int M, RowCtx& rc) const {
         rc.valid = 0;
 #pragma unroll
@@ -321,16 +374,33 @@ struct EpiSwiGLU {
             rc.off[r] = (long)m * ldo;
             rc.valid |= (m < M ? 1u : 0u) << r;
         }
+        if (fold.part) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int lr = epi_row(mb, r) - fold.m0;
+                rc.mu[r] = fold.lstat[2 * lr];
+                rc.rs[r] = fold.lstat[2 * lr + 1];
+            }
+        }
+    }
+    // packed [w1 | w3] column indices of hidden unit nh (32-column groups interleaved: Engine swiglu_perm)
+    __device__ __forceinline__ void fold_cols(int nh, float& c1, float& c3, float& v1, float& v3) const {
+        const int p1 = (nh >> 5) * 64 + (nh & 31);
+        c1 = fold.wc[p1]; c3 = fold.wc[p1 + 32];
+        v1 += fold.wsh[p1]; v3 += fold.wsh[p1 + 32];
     }
     __device__ __forceinline__ void col(int, int, const RowCtx&, const floatx16&) const {}
     __device__ __forceinline__ void colpair(int, int nh, const RowCtx& rc, const floatx16& a, const floatx16& b) const {
         float v1 = b1 ? b1[nh] : 0.f, v3 = b1 ? b3[nh] : 0.f;
-        epi_settle(v1); epi_settle(v3);
+        float c1 = 0.f, c3 = 0.f;
+        const bool fd = fold.part != nullptr;
+        if (fd) fold_cols(nh, c1, c3, v1, v3);
+        epi_settle(v1); epi_settle(v3); epi_settle(c1); epi_settle(c3);
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             if (rc.valid >> r & 1) {
-                const float x = a[r] + v1;
-                const float v = silu_f(x) * (b[r] + v3);
+                const float x = (fd ? rc.rs[r] * fmaf(-rc.mu[r], c1, a[r]) : a[r]) + v1;
+                const float v = silu_f(x) * ((fd ? rc.rs[r] * fmaf(-rc.mu[r], c3, b[r]) : b[r]) + v3);
                 if (ohi) {
                     store_act1(ohi, olo, rc.off[r] + nh, v);
                 } else {
@@ -344,14 +414,22 @@ struct EpiSwiGLU {
     __device__ __forceinline__ bf16_t* out16() const { return ohi; }
     __device__ __forceinline__ long row_off(int, int m) const { return (long)m * ldo; }
     __device__ __forceinline__ void col16(int, int, const RowCtx&, const floatx16&, unsigned short (&)[16]) const {}
-    __device__ __forceinline__ void colpair16(int, int nh, const RowCtx&, const floatx16& a, const floatx16& b, unsigned short (&o)[16]) const {
-        const float v1 = b1 ? b1[nh] : 0.f, v3 = b1 ? b3[nh] : 0.f;
+    __device__ __forceinline__ void colpair16(int, int nh, const RowCtx& rc, const floatx16& a, const floatx16& b, unsigned short (&o)[16]) const {
+        float v1 = b1 ? b1[nh] : 0.f, v3 = b1 ? b3[nh] : 0.f;
+        float c1 = 0.f, c3 = 0.f;
+        const bool fd = fold.part != nullptr;
+        if (fd) fold_cols(nh, c1, c3, v1, v3);
         const bool f16 = sm_is_f16(olo);
         unsigned sat = 0;
 #pragma unroll
         for (int r = 0; r < 16; r += 2) {
-            const float x0 = a[r] + v1, x1 = a[r + 1] + v1;
-            const float w0 = silu_f(x0) * (b[r] + v3), w1 = silu_f(x1) * (b[r + 1] + v3);
+            float a0 = a[r], a1 = a[r + 1], g0 = b[r], g1 = b[r + 1];
+            if (fd) {
+                a0 = rc.rs[r] * fmaf(-rc.mu[r], c1, a0); a1 = rc.rs[r + 1] * fmaf(-rc.mu[r + 1], c1, a1);
+                g0 = rc.rs[r] * fmaf(-rc.mu[r], c3, g0); g1 = rc.rs[r + 1] * fmaf(-rc.mu[r + 1], c3, g1);
+            }
+            const float x0 = a0 + v1, x1 = a1 + v1;
+            const float w0 = silu_f(x0) * (g0 + v3), w1 = silu_f(x1) * (g1 + v3);
             unsigned p;
             if (f16) {
                 p = cvt_pk_f16_sat(w0, w1, sat);
@@ -372,6 +450,7 @@ struct EpiSwiGLU {
 //   launch_tanh_gates)     GATE 2: g = gate[n]
 template <int GATE>
 struct EpiResid {
+    static constexpr bool SMALL_N = GATE == 1;
     static constexpr bool PAIRED = false;
     static constexpr bool STAGE16 = false;
     static constexpr bool TILE = false;
@@ -386,11 +465,8 @@ struct EpiResid {
     __device__ __forceinline__ void rows(int, int mb, int M, RowCtx& rc) const {
         rc.valid = 0;
         int mk[16];   // all sixteen mask bytes are requested before the first is looked at (one round trip, not sixteen dependent ones)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int m = epi_row(mb, r);
-            mk[r] = rowmask ? (int)rowmask[m < M ? m : 0] : 1;
-        }
+        epi_row_masks(rowmask, mb, M, mk);
+        EPI_STAMP(154);   // mask bytes landed
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int m = epi_row(mb, r);
@@ -406,10 +482,11 @@ struct EpiResid {
         const float g2 = GATE == 2 ? gate[n] : 1.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const bool ok = rc.valid >> r & 1;
-            gv[r] = (GATE == 1 && ok) ? gate[(long)rc.aux[r] * gld + n] : g2;
-            xv[r] = ok ? x[rc.off[r] + n] : 0.f;
+            // (rows that are not stored carry row 0's offsets: the loads are unconditional — no exec-mask diamonds — and unused)
+            gv[r] = GATE == 1 ? gate[(long)rc.aux[r] * gld + n] : g2;
+            xv[r] = x[rc.off[r] + n];
         }
+        EPI_STAMP(155);
         epi_settle(b);   // (gv / xv are consumed in order by the store loop: settling all 32 costs registers — 115 -> 130 VGPRs on the
                          // 128 x 128 tile, one workgroup per CU less — for nothing, the first store needs them anyway)
 #pragma unroll
@@ -418,6 +495,93 @@ struct EpiResid {
                 x[rc.off[r] + n] = xv[r] + gv[r] * (acc[r] + b);
             }
         }
+    }
+    __device__ __forceinline__ void colpair(int, int, const RowCtx&, const floatx16&, const floatx16&) const {}
+};
+
+// LN-fold producer: the gated residual of the DiT's N = 960 projections (dit.py:198,201), all batch rows sharing ONE modulation row
+// (the fused sampler: t is shared), followed by what the next AdaLN'd GEMM needs instead of a norm launch (LnFoldIn):
+//   x[m][n] += mask(m) gate[n] (acc + bias[n]);   y[m][n] = fmt(x[m][n] (1 + nscale[n]));   part[m][n / 32] = (sum_n x, sum_n x^2)
+// Masked rows keep x but still get their image row and partials.  N % 32 == 0 (every lane of a 32-column group takes part in the
+// group's butterfly).
+template <int W>   // one reduce-scatter step: the lane keeps W of its 2 W values and adds the partner lane's other half (static indices only)
+__device__ __forceinline__ void fold_rs_step(float (&v)[32], int lane) {
+    const bool up = (lane & W) != 0;
+#pragma unroll
+    for (int k = 0; k < W; ++k) {
+        const float keep = up ? v[k + W] : v[k];
+        const float send = up ? v[k] : v[k + W];
+        v[k] = keep + __shfl_xor(send, W, 64);
+    }
+}
+struct EpiResidLN {
+    static constexpr bool SMALL_N = true;
+    static constexpr bool PAIRED = false;
+    static constexpr bool STAGE16 = false;
+    static constexpr bool TILE = false;
+    float* x;
+    RowMap xmap;
+    const float* bias;       // may be null
+    const float* gate;       // [N]: tanh(gate) of this step (modulation-table row)
+    const uint8_t* rowmask;  // may be null: masked rows are left untouched
+    const float* nscale;     // [N]: scale of the AdaLN in front of the NEXT GEMM
+    bf16_t* yhi;             // that GEMM's operand image [M][yld] in the format (yhi, ylo) encode (common.hpp sm_lo_for)
+    bf16_t* ylo;
+    long yld;
+    float* part;             // [M][NP][2]
+    int NP;
+    __device__ __forceinline__ void rows(int, int mb, int M, RowCtx& rc) const {
+        rc.valid = 0;
+        rc.mb = mb;
+        int mk[16];
+        epi_row_masks(rowmask, mb, M, mk);
+        EPI_STAMP(154);   // mask bytes landed
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = epi_row(mb, r);
+            const bool ok = m < M;
+            rc.off[r] = xmap.at(ok ? m : 0);
+            rc.aux[r] = ok && mk[r] != 0;     // the residual is applied
+            rc.valid |= (ok ? 1u : 0u) << r;  // the row exists
+        }
+    }
+    __device__ __forceinline__ void col(int, int n, const RowCtx& rc, const floatx16& acc) const {
+        float b = bias ? bias[n] : 0.f;
+        float g = gate[n], s1 = 1.0f + nscale[n];
+        float xv[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) xv[r] = x[rc.off[r] + n];   // (rows past M: row 0's, unused)
+        epi_settle(b); epi_settle(g); epi_settle(s1);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) epi_settle(xv[r]);
+        EPI_STAMP(155);   // residual / vector loads landed
+        float v[32];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float xn = rc.aux[r] ? fmaf(g, acc[r] + b, xv[r]) : xv[r];
+            if (rc.aux[r]) x[rc.off[r] + n] = xn;
+            v[2 * r] = xn;
+            v[2 * r + 1] = xn * xn;
+        }
+        if (sm_is_f16(ylo)) {   // (one format decision per column; the clamp count goes out once, behind the stores)
+            unsigned sat = 0;
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                if (rc.valid >> r & 1)
+                    reinterpret_cast<unsigned short*>(yhi)[(long)epi_row(rc.mb, r) * yld + n] = (unsigned short)(cvt_pk_f16_sat(v[2 * r] * s1, 0.f, sat) & 0xffffu);
+            sat_note(sat, ylo);
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                if (rc.valid >> r & 1) store_act1(yhi, ylo, (long)epi_row(rc.mb, r) * yld + n, v[2 * r] * s1);
+        }
+        EPI_STAMP(156);   // residual + image stores issued
+        // reduce-scatter over the 32 lanes (columns) of this half-wave: after the step of width w a lane holds w values; lane l ends
+        // with the total of value index l = 2 r + {0: sum, 1: sum of squares}
+        const int lane = threadIdx.x & 63;
+        fold_rs_step<16>(v, lane); fold_rs_step<8>(v, lane); fold_rs_step<4>(v, lane); fold_rs_step<2>(v, lane); fold_rs_step<1>(v, lane);
+        const int l = lane & 31, r = l >> 1;
+        if (rc.valid >> r & 1) part[((long)epi_row(rc.mb, r) * NP + (n >> 5)) * 2 + (l & 1)] = v[0];
     }
     __device__ __forceinline__ void colpair(int, int, const RowCtx&, const floatx16&, const floatx16&) const {}
 };
@@ -543,6 +707,8 @@ struct EpiQKV {
     int rot_dim, prec;
     bf16_t *q, *q_lo, *k, *k_lo, *vt, *vt_lo, *g, *g_lo;
     int Nseq, H, dh, HW, Np;
+    static constexpr bool FOLD_IN = true;
+    LnFoldIn fold;                   // the operand is x (1 + scale), not the AdaLN output: see LnFoldIn
     // (the generic column protocol is not used by this epilogue)
     __device__ __forceinline__ void rows(int, int, int, RowCtx&) const {}
     __device__ __forceinline__ void col(int, int, const RowCtx&, const floatx16&) const {}
@@ -564,7 +730,18 @@ struct EpiQKV {
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
                     const int c = (wn * TN + j) * 32 + fr;
-                    const float bv = bias ? bias[n0 + c] : 0.f;
+                    float bv = bias ? bias[n0 + c] : 0.f;
+                    if (fold.part) {   // (uniform) LN-fold: rstd (acc - mu wc) + W shift + bias
+                        const float cw = fold.wc[n0 + c];
+                        bv += fold.wsh[n0 + c];
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int row = r32 + 4 * fh + (r & 3) + 8 * (r >> 2);
+                            const float2 st = *reinterpret_cast<const float2*>(fold.lstat + 2 * (rh * 64 + row));
+                            tile[row * TP + c] = st.y * fmaf(-st.x, cw, acc[i][j][r]) + bv;
+                        }
+                        continue;
+                    }
 #pragma unroll
                     for (int r = 0; r < 16; ++r)
                         tile[(r32 + 4 * fh + (r & 3) + 8 * (r >> 2)) * TP + c] = acc[i][j][r] + bv;

@@ -29,8 +29,8 @@ struct Gemm3Operands {
 };
 
 #ifdef G3_TIMELINE   // debug build (tools/gemm3_timeline.py): wave 0 of every workgroup stamps the shader clock around each k-tile's wait / barrier / MFMAs
-static __device__ unsigned long long g3_tl_buf[1024 * 160];   // (one copy per translation unit: read through gemm3_store.hip's)
-#define G3_STAMP(i) do { if (tid == 0 && blockIdx.x < 1024 && (i) < 160) g3_tl_buf[blockIdx.x * 160 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+// (g3_tl_buf: gemm.hpp, one copy per translation unit — read through the unit's smtts_debug_read_timeline*)
+#define G3_STAMP(i) do { if (tid == 0 && blockIdx.x < 1024 && ((i) < 146 || (i) >= 150) && (i) < 160) g3_tl_buf[blockIdx.x * 160 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
 #define G3_STAMPR(i) do { if (tid == 0 && blockIdx.x < 1024) g3_tl_buf[blockIdx.x * 160 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)   // constant 100 MHz: calibrates the shader clock
 #else
 #define G3_STAMPR(i) do { } while (0)
@@ -220,6 +220,30 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm3_kernel(Gemm3Operands g, Epi
     for (int s = 0; s < S - 1; ++s)
         if (s < nk) issue(s);
     G3_STAMP(1);
+    if constexpr (epi_fold_in<Epi>::value) {
+        // LN-fold consumer (gemm.hpp LnFoldIn): (mu, rstd) of the tile's rows from the producer's per-group partials, reduced in a
+        // fixed order, into an LDS table behind the ring.  The loads are requested behind the ring's first stages and waited for with
+        // them (the first k-tile waits for stage 0 anyway); the table is read in the epilogue only, many barriers later.
+        float* const lstat = reinterpret_cast<float*>(smem + S * STAGE_LD + 256);
+        epi.fold.lstat = lstat;
+        epi.fold.m0 = m0;
+        if (epi.fold.part && tid < BM) {
+            int m = m0 + tid;
+            m = m < g.M ? m : g.M - 1;
+            const float4* p = reinterpret_cast<const float4*>(epi.fold.part + (long)m * epi.fold.NP * 2);
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll 5
+            for (int i = 0; i < epi.fold.NP / 2; ++i) {
+                const float4 v = p[i];
+                s1 = (s1 + v.x) + v.z;
+                s2 = (s2 + v.y) + v.w;
+            }
+            const float mu = s1 * epi.fold.inv_c;
+            const float var = fmaf(-mu, mu, s2 * epi.fold.inv_c);
+            lstat[2 * tid] = mu;
+            lstat[2 * tid + 1] = 1.0f / sqrtf((var > 0.f ? var : 0.f) + epi.fold.eps);
+        }
+    }
 
     for (int kt = 0; kt < nk; ++kt) {
         // younger than stage kt's DMA: its own touch loads + (S-2) full later stages
@@ -335,7 +359,8 @@ template <int BM, int BN, int WM, int WN, int SPLIT, int S, class Epi>
 static inline hipError_t gemm3_launch_cfg(const Gemm3Operands& g, const Epi& epi, int Z, hipStream_t st) {
     constexpr int NARR_A = SPLIT == 3 ? 2 : 1, NARR_W = (SPLIT == 3 || SPLIT == PREC_F16X2) ? 2 : 1;
     constexpr bool DUMMY = (NARR_A * (BM / 8) + NARR_W * (BN / 8)) % (WM * WN) != 0;
-    constexpr size_t lds = (size_t)S * ((NARR_A * BM + NARR_W * BN) * 128 + (DUMMY ? 1024 : 0)) + 256;  // ring (+ pads) + dummy slot of the prefetch touches
+    constexpr size_t lds = (size_t)S * ((NARR_A * BM + NARR_W * BN) * 128 + (DUMMY ? 1024 : 0)) + 256  // ring (+ pads) + dummy slot of the prefetch touches
+                           + (epi_fold_in<Epi>::value ? BM * 8 : 0);                                    // + (mu, rstd) of the tile's rows (LN-fold consumers)
     static_assert(lds <= 160 * 1024, "LDS ring exceeds 160 KiB");
     dim3 grid(((g.N + BN - 1) / BN) * ((g.M + BM - 1) / BM), 1, Z);  // 1-D tile index, remapped per XCD in-kernel
     auto kern = gemm3_kernel<BM, BN, WM, WN, SPLIT, S, Epi>;
@@ -357,6 +382,8 @@ enum Gemm3Cfg {
     G3_160x128 = 5,  // 10 waves 5x2, wave 32x64, 2 stages (146 KiB): M = 600 (4 row tiles, 6 % padding) x wide N in ONE round
     G3_128x128_W4 = 6,  // 4 waves 2x2, wave 64x64: 4 fragment reads per 4 MFMAs instead of 3 per 2 — for the single-array formats,
                         // where one MFMA per fragment pair leaves the k-loop bound by ds_read_b128 traffic; 2 workgroups per CU
+    G3_64x32 = 8,       // 2 waves 2x1, wave 32x32 (12 KiB per single-array stage): twice the workgroups of 64x64 on the N = 960 projections (300 at M = 600)
+    G3_32x64 = 9,       // 2 waves 1x2
     G4_256x256 = 7,     // gemm4.hpp: 8 waves 2x4, wave 128x64, two 64-KiB k-tile buffers on the phase-split schedule (single-array formats)
 };
 static inline bool gemm3_ok(const Gemm3Operands& g) {
@@ -425,7 +452,8 @@ static inline hipError_t gemm3_launch_split(const Gemm3Operands& g, const Epi& e
         // deep rings pay when the whole grid is resident at once (one latency-bound round); a grid of several rounds at the deep
         // ring's occupancy runs faster shallow with more workgroups per CU (teacher QKVG, 450 tiles of 128x128: 35.1 us deep — two
         // rounds at one workgroup per CU — against 27.5 shallow; B = 8 QKVG as 600 tiles of 64x64: 20.4 against 15.3)
-        const long bm = cfg == G4_256x256 ? 256 : cfg == G3_64x128 || cfg == G3_64x64 ? 64 : cfg == G3_160x128 ? 160 : 128, bn = cfg == G4_256x256 ? 256 : cfg == G3_64x64 ? 64 : 128;
+        const long bm = cfg == G4_256x256 ? 256 : cfg == G3_64x128 || cfg == G3_64x64 || cfg == G3_64x32 ? 64 : cfg == G3_32x64 ? 32 : cfg == G3_160x128 ? 160 : 128,
+                   bn = cfg == G4_256x256 ? 256 : cfg == G3_64x64 || cfg == G3_32x64 ? 64 : cfg == G3_64x32 ? 32 : 128;
         const long tiles = ((g.M + bm - 1) / bm) * ((g.N + bn - 1) / bn) * (Z > 0 ? Z : 1);
         const long deep_slots = cfg == G3_64x64 ? 512 : 256;
         if (g_gemm3_deep && tiles <= deep_slots) {
@@ -436,6 +464,9 @@ static inline hipError_t gemm3_launch_split(const Gemm3Operands& g, const Epi& e
                     if constexpr (!Epi::PAIRED) return gemm3_launch_cfg<64, 128, 2, 4, SPLIT, 6, Epi>(g, epi, Z, st);
                     break;
                 case G3_64x64:
+                    if constexpr (epi_small_n<Epi>::value) {   // the DiT's N = 960 residual projections: 150 workgroups, one per CU — the LDS is there for a longer ring
+                        if (g_gemm3_deep >= 2) return gemm3_launch_cfg<64, 64, 2, 2, SPLIT, 8, Epi>(g, epi, Z, st);
+                    }
                     if constexpr (!Epi::PAIRED) return gemm3_launch_cfg<64, 64, 2, 2, SPLIT, 4, Epi>(g, epi, Z, st);
                     break;
                 case G3_160x128:
@@ -468,6 +499,14 @@ static inline hipError_t gemm3_launch_split(const Gemm3Operands& g, const Epi& e
         case G3_128x128_W4:
             if constexpr (SPLIT == PREC_BF16 || SPLIT == PREC_F16) return gemm3_launch_cfg<128, 128, 2, 2, SPLIT, 2, Epi>(g, epi, Z, st);
             break;
+        case G3_64x32:
+            if constexpr (epi_small_n<Epi>::value && SPLIT != 3) return g_gemm3_deep >= 2 ? gemm3_launch_cfg<64, 32, 2, 1, SPLIT, 8, Epi>(g, epi, Z, st)
+                                                                                         : gemm3_launch_cfg<64, 32, 2, 1, SPLIT, 4, Epi>(g, epi, Z, st);
+            break;
+        case G3_32x64:
+            if constexpr (epi_small_n<Epi>::value && SPLIT != 3) return g_gemm3_deep >= 2 ? gemm3_launch_cfg<32, 64, 1, 2, SPLIT, 8, Epi>(g, epi, Z, st)
+                                                                                         : gemm3_launch_cfg<32, 64, 1, 2, SPLIT, 4, Epi>(g, epi, Z, st);
+            break;
     }
     return hipErrorInvalidValue;
 }
@@ -487,6 +526,7 @@ static inline hipError_t gemm3_launch(const Gemm3Operands& g_in, const Epi& epi,
     extern int g_gemm3_group;
     const double wbytes = (double)g.N * g.K * (split == PREC_BF16X3 ? 4.0 : 2.0);
     g.nfast = g_gemm3_nfast && (long)g.M > (long)g.N ? (g_gemm3_group > 1 && wbytes > 3e6 && g.M >= 1024 ? g_gemm3_group : 1) : 0;
+    if ((cfg == G3_64x32 || cfg == G3_32x64) && (split == PREC_BF16X3 || !epi_small_n<Epi>::value)) cfg = G3_64x64;   // (no such instantiation)
     if (cfg == G4_256x256 && (split == PREC_BF16X3 || !gemm4_ok(g) || !gemm4_enabled<Epi>::value)) cfg = G3_128x128;   // (no such instantiation)
     if (split == PREC_BF16X3) return gemm3_launch_split<3, Epi>(g, epi, Z, cfg == G3_128x128_W4 ? G3_128x128 : cfg, st);
     if (split == PREC_F16) return gemm3_launch_split<2, Epi>(g, epi, Z, cfg, st);

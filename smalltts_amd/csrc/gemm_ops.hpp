@@ -33,7 +33,7 @@ hipError_t gemm_convpos(const GemmOperands& g, bool final, const EpiConvPos<0>& 
 // ---- v3 (split-A, DMA ring, 8 waves) entry points: definitions in gemm3_ops.hip --------------------------
 static inline std::string gemm3_prof_name(const Gemm3Operands& g, bool paired, int cfg, int split, const char* epi) {
     if (cfg < 0) cfg = gemm3_pick_cfg(g.M, g.N, paired, split != PREC_BF16X3);
-    static const char* tiles[] = {"64x128", "128x128", "64x64", "128x64", "128x32", "160x128", "128x128w4", "256x256"};
+    static const char* tiles[] = {"64x128", "128x128", "64x64", "128x64", "128x32", "160x128", "128x128w4", "256x256", "64x32", "32x64"};
     if (cfg == G4_256x256 && (split == PREC_BF16X3 || !gemm4_ok(g))) cfg = G3_128x128;   // (gemm3_launch's fallback)
     std::string n = std::string(cfg == G4_256x256 ? "gemm4<" : "gemm3<") + tiles[cfg] + ",s" + std::to_string(split) + "," + epi + ">";
     extern thread_local int g_prof_shapes;   // profile mode 3: the product's shape behind the class name ("... 600x3840x960[/k3]")
@@ -59,6 +59,7 @@ hipError_t gemm3_store(const Gemm3Operands& g, int act, const EpiStore<ACT_NONE>
 hipError_t gemm3_store_x2(const Gemm3Operands& g, const EpiStore<ACT_NONE>& p, hipStream_t st, int cfg = -1);   // PREC_F16X2: A = g.Ahi (fp16), W = g.Whi + g.Wlo (fp16 pair)
 hipError_t gemm3_swiglu(const Gemm3Operands& g, const EpiSwiGLU& p, int split, hipStream_t st);
 hipError_t gemm3_resid(const Gemm3Operands& g, int gate_mode, const EpiResid<0>& p, int split, hipStream_t st, int cfg = -1);
+hipError_t gemm3_resid_ln(const Gemm3Operands& g, const EpiResidLN& p, int split, hipStream_t st, int cfg = -1);   // LN-fold producer (N % 32 == 0)
 hipError_t gemm3_kv(const Gemm3Operands& g, const EpiKV& p, int split, hipStream_t st);
 hipError_t gemm3_convpos(const Gemm3Operands& g, bool final, const EpiConvPos<0>& p, int Z, int split, hipStream_t st);
 // QKVG projection -> attention operand images (EpiQKV): columns n = (part * H + h) * HW + d, N = 4 * H * HW

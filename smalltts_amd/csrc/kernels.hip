@@ -765,6 +765,98 @@ hipError_t launch_tanh_gates(float* mod, int rows, long ld, int n_blocks, int pe
     LAUNCH_CHECK();
 }
 
+// ------------------------------------------------------------------------------------------
+// LN-fold tables: W shift and W (1 + scale) for every (step, block, site) in ONE launch (kernels.hpp FoldSites).
+// A workgroup takes 64 weight rows of one site and FV_STEPS steps: the 2 FV_STEPS vectors sit in LDS as fp32, four lanes share a
+// row (16-byte pieces of it, interleaved), every weight element is read once per step chunk.  HBM-bound on the weights
+// (205 MB at fp16 for the 24 sites), fixed summation order.
+// ------------------------------------------------------------------------------------------
+static constexpr int FV_STEPS = 4, FV_ROWS = 64, FV_K = 960;
+__global__ __launch_bounds__(256) void fold_vectors_kernel(FoldSites fs, const float* __restrict__ mod, long mod_ld, int rows,
+                                                           float* __restrict__ tab) {
+    __shared__ __attribute__((aligned(16))) float vec[2 * FV_STEPS][FV_K];
+    // which site: blockIdx.x counts 64-row groups over the sites in order
+    int si = 0, g0 = blockIdx.x;
+    for (; si < fs.n; ++si) {
+        const int ng = (fs.s[si].N + FV_ROWS - 1) / FV_ROWS;
+        if (g0 < ng) break;
+        g0 -= ng;
+    }
+    if (si >= fs.n) return;
+    const FoldSite S = fs.s[si];
+    const int step0 = blockIdx.y * FV_STEPS;
+    for (int i = threadIdx.x; i < 2 * FV_STEPS * FV_K; i += 256) {
+        const int v = i / FV_K, k = i - v * FV_K, st = step0 + (v >> 1);
+        float x = 0.f;
+        if (st < rows) x = (v & 1) ? 1.0f + mod[(long)st * mod_ld + S.scale_off + k] : mod[(long)st * mod_ld + S.shift_off + k];
+        vec[v][k] = x;
+    }
+    __syncthreads();
+    const int q = threadIdx.x & 3, n = g0 * FV_ROWS + (threadIdx.x >> 2);
+    const int nn = n < S.N ? n : S.N - 1;
+    const uint4* wr = reinterpret_cast<const uint4*>(S.w + (long)nn * FV_K);
+    const uint4* wl = S.wlo ? reinterpret_cast<const uint4*>(S.wlo + (long)nn * FV_K) : nullptr;
+    float acc[2 * FV_STEPS];
+#pragma unroll
+    for (int v = 0; v < 2 * FV_STEPS; ++v) acc[v] = 0.f;
+#pragma unroll 2
+    for (int i = 0; i < FV_K / 32; ++i) {
+        const int c = q + 4 * i;   // 16-byte piece of the row: elements [8 c, 8 c + 8)
+        const uint4 u = wr[c];
+        float w[8];
+        const unsigned uu[4] = {u.x, u.y, u.z, u.w};
+        if (S.fmt == 0) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const half2_t h = __builtin_bit_cast(half2_t, uu[e]);
+                w[2 * e] = (float)h[0]; w[2 * e + 1] = (float)h[1];
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { w[2 * e] = __uint_as_float(uu[e] << 16); w[2 * e + 1] = __uint_as_float(uu[e] & 0xffff0000u); }
+            if (wl) {
+                const uint4 l = wl[c];
+                const unsigned ll[4] = {l.x, l.y, l.z, l.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { w[2 * e] += __uint_as_float(ll[e] << 16); w[2 * e + 1] += __uint_as_float(ll[e] & 0xffff0000u); }
+            }
+        }
+#pragma unroll
+        for (int v = 0; v < 2 * FV_STEPS; ++v) {
+            const float4 a = *reinterpret_cast<const float4*>(&vec[v][8 * c]);
+            const float4 b = *reinterpret_cast<const float4*>(&vec[v][8 * c + 4]);
+            float t = acc[v];
+            t = fmaf(w[0], a.x, t); t = fmaf(w[1], a.y, t); t = fmaf(w[2], a.z, t); t = fmaf(w[3], a.w, t);
+            t = fmaf(w[4], b.x, t); t = fmaf(w[5], b.y, t); t = fmaf(w[6], b.z, t); t = fmaf(w[7], b.w, t);
+            acc[v] = t;
+        }
+    }
+#pragma unroll
+    for (int v = 0; v < 2 * FV_STEPS; ++v) {
+        acc[v] += __shfl_xor(acc[v], 1, 64);
+        acc[v] += __shfl_xor(acc[v], 2, 64);
+    }
+    if (q == 0 && n < S.N) {
+#pragma unroll
+        for (int v = 0; v < 2 * FV_STEPS; ++v) {
+            const int st = step0 + (v >> 1);
+            if (st < rows) tab[((long)st * 2 + (v & 1)) * fs.NF + S.out_off + n] = acc[v];
+        }
+    }
+}
+hipError_t launch_fold_vectors(const FoldSites& sites, const float* mod, long mod_ld, int rows, float* tab, hipStream_t st) {
+    if (rows <= 0 || sites.n <= 0) return hipSuccess;
+    long groups = 0, wbytes = 0;
+    for (int i = 0; i < sites.n; ++i) {
+        groups += (sites.s[i].N + FV_ROWS - 1) / FV_ROWS;
+        wbytes += (long)sites.s[i].N * FV_K * (sites.s[i].wlo ? 4 : 2);
+    }
+    const int chunks = (rows + FV_STEPS - 1) / FV_STEPS;
+    ProfScope ps(st, "fold_vectors", 4.0 * sites.NF * FV_K * rows, (double)wbytes * chunks + 8.0 * sites.NF * rows, 0.0);
+    hipLaunchKernelGGL(fold_vectors_kernel, dim3((unsigned)groups, (unsigned)chunks), dim3(256), 0, st, sites, mod, mod_ld, rows, tab);
+    LAUNCH_CHECK();
+}
+
 __global__ void to_split_kernel(const float* __restrict__ x, RowMap xmap, bf16_t* __restrict__ hi, bf16_t* __restrict__ lo,
                                 RowMap omap, int M, int C4) {
     long i = (long)blockIdx.x * blockDim.x + threadIdx.x;

@@ -100,6 +100,12 @@ hipError_t launch_len_mask(const int64_t* len, uint8_t* mask, int B, int R, hipS
 hipError_t launch_convpos_pack(const float* h, const uint8_t* mask, bf16_t* gm_hi, bf16_t* gm_lo, int B, int T, int G,
                                int cpg, int pad, int gstride, hipStream_t st);
 // in place: table[r][c0 + c] = tanh(table[r][c0 + c]) for the two gate column blocks of every DiT block
+// LN-fold tables (gemm.hpp LnFoldIn): for every sampler step (modulation-table row) and every AdaLN'd GEMM site of the DiT blocks,
+//   tab[row][0][off + n] = sum_k W[n][k] shift[k],   tab[row][1][off + n] = sum_k W[n][k] (1 + scale[k])        (K = 960)
+// with W the 16-bit weights the GEMM itself multiplies (fmt 0: one fp16 array, 1: bf16 hi (+ lo when non-null)).
+struct FoldSite { const bf16_t* w; const bf16_t* wlo; int N; int fmt; int shift_off, scale_off; long out_off; };
+struct FoldSites { FoldSite s[24]; int n; long NF; };
+hipError_t launch_fold_vectors(const FoldSites& sites, const float* mod, long mod_ld, int rows, float* tab, hipStream_t st);
 hipError_t launch_tanh_gates(float* mod, int rows, long ld, int n_blocks, int per_block, int hidden, hipStream_t st);
 // fp32 -> split bf16 pair, rows addressed through RowMaps (element offsets)
 hipError_t launch_to_split(const float* x, RowMap xmap, bf16_t* hi, bf16_t* lo, RowMap omap, int M, int C, hipStream_t st);

@@ -109,6 +109,14 @@ class HipEngine:
         self.tuning = mode
         return prev
 
+    def set_ln_fold(self, on: bool) -> bool:
+        """Test hook: the fused sampler's AdaLN between two DiT block GEMMs folded into their epilogues (default) or as separate
+        split-K reduce / ln_modulate launches.  Returns the previous setting."""
+        prev = getattr(self, "ln_fold", True)
+        self._ck(self.lib.smtts_test_set_ln_fold(self.h, int(bool(on))), "test_set_ln_fold")
+        self.ln_fold = bool(on)
+        return prev
+
     def release_workspaces(self):
         """Drop the named per-stream scratch buffers (synthesize_batches / bench keep one per batch in flight)."""
         self._ws_named.clear()

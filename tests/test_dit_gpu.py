@@ -99,6 +99,42 @@ def test_full_bench_shape_vs_oracle(eng, dit_weights):
     assert e1 < 5e-2
 
 
+@pytest.mark.parametrize("tuning", ["latency", "throughput"])
+def test_ln_fold_agrees_with_the_norm_launches_and_the_oracle(eng, dit_weights, tuning):
+    """Round 6: inside the fused sampler the AdaLN between two block GEMMs is folded into their epilogues (gemm.hpp LnFoldIn:
+    the producer writes x (1 + scale) and per-row partial sums, the consumer applies rstd (acc - mu W (1 + scale)) + W shift + b).
+    Same arithmetic as LN -> modulate -> GEMM (dit.py:19-25,197-212) up to fp32 rounding: held to the oracle at the split-bf16
+    tolerance, to the norm-launch path far inside it, on a RAGGED batch (masked rows keep x but feed the statistics), in both
+    tunings, and bit-repeatable."""
+    gen = torch.Generator().manual_seed(5)
+    B, N, R, P = 5, 37, 9, 11
+    ref = torch.randn(B, R, 64, generator=gen)
+    ref_len = torch.tensor([9, 4, 7, 9, 1])
+    ids = torch.randint(1, 198, (B, P), generator=gen)
+    pm = torch.arange(P)[None] < torch.tensor([11, 6, 11, 3, 8])[:, None]
+    mask = torch.arange(N)[None] < torch.tensor([37, 20, 33, 37, 5])[:, None]
+    noise = torch.randn(4, B, N, 64, generator=gen)
+    with torch.no_grad():
+        oc = O.encode_conditions(dit_weights, ref, ref_len, ids, pm)
+        ox = O.sample_dmd(dit_weights, oc, pm, mask, noise, 4).numpy()
+    prev_t = eng.set_tuning(tuning)
+    try:
+        cache = eng.cond_encode(ref, ref_len, ids, pm)
+        assert eng.set_ln_fold(True) is True            # the default
+        x_fold = eng.sample(cache, mask, num_steps=4, noise=noise).cpu().numpy()
+        x_again = eng.sample(cache, mask, num_steps=4, noise=noise).cpu().numpy()
+        eng.set_ln_fold(False)
+        x_norm = eng.sample(cache, mask, num_steps=4, noise=noise).cpu().numpy()
+    finally:
+        eng.set_ln_fold(True)
+        eng.set_tuning(prev_t)
+    m = mask.numpy()
+    assert np.array_equal(x_fold, x_again)
+    e_fold, e_norm, e_ab = rel_l2(x_fold[m], ox[m]), rel_l2(x_norm[m], ox[m]), rel_l2(x_fold[m], x_norm[m])
+    print(f"\n[ln-fold, {tuning}] vs oracle: fold {e_fold:.3e}, norm launches {e_norm:.3e}; fold vs norm launches {e_ab:.3e}")
+    assert e_fold < TOL and e_norm < TOL and e_ab < TOL
+
+
 def test_ragged_batch_equals_per_utterance(eng):
     """A1 (infer/onnx.py:131-159): padded batch == per-utterance results on the valid frames."""
     gen = torch.Generator().manual_seed(3)

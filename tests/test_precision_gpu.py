@@ -57,6 +57,29 @@ def test_default_precision_vs_reference_golden(eng, case):
     assert err < TOL_F16, f"{case}: velocity rel L2 {err:.3e}"
 
 
+def test_default_precision_ln_fold_vs_norm_launches_at_the_bench_shape(eng):
+    """The LN-fold of the fused sampler (tests/test_dit_gpu.py) at the SHIPPED precision and the bench shape: the operand image is
+    fp16(x (1 + scale)) of the un-normalised residual stream, the mean is taken out after the product — both paths must sit at the
+    same distance from the fp32 oracle (asserted: 3e-4 each, and the fold no more than 1.25x the norm launches' error)."""
+    ref, ref_len, ids, pm, mask, noise = _bench_inputs()
+    cache = eng.cond_encode(ref, ref_len, ids, pm)
+    x_fold = eng.sample(cache, mask, num_steps=4, noise=noise).cpu().numpy()
+    eng.set_ln_fold(False)
+    try:
+        x_norm = eng.sample(cache, mask, num_steps=4, noise=noise).cpu().numpy()
+    finally:
+        eng.set_ln_fold(True)
+    eng.set_precision("bf16x3")
+    try:
+        cache3 = eng.cond_encode(ref, ref_len, ids, pm)
+        x_ref = eng.sample(cache3, mask, num_steps=4, noise=noise).cpu().numpy()    # fp32-class operands (7e-6 from the oracle)
+    finally:
+        eng.set_precision("f16")
+    e_fold, e_norm = rel_l2(x_fold, x_ref), rel_l2(x_norm, x_ref)
+    print(f"\n[ln-fold, f16 mixed, 8 x 75] vs split-bf16: fold {e_fold:.3e}, norm launches {e_norm:.3e}")
+    assert e_fold < TOL_F16 and e_norm < TOL_F16 and e_fold < 1.25 * e_norm + 2e-5
+
+
 def test_default_precision_sampler_vs_reference_golden(eng):
     g = golden("case_sampler4.npz")
     B, N = g["noise"].shape[1:3]
