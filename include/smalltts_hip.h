@@ -25,8 +25,9 @@
  * That thread MAY keep several operator calls in flight on DIFFERENT streams, provided that
  *   (1) every call in flight has its own workspace and its own output buffers (all per-call scratch lives in the workspace;
  *       weights are read-only after smtts_finalize);
- *   (2) smtts_set_tuning(h, 1) ("throughput") was selected first — it also turns the engine-owned side stream of
- *       smtts_cond_encode off, whose single stream + event pair would otherwise be shared by the calls in flight;
+ *   (2) smtts_set_tuning(h, 1) ("throughput") was selected first: kernels that cost the fewest CU-microseconds, no side streams
+ *       (the side stream of smtts_cond_encode / smtts_sample belongs to the caller's stream — one per caller stream — so calls in
+ *       flight would not share it, but six streams for three batches run 20 % slower than three: profiles/r06j_ab_dual_tp.txt);
  *   (3) per-kernel profiling (smtts_profile_enable) is off: it assumes one call at a time.
  * Calls on one stream are ordered like any other work on that stream; results do not depend on what runs on the other streams
  * (tests/test_api_gpu.py::test_results_repeat_bit_for_bit_next_to_other_streams).
@@ -149,9 +150,9 @@ int smtts_resample_poly(smtts_handle h, void* stream, const float* x, int channe
 /* float [-1, 1] -> int16 PCM: clamp, x 32767, round to nearest (reference server audio.rs:22-37; CLIs write PCM_16, tryme.py:29) */
 int smtts_pcm16(smtts_handle h, void* stream, const float* x, int64_t n, int16_t* y);
 
-/* cond_encode runs the text encoder on an engine-owned side stream (fork / join with events; default on: shortest latency
- * for one batch at a time).  Callers that keep several batches in flight on their own streams should turn it off: the single
- * side stream would serialise the text encoders of all of them (16.2 -> 15.7 ms per batch at three in flight). */
+/* cond_encode runs the text encoder on a side stream owned by the engine, one per caller stream (fork / join with events; default
+ * on: shortest latency for one batch at a time).  Callers that keep several batches in flight on their own streams should turn it
+ * off (throughput tuning does): twice the streams cost more than the overlap buys (7.96 -> 9.59 ms per batch at three in flight). */
 int smtts_set_dual_stream(smtts_handle h, int on);
 /* Tuning mode: 0 = latency (default: one batch at a time finishes as early as possible: split-K on the small-M projections, deep
  * DMA rings, text encoder on the side stream), 1 = throughput (the caller keeps several independent batches in flight on its own

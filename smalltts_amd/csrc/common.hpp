@@ -165,10 +165,12 @@ __device__ __forceinline__ unsigned cvt_pk_f16_raw(float a, float b) {
 //     3    |        3.19e-4          |             2.3e-2               |              7.2e-3   (2^Q0 = 0.4971: a +0.29 % |x| bias at small |x|)
 //   (correctly rounded fp16 of the exact value: 2.12e-4 / 4.9e-4 / 4.9e-4.)
 // Round 5 shipped degree 3 (two of eleven VALU instructions per value pair fewer; 2-4 % of the VALU-bound kernels, 0.6 % of a batch);
-// its small-|x| bias is systematic, not noise, so the default is degree 4 since round 6: one instruction fewer than
-// degree 5 at degree-5 accuracy.  -DGELU_PK_DEG=3 / 5 remain as A/B builds.
+// its small-|x| bias is systematic, not noise.  Degree 4 has a POSITIVE leading coefficient: q(a) turns upward past
+// a ~ 12 and 2^q overflows for hidden values of a few hundred — NaN audio on the outlier weights of tests/test_range_guard_gpu.py
+// (certified bound 840) — so it would need a clamp of |x|, which costs the instruction it saves.  Degrees 5 and 3 end in a negative
+// coefficient (large |x| extrapolates to exactly max(x, 0)).  Default since round 6: degree 5.  -DGELU_PK_DEG=3 / 4 remain as A/B builds.
 #ifndef GELU_PK_DEG
-#define GELU_PK_DEG 4
+#define GELU_PK_DEG 5
 #endif
 struct GeluQ4 {   // minimax fit of a Phi(-a) = a 2^q(a) over a in [0, 9] (tests/studies/gelu_q5_fit.py fit(4)): |error| <= 2.0e-5 in exact arithmetic
     static constexpr float Q0 = -1.0013247728347778f, Q1 = -1.1435197591781616f, Q2 = -0.47347283363342285f, Q3 = -0.04111006110906601f,

@@ -68,6 +68,7 @@ Engine::Engine(int device) : device_(device) {
     if ((s = getenv("SMTTS_ATTN_EPI"))) attn_epi_ = atoi(s) != 0;
     if ((s = getenv("SMTTS_ATTN_IMG"))) attn_img_ = atoi(s) != 0;
     if ((s = getenv("SMTTS_LN_FOLD"))) ln_fold_ = atoi(s) != 0;
+    if ((s = getenv("SMTTS_LN_FOLD_TP"))) ln_fold_tp_ = atoi(s) != 0;
     if ((s = getenv("SMTTS_UP_G3_MINK")) && atoi(s) >= 64) up_g3_mink_ = atoi(s);
     if ((s = getenv("SMTTS_MIXER_WIDE"))) mixer_wide_ = atoi(s) != 0;
     if ((s = getenv("SMTTS_X2_MINK")) && atoi(s) >= 64) x2_mink_ = atoi(s);
@@ -102,7 +103,10 @@ void Engine::set_tuning(int mode) {
     if (mode == TUNE_THROUGHPUT) {
         if (tuning_ != TUNE_THROUGHPUT) dual_stream_latency_ = dual_stream_;
         tuning_ = TUNE_THROUGHPUT;
-        dual_stream_ = getenv("SMTTS_DUAL_TP") && atoi(getenv("SMTTS_DUAL_TP")) != 0;   // (A/B only: engine-owned side stream with batches in flight)
+        // (A/B only: side streams with batches in flight.  Round 6 gave every caller stream its OWN side stream — three batches in flight
+        // then drive six streams, and the batch goes from 7.96 to 9.59 ms (profiles/r06j_ab_dual_tp.txt): more streams than hardware
+        // queues serialise worse than one text encoder behind its style encoder.  Stays off.)
+        dual_stream_ = getenv("SMTTS_DUAL_TP") && atoi(getenv("SMTTS_DUAL_TP")) != 0;
         // Ring depth with batches in flight: round 2 measured shallow rings ahead (10.14 vs 10.38 ms: a workgroup holding 64-128 KiB
         // of LDS while it waits kept the other streams' kernels off its CU).  Re-measured at the end of round 3 — fp16 operand images,
         // shorter epilogues, persistent codec grids capped — deep rings win: 8.53 -> 8.42 ms (profiles/r03ag_*).
@@ -145,9 +149,11 @@ std::string Engine::profile_report() {
 Engine::~Engine() {
     if (g_prof == &prof_) g_prof = nullptr;
     (void)hipSetDevice(device_);
-    if (aux_) (void)hipStreamDestroy(aux_);
-    if (ev_fork_) (void)hipEventDestroy(ev_fork_);
-    if (ev_join_) (void)hipEventDestroy(ev_join_);
+    for (auto& kv : aux_sets_) {
+        if (kv.second.stream) (void)hipStreamDestroy(kv.second.stream);
+        if (kv.second.fork) (void)hipEventDestroy(kv.second.fork);
+        if (kv.second.join) (void)hipEventDestroy(kv.second.join);
+    }
     for (void* p : allocs_) (void)hipFree(p);
     for (void* p : pack_allocs_) (void)hipFree(p);
 }
@@ -835,7 +841,7 @@ static hipError_t gemm3_store_splitk(const Gemm3Operands& g0, float* partial, in
 // ---------------------------------------------------------------------------------------------
 namespace {
 struct EncWs {
-    float *x, *qkvg, *seq, *part;
+    float *x, *qkvg, *seq, *part, *lnpart;
     SplitBuf y, o, ffh, seqs;
     SplitBuf qi, ki, vti, gi;   // attention operand images (attention_img.hip): [B][H][S][dhp] x 2, [B][H][dhp][pad8(S)], [M][D]
     size_t vt_elems;
@@ -843,6 +849,7 @@ struct EncWs {
         const int Mx = B * S > 0 ? B * S : 1;
         x = b.take<float>((size_t)Mx * 512);
         part = b.take<float>((size_t)kSplitK * Mx * 512);
+        lnpart = b.take<float>((size_t)Mx * (512 / 32) * 2);
         qkvg = b.take<float>((size_t)Mx * 2048);
         seq = b.take<float>((size_t)Mx * kHidden);
         y = take_split(b, (size_t)Mx * 512);
@@ -871,6 +878,11 @@ int Engine::run_encoder(hipStream_t st, const EncoderW& e, void* wsv, int B, int
     unsigned* const se = satp(SITE_ENCODER);
     const SplitBuf y = w.y.as(pe, se), o = w.o.as(pe, se), ffh = w.ffh.as(pe, se);  // every activation here feeds a SITE_ENCODER GEMM
     HIPC(launch_rmsnorm(w.x, rd, nullptr, y.hi, y.lo, rd, M, D, e.eps, e.blocks[0].an, st));
+    // RMSNorm fold (gemm.hpp LnFoldIn, rms): the norm between two block GEMMs lives in their epilogues — the producer writes x w and the
+    // row's sum-of-squares partials, the consumer scales by rstd; the first norm (above) and the final one (feeds a plain projection) stay
+    const bool fold = ln_fold_now() && attn_img_ && attn_epi_ && D % 32 == 0;
+    LnFoldIn fin;
+    fin.part = w.lnpart; fin.NP = D / 32; fin.inv_c = 1.0f / D; fin.eps = e.eps; fin.rms = 1;
     for (size_t l = 0; l < e.blocks.size(); ++l) {
         const EncBlockW& b = e.blocks[l];
         const bool epi = attn_img_ && attn_epi_;   // the GEMM's own epilogue writes the attention operands
@@ -899,6 +911,7 @@ int Engine::run_encoder(hipStream_t st, const EncoderW& e, void* wsv, int B, int
             if (epi) {
                 EpiQKV eq{nullptr, pk.qw, pk.kw, pk.rope_cos, pk.rope_sin, pk.eps, pk.q_scale, pk.rot_dim, pa,
                           pk.q, pk.q_lo, pk.k, pk.k_lo, pk.vt, pk.vt_lo, pk.g, pk.g_lo, S, e.heads, e.dh, pk.dhp, Sp};
+                if (fold && l > 0) eq.fold = fin;   // w.y = x attention_norm.weight, written by the previous block's FF2 epilogue
                 HIPC(gemm3_qkv(ops3(w.y, rd, b.qkvg, M, pe), eq, pe, st));   // (both encoders' heads are 64 / 128 wide: no padding)
             } else {
                 HIPC(launch_qkv_pack(pk, st));
@@ -918,16 +931,23 @@ int Engine::run_encoder(hipStream_t st, const EncoderW& e, void* wsv, int B, int
         }
         EpiResid<0> r1{w.x, rd, nullptr, nullptr, 0, 0, 0, 1, nullptr};
         NextLN n1{b.mn, nullptr, y.hi, y.lo, true, e.eps};
-        if (ksplit_enc_ > 1) {
+        if (fold) {
+            EpiResidLN e1{w.x, rd, nullptr, nullptr, nullptr, b.mn, y.hi, y.lo, D, w.lnpart, D / 32, 1};
+            HIPC(gemm3_resid_ln(ops3(w.o, rd, b.wo, M, pe), e1, pe, st));
+        } else if (ksplit_enc_ > 1) {
             HIPC(gemm3_resid_splitk(ops3(w.o, rd, b.wo, M, pe), r1, w.part, ksplit_enc_, pe, st, n1));
         } else {
             HIPC(gemm3_resid(ops3(w.o, rd, b.wo, M, pe), 0, r1, pe, st));
             HIPC(launch_rmsnorm(w.x, rd, nullptr, y.hi, y.lo, rd, M, D, e.eps, n1.shift, st));
         }
         EpiSwiGLU sw{nullptr, e.ff, nullptr, nullptr, ffh.hi, ffh.lo};
+        if (fold) sw.fold = fin;
         HIPC(gemm3_swiglu(ops3(w.y, rd, b.ff13, M, pe), sw, pe, st));
         NextLN n2{l + 1 < e.blocks.size() ? e.blocks[l + 1].an : e.final_norm, nullptr, y.hi, y.lo, true, e.eps};
-        if (ksplit_enc_ > 1) {
+        if (fold && l + 1 < e.blocks.size()) {
+            EpiResidLN e2{w.x, rd, nullptr, nullptr, nullptr, e.blocks[l + 1].an, y.hi, y.lo, D, w.lnpart, D / 32, 1};
+            HIPC(gemm3_resid_ln(ops3(w.ffh, rowmap_plain(e.ff), b.w2, M, pe), e2, pe, st));
+        } else if (ksplit_enc_ > 1) {
             HIPC(gemm3_resid_splitk(ops3(w.ffh, rowmap_plain(e.ff), b.w2, M, pe), r1, w.part, ksplit_enc_, pe, st, n2));
         } else {
             HIPC(gemm3_resid(ops3(w.ffh, rowmap_plain(e.ff), b.w2, M, pe), 0, r1, pe, st));
@@ -951,11 +971,19 @@ size_t Engine::cond_ws_bytes(int B, int R, int P) const {
 // Side stream for the text-encoder half of cond_encode: forked from / joined into the caller's stream with
 // events, so the caller still sees a single-stream operator.  Both encoders are tiny-M launch chains (120 / 240
 // rows) that each fill a fraction of the chip; run side by side they overlap almost completely.
-int Engine::ensure_aux() {
-    if (aux_) return 0;
-    HIPC(hipStreamCreateWithFlags(&aux_, hipStreamNonBlocking));
-    HIPC(hipEventCreateWithFlags(&ev_fork_, hipEventDisableTiming));
-    HIPC(hipEventCreateWithFlags(&ev_join_, hipEventDisableTiming));
+// One side stream + event pair PER CALLER STREAM (round 6): a caller that keeps several batches in flight gives each its own stream, and
+// each of those forks onto its own side stream — the text encoders / modulation chains of batches in flight no longer queue behind one
+// another on a single engine-wide stream.  The set of the call being enqueued is installed in aux_ / ev_fork_ / ev_join_ (one host thread
+// enqueues one call at a time).
+int Engine::ensure_aux(hipStream_t st) {
+    AuxSet& a = aux_sets_[st];
+    if (!a.stream) {
+        if (aux_sets_.size() > 64) return fail("side streams: more than 64 caller streams on one engine");
+        HIPC(hipStreamCreateWithFlags(&a.stream, hipStreamNonBlocking));
+        HIPC(hipEventCreateWithFlags(&a.fork, hipEventDisableTiming));
+        HIPC(hipEventCreateWithFlags(&a.join, hipEventDisableTiming));
+    }
+    aux_ = a.stream; ev_fork_ = a.fork; ev_join_ = a.join;
     return 0;
 }
 
@@ -977,7 +1005,7 @@ int Engine::cond_encode(hipStream_t st, const float* ref, const int64_t* ref_len
     const bool fork = dual_stream_ && R > 0 && P > 0;
     hipStream_t stt = st;  // stream of the text half
     if (fork) {
-        if (ensure_aux()) return 1;
+        if (ensure_aux(st)) return 1;
         HIPC(hipEventRecord(ev_fork_, st));  // inputs produced on the caller's stream are visible to the side stream
         HIPC(hipStreamWaitEvent(aux_, ev_fork_, 0));
         stt = aux_;
@@ -1198,7 +1226,7 @@ int Engine::denoise_core(hipStream_t st, const float* x_t, const uint8_t* mask, 
     // LN-fold (gemm.hpp LnFoldIn): inside the fused sampler — one modulation row for the whole batch, tables from modulation() —
     // the AdaLN between two block GEMMs lives in their epilogues; the first AdaLN of a step (above) and the final one (velocity
     // head, SITE_COND precision) keep their ln_modulate
-    const bool fold = ln_fold_ && ftab && mod_rstride == 0 && attn_img_ && attn_epi_;
+    const bool fold = ln_fold_ && ftab && mod_rstride == 0 && attn_img_ && attn_epi_;   // (ftab: null under throughput tuning, see sample())
     const float* const mrow = mod + (long)mod_row0 * kModLd;            // this step's modulation row (fold path only)
     const float* const frow = fold ? ftab + (long)mod_row0 * 2 * kFoldNF : nullptr;   // [0]: W shift, [1]: W (1 + scale)
     auto fold_in = [&](int l, int site) {
@@ -1421,7 +1449,7 @@ size_t Engine::sample_ws_bytes(int B, int N, int R, int P, int n_steps, int cfg)
     SampleWs s;
     s.plan(b, B, N, n_steps, cfg);
     ModWs m;
-    m.plan(b, n_steps, ln_fold_);
+    m.plan(b, n_steps, ln_fold_now());
     return b.off + 256 + denoise_core_bytes(cfg ? 3 * B : B, N) + cross_img_bytes(cfg ? 3 * B : B, R, P);
 }
 
@@ -1439,7 +1467,7 @@ int Engine::sample(hipStream_t st, int mode, int n_steps, int cfg, float s_text,
     SampleWs s;
     s.plan(bump, B, N, n_steps, cfg);
     ModWs m;
-    m.plan(bump, n_steps, ln_fold_);
+    m.plan(bump, n_steps, ln_fold_now());
     char* core = static_cast<char*>(ws) + ((bump.off + 255) & ~size_t(255));
     const long e = (long)B * N * kLatent;
 
@@ -1463,7 +1491,7 @@ int Engine::sample(hipStream_t st, int mode, int n_steps, int cfg, float s_text,
         ~JoinGuard() { if (e->join_pending_) { (void)hipStreamWaitEvent(st, e->ev_join_, 0); e->join_pending_ = false; } }
     } join_guard{this, st};
     if (dual_stream_ && !prof_on_) {
-        if (ensure_aux()) return 1;
+        if (ensure_aux(st)) return 1;
         HIPC(hipEventRecord(ev_fork_, st));
         HIPC(hipStreamWaitEvent(aux_, ev_fork_, 0));
         const int mod_rc = modulation(aux_, s.ts, n_steps, m.sinb, m.t1, m.temb, m.e1, m.semb, m.mod, m.ftab);

@@ -4,8 +4,8 @@
 // Not thread-safe: one Engine per GPU, driven by one host thread (mirrors the reference's one-Session-per-pipeline model,
 // src/server/src/main.rs:24).  That thread may keep several operator calls in flight on DIFFERENT streams as long as each
 // call has its own workspace and outputs: all per-call scratch (incl. the rope cos / sin of a caller-supplied table) lives
-// in the workspace, weights are read-only after finalize().  Exceptions: the dual-stream condition encoder shares one side
-// stream + event pair (switch to throughput tuning first), and per-kernel profiling assumes one call at a time.
+// in the workspace, weights are read-only after finalize().  The dual-stream condition encoder / modulation chain forks onto a side
+// stream that belongs to the CALLER's stream (one per caller stream, round 6).  Exception: per-kernel profiling assumes one call at a time.
 #pragma once
 #include <initializer_list>
 #include <map>
@@ -270,9 +270,11 @@ class Engine {
                                            // a launch of these 600-row products is ~8 us of fixed cost whatever its k-loop (5 k-tiles at 3 slices), so the third
                                            // slice only adds a partial slab (a third of the fp32 slab traffic of the reduce kernel)
     bool dual_stream_ = true;  // cond_encode: text encoder on a side stream (SMTTS_SINGLE_STREAM=1 turns it off)
-    hipStream_t aux_ = nullptr;
+    struct AuxSet { hipStream_t stream = nullptr; hipEvent_t fork = nullptr, join = nullptr; };
+    std::map<hipStream_t, AuxSet> aux_sets_;   // side stream + fork / join events per caller stream (ensure_aux)
+    hipStream_t aux_ = nullptr;                // ... of the call being enqueued
     hipEvent_t ev_fork_ = nullptr, ev_join_ = nullptr;
-    int ensure_aux();
+    int ensure_aux(hipStream_t st);
     bool ws_ready_ = false, ws_keep_ = false;   // sample(): the denoiser workspace's never-written regions were zeroed by an earlier step of this call
     bool join_pending_ = false;   // sample(): the side stream's modulation table must be joined before the first AdaLN
     int num_cus_ = 256;
@@ -280,9 +282,15 @@ class Engine {
     bool attn_img_ = true;   // attention on producer-written operand images (attention_img.hip: DMA + MFMA only); false (SMTTS_ATTN_IMG=0, test hook) = fp32 projection + qk_prep + the fp32 VALU reference kernel (attention.hip)
     // LN-fold (round 6; gemm.hpp LnFoldIn): inside the fused sampler (one modulation row per step for the whole batch) the AdaLN in front
     // of the QKVG / FF1 products is folded into the producing out-proj / FF2 epilogue (operand image + row partials) and the consuming
-    // epilogue (mean / rstd correction): no ln_modulate launch in throughput tuning, no split-K partials + reduce in latency tuning —
-    // 5 launches per DiT block instead of 7 (SMTTS_LN_FOLD=0 / smtts_test_set_ln_fold restore the norm launches)
+    // epilogue (mean / rstd correction): no split-K partials + reduce launches in latency tuning — 5 launches per DiT block (and per
+    // encoder block: RMSNorm variant, no tables) instead of 7 (SMTTS_LN_FOLD=0 / smtts_test_set_ln_fold restore the norm launches)
     bool ln_fold_ = true;
+    // ... under THROUGHPUT tuning too.  Off: with batches in flight the DiT fold's per-call table kernel (fold_vectors: every block weight
+    // read once more, 205 MB = 80 us of the whole chip) costs more than the ln_modulate launches it replaces, and the encoders' unsplit
+    // 16-workgroup products no less than their split-K 4 + reduce pairs — measured (profiles/r06i_ab_fold.txt, three interleaved repeats):
+    // in flight 8.19 (off) / 8.22 (encoders only) / 8.26 (all) ms per batch, one at a time 11.77 -> 11.62 (SMTTS_LN_FOLD_TP=1: A/B)
+    bool ln_fold_tp_ = false;
+    bool ln_fold_now() const { return ln_fold_ && (tuning_ == TUNE_LATENCY || ln_fold_tp_); }
     bool attn_epi_ = true;   // ... written by the QKVG GEMM's own epilogue (gemm3 EpiQKV); false (SMTTS_ATTN_EPI=0): fp32 projection + qkv_pack kernel
     Profiler prof_;
     bool prof_on_ = false;

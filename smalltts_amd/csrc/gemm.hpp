@@ -41,6 +41,7 @@ __device__ __forceinline__ void split4(const float4& v, uint2& hi, uint2& lo) {
 
 #ifdef G3_TIMELINE   // debug build (tools/gemm3_timeline.py): wave 0 of every workgroup stamps the shader clock; one buffer per translation unit
 static __device__ unsigned long long g3_tl_buf[1024 * 160];
+static __device__ int g3_tl_skip_k;   // 1: no per-k-tile stamps (an s_memtime costs the one-wave-per-SIMD loop of the 64x64 tile as much as the k-tile itself)
 #define EPI_STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x < 1024) g3_tl_buf[blockIdx.x * 160 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define EPI_STAMP(i) do { } while (0)
@@ -232,8 +233,10 @@ struct LnFoldIn {
     const float* part = nullptr;   // [M][NP][2] (sum, sum of squares) per row and 32-column group; null = fold off (plain bias epilogue)
     int NP = 0;                    // groups per row (hidden / 32)
     float inv_c = 0.f, eps = 0.f;  // 1 / hidden, LayerNorm eps
-    const float* wc = nullptr;     // [N] W (1 + scale)
-    const float* wsh = nullptr;    // [N] W shift
+    const float* wc = nullptr;     // [N] W (1 + scale)        (null with rms)
+    const float* wsh = nullptr;    // [N] W shift              (null with rms)
+    int rms = 0;                   // 1: RMSNorm with weight w (the encoders, style.py:70-105 / phonemes.py:131-167): the image is x w, the consumer
+                                   //    only scales by rstd = 1 / sqrt(mean x^2 + eps) — no mean, no vectors
     const float* lstat = nullptr;  // set by the kernel: LDS table [BM][2] = (mu, rstd) of the tile's rows
     int m0 = 0;                    // set by the kernel: first row of the tile
 };
@@ -354,7 +357,8 @@ struct EpiStore {
 };
 
 // SwiGLU on interleaved [w1 | w3] 32-column groups: out[m][nh] = silu(a + b1[nh]) * (b + b3[nh])
-struct EpiSwiGLU {
+template <bool FOLD>   // FOLD: the LN-fold consumer code is compiled in (a separate instantiation: the plain kernels keep their registers)
+struct EpiSwiGLUT {
     static constexpr bool PAIRED = true;
     static constexpr bool STAGE16 = true;
     static constexpr bool TILE = false;
@@ -364,8 +368,8 @@ struct EpiSwiGLU {
     const float* b3;
     bf16_t* ohi;      // optional split output (see EpiStore)
     bf16_t* olo;
-    static constexpr bool FOLD_IN = true;
-    LnFoldIn fold;    // (gemm3 only) the operand is x (1 + scale), not LN(x) (1 + scale) + shift: see LnFoldIn
+    static constexpr bool FOLD_IN = FOLD;
+    LnFoldIn fold;    // (gemm3, FOLD only) the operand is x (1 + scale), not LN(x) (1 + scale) + shift: see LnFoldIn
     __device__ __forceinline__ void rows(int, int mb, int M, RowCtx& rc) const {
         rc.valid = 0;
 #pragma unroll
@@ -374,7 +378,7 @@ struct EpiSwiGLU {
             rc.off[r] = (long)m * ldo;
             rc.valid |= (m < M ? 1u : 0u) << r;
         }
-        if (fold.part) {
+        if (FOLD && fold.part) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int lr = epi_row(mb, r) - fold.m0;
@@ -386,16 +390,19 @@ struct EpiSwiGLU {
     // packed [w1 | w3] column indices of hidden unit nh (32-column groups interleaved: Engine swiglu_perm)
     __device__ __forceinline__ void fold_cols(int nh, float& c1, float& c3, float& v1, float& v3) const {
         const int p1 = (nh >> 5) * 64 + (nh & 31);
-        c1 = fold.wc[p1]; c3 = fold.wc[p1 + 32];
-        v1 += fold.wsh[p1]; v3 += fold.wsh[p1 + 32];
+        if (fold.wc) {   // (uniform; null for the RMSNorm fold)
+            c1 = fold.wc[p1]; c3 = fold.wc[p1 + 32];
+            v1 += fold.wsh[p1]; v3 += fold.wsh[p1 + 32];
+        }
     }
     __device__ __forceinline__ void col(int, int, const RowCtx&, const floatx16&) const {}
     __device__ __forceinline__ void colpair(int, int nh, const RowCtx& rc, const floatx16& a, const floatx16& b) const {
         float v1 = b1 ? b1[nh] : 0.f, v3 = b1 ? b3[nh] : 0.f;
         float c1 = 0.f, c3 = 0.f;
-        const bool fd = fold.part != nullptr;
+        const bool fd = FOLD && fold.part != nullptr;
         if (fd) fold_cols(nh, c1, c3, v1, v3);
-        epi_settle(v1); epi_settle(v3); epi_settle(c1); epi_settle(c3);
+        epi_settle(v1); epi_settle(v3);
+        if (FOLD) { epi_settle(c1); epi_settle(c3); }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             if (rc.valid >> r & 1) {
@@ -417,7 +424,7 @@ struct EpiSwiGLU {
     __device__ __forceinline__ void colpair16(int, int nh, const RowCtx& rc, const floatx16& a, const floatx16& b, unsigned short (&o)[16]) const {
         float v1 = b1 ? b1[nh] : 0.f, v3 = b1 ? b3[nh] : 0.f;
         float c1 = 0.f, c3 = 0.f;
-        const bool fd = fold.part != nullptr;
+        const bool fd = FOLD && fold.part != nullptr;
         if (fd) fold_cols(nh, c1, c3, v1, v3);
         const bool f16 = sm_is_f16(olo);
         unsigned sat = 0;
@@ -444,6 +451,9 @@ struct EpiSwiGLU {
         sat_note(sat, olo);
     }
 };
+
+using EpiSwiGLU = EpiSwiGLUT<false>;
+using EpiSwiGLUFold = EpiSwiGLUT<true>;
 
 // x[xmap(m) + n] += mask(m) * g(batch(m), n) * (acc + bias[n])
 //   GATE 0: g = 1      GATE 1: g = gate[(grow0 + batch*grstride) * gld + n]  (table holds tanh(gate) already,
@@ -522,14 +532,15 @@ struct EpiResidLN {
     float* x;
     RowMap xmap;
     const float* bias;       // may be null
-    const float* gate;       // [N]: tanh(gate) of this step (modulation-table row)
+    const float* gate;       // [N]: tanh(gate) of this step (modulation-table row); null: 1 (the encoders' plain residual)
     const uint8_t* rowmask;  // may be null: masked rows are left untouched
-    const float* nscale;     // [N]: scale of the AdaLN in front of the NEXT GEMM
+    const float* nscale;     // [N]: scale of the AdaLN in front of the NEXT GEMM (rms: the next RMSNorm's weight itself)
     bf16_t* yhi;             // that GEMM's operand image [M][yld] in the format (yhi, ylo) encode (common.hpp sm_lo_for)
     bf16_t* ylo;
     long yld;
     float* part;             // [M][NP][2]
     int NP;
+    int rms = 0;             // 1: the image is x nscale (RMSNorm weight), not x (1 + nscale)
     __device__ __forceinline__ void rows(int, int mb, int M, RowCtx& rc) const {
         rc.valid = 0;
         rc.mb = mb;
@@ -547,7 +558,7 @@ struct EpiResidLN {
     }
     __device__ __forceinline__ void col(int, int n, const RowCtx& rc, const floatx16& acc) const {
         float b = bias ? bias[n] : 0.f;
-        float g = gate[n], s1 = 1.0f + nscale[n];
+        float g = gate ? gate[n] : 1.0f, s1 = rms ? nscale[n] : 1.0f + nscale[n];
         float xv[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) xv[r] = x[rc.off[r] + n];   // (rows past M: row 0's, unused)
@@ -695,7 +706,8 @@ struct EpiConvPos {
 // all in the 16-bit operand format `prec`.  Same arithmetic, in the same order, as qkv_pack_kernel (attention_img.hip), which
 // tests/test_kernels_gpu.py holds it to bit for bit.
 // ------------------------------------------------------------------------------------------
-struct EpiQKV {
+template <bool FOLD>
+struct EpiQKVT {
     static constexpr bool PAIRED = false;
     static constexpr bool STAGE16 = false;
     static constexpr bool TILE = true;
@@ -707,8 +719,8 @@ struct EpiQKV {
     int rot_dim, prec;
     bf16_t *q, *q_lo, *k, *k_lo, *vt, *vt_lo, *g, *g_lo;
     int Nseq, H, dh, HW, Np;
-    static constexpr bool FOLD_IN = true;
-    LnFoldIn fold;                   // the operand is x (1 + scale), not the AdaLN output: see LnFoldIn
+    static constexpr bool FOLD_IN = FOLD;
+    LnFoldIn fold;                   // (FOLD only) the operand is x (1 + scale), not the AdaLN output: see LnFoldIn
     // (the generic column protocol is not used by this epilogue)
     __device__ __forceinline__ void rows(int, int, int, RowCtx&) const {}
     __device__ __forceinline__ void col(int, int, const RowCtx&, const floatx16&) const {}
@@ -731,9 +743,9 @@ struct EpiQKV {
                 for (int j = 0; j < TN; ++j) {
                     const int c = (wn * TN + j) * 32 + fr;
                     float bv = bias ? bias[n0 + c] : 0.f;
-                    if (fold.part) {   // (uniform) LN-fold: rstd (acc - mu wc) + W shift + bias
-                        const float cw = fold.wc[n0 + c];
-                        bv += fold.wsh[n0 + c];
+                    if (FOLD && fold.part) {   // (uniform) LN-fold: rstd (acc - mu wc) + W shift + bias
+                        float cw = 0.f;
+                        if (fold.wc) { cw = fold.wc[n0 + c]; bv += fold.wsh[n0 + c]; }
 #pragma unroll
                         for (int r = 0; r < 16; ++r) {
                             const int row = r32 + 4 * fh + (r & 3) + 8 * (r >> 2);
@@ -815,6 +827,9 @@ struct EpiQKV {
         }
     }
 };
+
+using EpiQKV = EpiQKVT<false>;
+using EpiQKVFold = EpiQKVT<true>;
 
 // C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
 template <int TM, int TN, class Epi>

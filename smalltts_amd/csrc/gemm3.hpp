@@ -30,9 +30,11 @@ struct Gemm3Operands {
 
 #ifdef G3_TIMELINE   // debug build (tools/gemm3_timeline.py): wave 0 of every workgroup stamps the shader clock around each k-tile's wait / barrier / MFMAs
 // (g3_tl_buf: gemm.hpp, one copy per translation unit — read through the unit's smtts_debug_read_timeline*)
-#define G3_STAMP(i) do { if (tid == 0 && blockIdx.x < 1024 && ((i) < 146 || (i) >= 150) && (i) < 160) g3_tl_buf[blockIdx.x * 160 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define G3_STAMPK(i) do { if (tid == 0 && blockIdx.x < 1024 && (i) < 146 && !g3_tl_skip_k) g3_tl_buf[blockIdx.x * 160 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)   // k-tiles 0 .. 35
+#define G3_STAMP(i) do { if (tid == 0 && blockIdx.x < 1024 && (i) < 160) g3_tl_buf[blockIdx.x * 160 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
 #define G3_STAMPR(i) do { if (tid == 0 && blockIdx.x < 1024) g3_tl_buf[blockIdx.x * 160 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)   // constant 100 MHz: calibrates the shader clock
 #else
+#define G3_STAMPK(i) do { } while (0)
 #define G3_STAMPR(i) do { } while (0)
 #define G3_STAMP(i) do { } while (0)
 #endif
@@ -238,7 +240,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm3_kernel(Gemm3Operands g, Epi
                 s1 = (s1 + v.x) + v.z;
                 s2 = (s2 + v.y) + v.w;
             }
-            const float mu = s1 * epi.fold.inv_c;
+            const float mu = epi.fold.rms ? 0.f : s1 * epi.fold.inv_c;
             const float var = fmaf(-mu, mu, s2 * epi.fold.inv_c);
             lstat[2 * tid] = mu;
             lstat[2 * tid + 1] = 1.0f / sqrtf((var > 0.f ? var : 0.f) + epi.fold.eps);
@@ -251,9 +253,9 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm3_kernel(Gemm3Operands g, Epi
             wait_vmcnt<(S - 2) * OPS + PFN>();
         else
             wait_vmcnt<0>();
-        G3_STAMP(2 + 4 * kt);          // own DMA pieces of k-tile kt landed
+        G3_STAMPK(2 + 4 * kt);          // own DMA pieces of k-tile kt landed
         __builtin_amdgcn_s_barrier();
-        G3_STAMP(3 + 4 * kt);          // everybody's did
+        G3_STAMPK(3 + 4 * kt);          // everybody's did
         const char* st = smem + (kt % S) * STAGE_LD;
         // Small latency-bound tiles (64x64: the DiT's N = 960 projections) issue every fragment read of the k-tile first, THEN the
         // next stage's DMAs (4 wave-instructions of ~60 cycles each, M0 dance included), then the MFMAs: the LDS latency of the
@@ -281,7 +283,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm3_kernel(Gemm3Operands g, Epi
                 }
             }
             if (kt + S - 1 < nk) issue(kt + S - 1);
-            G3_STAMP(4 + 4 * kt);          // fragment reads + next stage's DMAs issued
+            G3_STAMPK(4 + 4 * kt);          // fragment reads + next stage's DMAs issued
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
@@ -297,7 +299,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm3_kernel(Gemm3Operands g, Epi
                     }
         } else {
             if (kt + S - 1 < nk) issue(kt + S - 1);
-            G3_STAMP(4 + 4 * kt);          // next stage's DMAs issued
+            G3_STAMPK(4 + 4 * kt);          // next stage's DMAs issued
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) {
                 bf16x8 ah[TM], al[TM], bh[TN], bl[TN];
@@ -327,7 +329,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm3_kernel(Gemm3Operands g, Epi
 #ifdef G3_TIMELINE
         asm volatile("s_nop 0" :: "v"(acc[0][0][0]));   // (the stamp must not move above the MFMAs' issue)
 #endif
-        G3_STAMP(5 + 4 * kt);          // fragment reads + MFMAs of k-tile kt issued
+        G3_STAMPK(5 + 4 * kt);          // fragment reads + MFMAs of k-tile kt issued
     }
     G3_STAMP(150);
     if constexpr (Epi::TILE) {   // whole-workgroup epilogue through an fp32 LDS tile in the finished ring (EpiQKV)

@@ -3,6 +3,10 @@
 hipError_t gemm3_swiglu(const Gemm3Operands& g, const EpiSwiGLU& p, int split, hipStream_t st) {
     const int cfg = gemm3_pick_cfg(g.M, g.N, true, split != PREC_BF16X3);
     ProfScope ps(st, gemm3_prof_name(g, true, cfg, split, "swiglu"), gemm3_flops(g, 1), gemm3_bytes(g, 1, split, 2.0), gemm_bytes8d(g.N, g.K, (g.ksplit_tiles ? 1 : 1)));
+    if (p.fold.part) {   // LN-fold consumer: its own instantiations
+        const EpiSwiGLUFold q{p.out, p.ldo, p.b1, p.b3, p.ohi, p.olo, p.fold};
+        return gemm3_launch(g, q, 1, split, st, cfg);
+    }
     return gemm3_launch(g, p, 1, split, st, cfg);
 }
 hipError_t gemm3_kv(const Gemm3Operands& g, const EpiKV& p, int split, hipStream_t st) {

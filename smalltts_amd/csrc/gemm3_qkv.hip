@@ -4,14 +4,20 @@
 #include "gemm_ops.hpp"
 #include "prof.hpp"
 
-template <int SPLIT>
-static hipError_t qkv_go(const Gemm3Operands& g, const EpiQKV& p, bool big, bool deep, hipStream_t st) {
+template <int SPLIT, class E>
+static hipError_t qkv_go(const Gemm3Operands& g, const E& p, bool big, bool deep, hipStream_t st) {
     if (big) {   // many rows (the teacher's 3B-row CFG batches): 128x128 tiles, 32x64 wave tiles
-        if (deep) return gemm3_launch_cfg<128, 128, 4, 2, SPLIT, SPLIT == 3 ? 2 : 4, EpiQKV>(g, p, 1, st);
-        return gemm3_launch_cfg<128, 128, 4, 2, SPLIT, 2, EpiQKV>(g, p, 1, st);
+        if (deep) return gemm3_launch_cfg<128, 128, 4, 2, SPLIT, SPLIT == 3 ? 2 : 4, E>(g, p, 1, st);
+        return gemm3_launch_cfg<128, 128, 4, 2, SPLIT, 2, E>(g, p, 1, st);
     }
-    if (deep) return gemm3_launch_cfg<64, 128, 2, 4, SPLIT, SPLIT == 3 ? 3 : 6, EpiQKV>(g, p, 1, st);
-    return gemm3_launch_cfg<64, 128, 2, 4, SPLIT, 3, EpiQKV>(g, p, 1, st);
+    if (deep) return gemm3_launch_cfg<64, 128, 2, 4, SPLIT, SPLIT == 3 ? 3 : 6, E>(g, p, 1, st);
+    return gemm3_launch_cfg<64, 128, 2, 4, SPLIT, 3, E>(g, p, 1, st);
+}
+template <class E>
+static hipError_t qkv_split(const Gemm3Operands& g, const E& p, int split, bool big, bool deep, hipStream_t st) {
+    if (split == PREC_BF16X3) return qkv_go<3>(g, p, big, deep, st);
+    if (split == PREC_F16) return qkv_go<2>(g, p, big, deep, st);
+    return qkv_go<1>(g, p, big, deep, st);
 }
 
 hipError_t gemm3_qkv(const Gemm3Operands& g_in, const EpiQKV& p, int split, hipStream_t st) {
@@ -30,7 +36,10 @@ hipError_t gemm3_qkv(const Gemm3Operands& g_in, const EpiQKV& p, int split, hipS
     ProfScope ps(st, gemm3_prof_name(g, false, big ? G3_128x128 : G3_64x128, split, "qkv_img"), 2.0 * g.M * (double)g.N * g.K,
                  (split == 3 ? 4.0 : 2.0) * ((double)g.M * g.K + (double)g.N * g.K) + (p.prec == PREC_BF16X3 ? 4.0 : 2.0) * g.M * (double)g.N,
                  gemm_bytes8d(4 * p.H * p.dh, g.K, 1));
-    if (split == PREC_BF16X3) return qkv_go<3>(g, p, big, deep, st);
-    if (split == PREC_F16) return qkv_go<2>(g, p, big, deep, st);
-    return qkv_go<1>(g, p, big, deep, st);
+    if (p.fold.part) {   // LN-fold consumer: its own instantiations
+        const EpiQKVFold q{p.bias, p.qw, p.kw, p.rope_cos, p.rope_sin, p.eps, p.q_scale, p.rot_dim, p.prec, p.q, p.q_lo, p.k, p.k_lo, p.vt, p.vt_lo,
+                           p.g, p.g_lo, p.Nseq, p.H, p.dh, p.HW, p.Np, p.fold};
+        return qkv_split(g, q, split, big, deep, st);
+    }
+    return qkv_split(g, p, split, big, deep, st);
 }

@@ -17,7 +17,7 @@ hipError_t gemm3_resid(const Gemm3Operands& g, int gate_mode, const EpiResid<0>&
 // the DiT's gated-residual projections with the LN-fold producer epilogue (gemm.hpp EpiResidLN): the residual row, the next GEMM's
 // operand image and the row partials in one pass — no split-K partials, no norm launch
 hipError_t gemm3_resid_ln(const Gemm3Operands& g, const EpiResidLN& p, int split, hipStream_t st, int cfg) {
-    if (g.N % 32 || p.NP != g.N / 32 || !p.part || !p.yhi || !p.nscale || !p.gate) return hipErrorInvalidValue;
+    if (g.N % 32 || p.NP != g.N / 32 || !p.part || !p.yhi || !p.nscale) return hipErrorInvalidValue;
     ProfScope ps(st, gemm3_prof_name(g, false, cfg, split, "resid_ln"), gemm3_flops(g, 1), gemm3_bytes(g, 1, split, 8.0 + (sm_is_split(p.ylo) ? 4.0 : 2.0)),
                  gemm_bytes8d(g.N, g.K, 1));
     return gemm3_launch(g, p, 1, split, st, cfg);
@@ -27,6 +27,7 @@ hipError_t gemm3_resid_ln(const Gemm3Operands& g, const EpiResidLN& p, int split
 extern "C" int smtts_debug_read_timeline_resid(unsigned long long* host, int n) {
     return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g3_tl_buf), (size_t)n * 8);
 }
+extern "C" int smtts_debug_timeline_resid_skip_k(int on) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(g3_tl_skip_k), &on, sizeof on); }
 extern "C" int smtts_debug_clear_timeline_resid(void) {
     void* p = nullptr;
     if (hipGetSymbolAddress(&p, HIP_SYMBOL(g3_tl_buf)) != hipSuccess) return 1;

@@ -300,6 +300,9 @@ def test_packed_fp16_gelu_of_the_default_degree_is_relatively_accurate_at_small_
     body = re.search(r"struct GeluQ%d \{(.*?)\};" % deg, src, re.S).group(1)
     c = [float(v) for v in re.findall(r"Q\d = (-?[0-9.e-]+)f", body)]
     assert len(c) == deg + 1 and abs(2.0 ** c[0] - 0.5) < 5e-4          # gelu(x) -> x / 2 at small |x|: no fixed-fraction bias
+    assert c[-1] < 0     # negative leading coefficient: 2^q -> 0 for large |x| (degree 4 ends positive: 2^q overflows past |x| ~ 20, NaN audio)
+    big = torch.tensor([30.0, -30.0, 800.0, -800.0, 60000.0, -60000.0])
+    assert torch.equal(gelu_pk_f16_deg(c)(big), torch.clamp_min(big.to(torch.float16).float(), 0))
     g = gelu_pk_f16_deg(c)
     x = torch.linspace(-12, 12, 400001)
     exact = 0.5 * x.double() * (1 + torch.erf(x.double() / np.sqrt(2)))
