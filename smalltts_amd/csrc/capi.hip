@@ -186,6 +186,9 @@ int smtts_test_attention(smtts_handle h, void* stream, const float* qkvg, const 
                          const float* rope, int rot_dim, const float* k_ref, const float* v_ref, int R,
                          const float* k_text, const float* v_text, int P, const uint8_t* mask_self,
                          const uint8_t* mask_ref, const uint8_t* mask_text, int B, int N, int H, int dh, float* out) { NULLCHK;
+#ifndef SMTTS_TEST_KERNELS
+    return E.fail("smtts_test_attention: the fp32 VALU reference attention is not part of this build (make TEST_KERNELS=1)");
+#else
     AttnArgs a{};
     const int D = H * dh;
     a.q = qkvg; a.k = qkvg + D; a.v = qkvg + 2 * D; a.gate = qkvg + 3 * D;
@@ -206,6 +209,7 @@ int smtts_test_attention(smtts_handle h, void* stream, const float* qkvg, const 
     (void)hipFree(rc);
     (void)hipFree(rs);
     return e == hipSuccess ? 0 : E.fail_hip(e, "attention");
+#endif
 }
 
 int smtts_test_attention_mfma(smtts_handle h, void* stream, const float* qkvg, const float* qw, const float* kw, float eps,

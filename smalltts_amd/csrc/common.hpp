@@ -18,6 +18,19 @@ typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
 typedef float f32x2_t __attribute__((ext_vector_type(2)));
 
 #define SMTTS_WAVE 64
+// Environment switches.  A shipped library reads TEN (SMTTS_ATTN_EPI, _GEMM_DEEP, _GEMM_GROUP, _GEMM_XCD, _LN_FOLD,
+// _MIXER_STREAM, _MIXER_WIDE, _PERSIST_CUS, _SINGLE_STREAM, _STAGE_CHAIN: each selects between two product paths that
+// tests/test_codec_gpu.py / test_kernels_gpu.py hold to each other).  Every other switch belongs to the A/B sessions under tools/ and is
+// seen only by a lab build (make LAB=1 -> -DSMTTS_LAB): a stray variable cannot put the product into an unmeasured configuration.
+#include <cstdlib>
+static inline const char* lab_env(const char* name) {
+#ifdef SMTTS_LAB
+    return getenv(name);
+#else
+    (void)name;
+    return nullptr;
+#endif
+}
 
 // One-time launch setup PER DEVICE: hipFuncSetAttribute(MaxDynamicSharedMemorySize) and the CU count belong to a device, and a
 // process may hold engines on several (smtts_create(device_id)).  Thread-safe: the bit is published after the setup

@@ -49,33 +49,33 @@ thread_local int g_prof_shapes = 0;
 static int g_small_m_splitk = 1;   // SMTTS_SMALLM_SPLITK=0: A/B switch for the K-sliced small-M products of the codec
 Engine::Engine(int device) : device_(device) {
     set_precision(kDefaultPrecision);
-    if (const char* nf = getenv("SMTTS_GEMM_NFAST")) g_gemm3_nfast = atoi(nf);
+    if (const char* nf = lab_env("SMTTS_GEMM_NFAST")) g_gemm3_nfast = atoi(nf);
     if (const char* gg = getenv("SMTTS_GEMM_GROUP")) g_gemm3_group = atoi(gg);
     if (const char* gx = getenv("SMTTS_GEMM_XCD")) g_gemm_xcd = atoi(gx);
     if (const char* pc = getenv("SMTTS_PERSIST_CUS")) persist_cus_tp_ = atoi(pc);
-    if (const char* pm = getenv("SMTTS_PERSIST_MASK")) g_persist_mask = atoi(pm);
+    if (const char* pm = lab_env("SMTTS_PERSIST_MASK")) g_persist_mask = atoi(pm);
     if (const char* dp = getenv("SMTTS_GEMM_DEEP")) gemm_deep_ = atoi(dp);
-    if (const char* s16 = getenv("SMTTS_GEMM_STAGE16")) g_gemm3_stage16 = atoi(s16);
-    if (const char* w4 = getenv("SMTTS_GEMM_W4_MINM")) g_gemm3_w4_minm = atoi(w4);
-    if (const char* t1 = getenv("SMTTS_GEMM_T160")) g_gemm3_t160 = atoi(t1);
+    if (const char* s16 = lab_env("SMTTS_GEMM_STAGE16")) g_gemm3_stage16 = atoi(s16);
+    if (const char* w4 = lab_env("SMTTS_GEMM_W4_MINM")) g_gemm3_w4_minm = atoi(w4);
+    if (const char* t1 = lab_env("SMTTS_GEMM_T160")) g_gemm3_t160 = atoi(t1);
     const char* s = getenv("SMTTS_SINGLE_STREAM");
     if (s && *s == '1') dual_stream_ = false;
-    if ((s = getenv("SMTTS_BLOCK_WAVE"))) block_wave_ = atoi(s) != 0;
+    if ((s = lab_env("SMTTS_BLOCK_WAVE"))) block_wave_ = atoi(s) != 0;
     if ((s = getenv("SMTTS_STAGE_CHAIN"))) stage_chain_ = atoi(s) != 0;
-    if ((s = getenv("SMTTS_CHAIN_MIN"))) chain_min_blocks_ = atoi(s);
-    if ((s = getenv("SMTTS_SMALLM_SPLITK"))) g_small_m_splitk = atoi(s);
-    if ((s = getenv("SMTTS_CONVPOS_BY_GROUP"))) convpos_by_group_ = atoi(s) != 0;
+    if ((s = lab_env("SMTTS_CHAIN_MIN"))) chain_min_blocks_ = atoi(s);
+    if ((s = lab_env("SMTTS_SMALLM_SPLITK"))) g_small_m_splitk = atoi(s);
+    if ((s = lab_env("SMTTS_CONVPOS_BY_GROUP"))) convpos_by_group_ = atoi(s) != 0;
     if ((s = getenv("SMTTS_ATTN_EPI"))) attn_epi_ = atoi(s) != 0;
-    if ((s = getenv("SMTTS_ATTN_IMG"))) attn_img_ = atoi(s) != 0;
+    if ((s = lab_env("SMTTS_ATTN_IMG"))) attn_img_ = atoi(s) != 0;
     if ((s = getenv("SMTTS_LN_FOLD"))) ln_fold_ = atoi(s) != 0;
-    if ((s = getenv("SMTTS_LN_FOLD_TP"))) ln_fold_tp_ = atoi(s) != 0;
-    if ((s = getenv("SMTTS_UP_G3_MINK")) && atoi(s) >= 64) up_g3_mink_ = atoi(s);
+    if ((s = lab_env("SMTTS_LN_FOLD_TP"))) ln_fold_tp_ = atoi(s) != 0;
+    if ((s = lab_env("SMTTS_UP_G3_MINK")) && atoi(s) >= 64) up_g3_mink_ = atoi(s);
     if ((s = getenv("SMTTS_MIXER_WIDE"))) mixer_wide_ = atoi(s) != 0;
-    if ((s = getenv("SMTTS_X2_MINK")) && atoi(s) >= 64) x2_mink_ = atoi(s);
-    if ((s = getenv("SMTTS_X2_MAXK")) && atoi(s) >= 64) x2_maxk_ = atoi(s);
-    if ((s = getenv("SMTTS_KSPLIT_OUT")) && atoi(s) >= 1 && atoi(s) <= kSplitK) ksplit_out_ = atoi(s);
-    if ((s = getenv("SMTTS_KSPLIT_ENC")) && atoi(s) >= 1 && atoi(s) <= kSplitK) ksplit_enc_ = atoi(s);
-    if ((s = getenv("SMTTS_KSPLIT_FF2")) && atoi(s) >= 1 && atoi(s) <= kSplitK) ksplit_ff2_ = atoi(s);
+    if ((s = lab_env("SMTTS_X2_MINK")) && atoi(s) >= 64) x2_mink_ = atoi(s);
+    if ((s = lab_env("SMTTS_X2_MAXK")) && atoi(s) >= 64) x2_maxk_ = atoi(s);
+    if ((s = lab_env("SMTTS_KSPLIT_OUT")) && atoi(s) >= 1 && atoi(s) <= kSplitK) ksplit_out_ = atoi(s);
+    if ((s = lab_env("SMTTS_KSPLIT_ENC")) && atoi(s) >= 1 && atoi(s) <= kSplitK) ksplit_enc_ = atoi(s);
+    if ((s = lab_env("SMTTS_KSPLIT_FF2")) && atoi(s) >= 1 && atoi(s) <= kSplitK) ksplit_ff2_ = atoi(s);
     int cus = 0;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) num_cus_ = cus;
     // three quarters of the CUs, in whole rounds of the 32 shader engines the dispatcher deals workgroups to (measured in flight,
@@ -106,11 +106,11 @@ void Engine::set_tuning(int mode) {
         // (A/B only: side streams with batches in flight.  Round 6 gave every caller stream its OWN side stream — three batches in flight
         // then drive six streams, and the batch goes from 7.96 to 9.59 ms (profiles/r06j_ab_dual_tp.txt): more streams than hardware
         // queues serialise worse than one text encoder behind its style encoder.  Stays off.)
-        dual_stream_ = getenv("SMTTS_DUAL_TP") && atoi(getenv("SMTTS_DUAL_TP")) != 0;
+        dual_stream_ = lab_env("SMTTS_DUAL_TP") && atoi(lab_env("SMTTS_DUAL_TP")) != 0;
         // Ring depth with batches in flight: round 2 measured shallow rings ahead (10.14 vs 10.38 ms: a workgroup holding 64-128 KiB
         // of LDS while it waits kept the other streams' kernels off its CU).  Re-measured at the end of round 3 — fp16 operand images,
         // shorter epilogues, persistent codec grids capped — deep rings win: 8.53 -> 8.42 ms (profiles/r03ag_*).
-        gemm_deep_ = getenv("SMTTS_GEMM_DEEP_TP") ? atoi(getenv("SMTTS_GEMM_DEEP_TP")) : 1;
+        gemm_deep_ = getenv("SMTTS_GEMM_DEEP") ? atoi(getenv("SMTTS_GEMM_DEEP")) : 1;
         persist_cus_ = persist_cus_tp_;
     } else {
         if (tuning_ == TUNE_THROUGHPUT) dual_stream_ = dual_stream_latency_;
@@ -477,6 +477,7 @@ int Engine::finalize_dit() {
         for (int h = 0; h < kHeads; ++h)
             for (int d = 0; d < kDh; ++d) hperm[(part * kHeads + h) * 128 + d] = part * kHidden + h * kDh + d;
     blocks_.clear();
+    qkvg_unpadded_ready_ = false;
     for (int i = 0; i < kBlocks; ++i) {
         std::string p = sidx(T, i, "");
         DitBlockW b;
@@ -925,9 +926,13 @@ int Engine::run_encoder(hipStream_t st, const EncoderW& e, void* wsv, int B, int
             ai.B = B; ai.N = S; ai.H = e.heads; ai.dh = e.dh; ai.Np = Sp;
             HIPC(launch_attention_img(ai, st));
         } else {
+#ifdef SMTTS_TEST_KERNELS   // the fp32 VALU reference attention (attention.hip): test builds only
             a.prenormed = 1;
             HIPC(launch_qk_prep(a, st));
             HIPC(launch_attention(a, st));
+#else
+            return fail("the fp32 VALU reference attention is not part of this build (make TEST_KERNELS=1)");
+#endif
         }
         EpiResid<0> r1{w.x, rd, nullptr, nullptr, 0, 0, 0, 1, nullptr};
         NextLN n1{b.mn, nullptr, y.hi, y.lo, true, e.eps};
@@ -1219,7 +1224,7 @@ int Engine::denoise_core(hipStream_t st, const float* x_t, const uint8_t* mask, 
     // sampler (M = 1800: 435 tiles) fill it without, and the fused epilogue is cheaper than partials + reduce (495 -> 454 ms)
     // ... and so do several batches in flight (throughput tuning): there the unsplit GEMM + a separate AdaLN costs 2.3x fewer
     // workgroup-microseconds than three K slices + reduce, and that is what counts when other streams want the CUs
-    static const bool splitk_tp = getenv("SMTTS_SPLITK_TP") && atoi(getenv("SMTTS_SPLITK_TP")) != 0;   // (A/B only)
+    static const bool splitk_tp = lab_env("SMTTS_SPLITK_TP") && atoi(lab_env("SMTTS_SPLITK_TP")) != 0;   // (A/B only)
     const bool unsplit = M > 1024 || (tuning_ == TUNE_THROUGHPUT && !splitk_tp);
     const int ks_out = unsplit ? 1 : ksplit_out_, ks_ff2 = unsplit ? 1 : ksplit_ff2_;
     if (!(attn_img_ && attn_epi_) && ensure_qkvg_unpadded()) return 1;
@@ -1290,9 +1295,13 @@ int Engine::denoise_core(hipStream_t st, const float* x_t, const uint8_t* mask, 
             ai.B = B; ai.N = N; ai.H = kHeads; ai.dh = kDh; ai.Np = Np; ai.R = R; ai.P = P; ai.Rp = ci.Rp; ai.Cp = ci.Cp;
             HIPC(launch_attention_img(ai, st));
         } else {
+#ifdef SMTTS_TEST_KERNELS   // the fp32 VALU reference attention (attention.hip): test builds only
             a.prenormed = 1;
             HIPC(launch_qk_prep(a, st));
             HIPC(launch_attention(a, st));
+#else
+            return fail("the fp32 VALU reference attention is not part of this build (make TEST_KERNELS=1)");
+#endif
         }
         // to_out + mask + gated residual (dit.py:117-118,198), then the MLP AdaLN (dit.py:199)
         EpiResid<0> r1{w.x, rh, nullptr, m + 2 * kHidden, kModLd, mod_row0, mod_rstride, N, mask};
@@ -1339,15 +1348,22 @@ int Engine::denoise_core(hipStream_t st, const float* x_t, const uint8_t* mask, 
 // The unpadded QKVG pack of the DiT blocks, read by the A/B attention paths only: packed when one of them first runs (a test hook
 // can flip the path after finalize), from the fp32 tensors that stay resident.  Synchronises the device: never on the product path.
 int Engine::ensure_qkvg_unpadded() {
-    if (blocks_.empty() || blocks_[0].qkvg.N) return 0;
+    if (blocks_.empty() || qkvg_unpadded_ready_) return 0;
     HIPC(hipDeviceSynchronize());
     struct PackMode { bool& f; bool old; explicit PackMode(bool& b) : f(b), old(b) { f = true; } ~PackMode() { f = old; } } pm(packing_);
     for (DitBlockW& b : blocks_) {
+        if (b.qkvg.N) continue;   // (packed by finalize_dit when an A/B path was selected before it)
         b.qkvg = pack_rows({b.name + ".attn.to_q.weight", b.name + ".attn.to_k_self.weight", b.name + ".attn.to_v_self.weight",
                             b.name + ".attn.gate.weight"});
-        if (!b.qkvg.N) return fail("DiT block " + b.name + ": unpadded QKVG pack failed (" + err_ + ")");
+        if (!b.qkvg.N) {
+            // a block failed (out of memory): nothing half-built may look finished to the next call — the packs made so far stay in
+            // pack_allocs_ (freed by the next finalize) but are unlinked, and the flag stays down
+            for (DitBlockW& c : blocks_) c.qkvg = PW();
+            return fail("DiT block " + b.name + ": unpadded QKVG pack failed (" + err_ + ")");
+        }
     }
     HIPC(hipDeviceSynchronize());
+    qkvg_unpadded_ready_ = true;
     return 0;
 }
 
@@ -1449,7 +1465,7 @@ size_t Engine::sample_ws_bytes(int B, int N, int R, int P, int n_steps, int cfg)
     SampleWs s;
     s.plan(b, B, N, n_steps, cfg);
     ModWs m;
-    m.plan(b, n_steps, ln_fold_now());
+    m.plan(b, n_steps, ln_fold_now() && (long)(cfg ? 3 * B : B) * N <= kFoldMaxRows);
     return b.off + 256 + denoise_core_bytes(cfg ? 3 * B : B, N) + cross_img_bytes(cfg ? 3 * B : B, R, P);
 }
 
@@ -1467,7 +1483,10 @@ int Engine::sample(hipStream_t st, int mode, int n_steps, int cfg, float s_text,
     SampleWs s;
     s.plan(bump, B, N, n_steps, cfg);
     ModWs m;
-    m.plan(bump, n_steps, ln_fold_now());
+    // (the fold replaces split-K partials + reduce; the 3B-row CFG batches of the teacher run unsplit + ln_modulate already, and there
+    // the table kernel — every block weight once per four steps — and the heavier epilogue cost more than the norm launches: 239.0 vs
+    // 240.6 ms per 128-step batch, profiles/r06l_ab_teacher_fold.txt)
+    m.plan(bump, n_steps, ln_fold_now() && (long)(cfg ? 3 * B : B) * N <= kFoldMaxRows);
     char* core = static_cast<char*>(ws) + ((bump.off + 255) & ~size_t(255));
     const long e = (long)B * N * kLatent;
 
@@ -1977,7 +1996,11 @@ int Engine::test_swiglu(hipStream_t st, const float* A, const float* W1, const f
     PW w;
     w.hi = hi; w.lo = lo; w.N = 2 * F; w.K = K;
     EpiSwiGLU sw{out, F, b1, b3, nullptr, nullptr};
+#ifdef SMTTS_TEST_KERNELS
     hipError_t e = gemm_swiglu(ops(A, rowmap_plain(K), w, M), sw, split, st);
+#else
+    hipError_t e = hipErrorNotSupported;   // (the v1 SwiGLU instantiations are test kernels: make TEST_KERNELS=1)
+#endif
     (void)hipStreamSynchronize(st);
     (void)hipFree(cat); (void)hipFree(dperm); (void)hipFree(hi); (void)hipFree(lo);
     return e == hipSuccess ? 0 : fail_hip(e, "test_swiglu");
@@ -2039,7 +2062,9 @@ int Engine::bench_gemm(int M, int N, int K, int epi, int split, int cfg, int ite
         switch (epi) {
             case 0: return gemm_store(g, ACT_NONE, store_to(C, rowmap_plain(N), bias), 1, split, 0, cfg);
             case 1: return gemm_store(g, ACT_GELU, store_to(C, rowmap_plain(N), bias), 1, split, 0, cfg);
+#ifdef SMTTS_TEST_KERNELS
             case 2: { EpiSwiGLU sw{C, N / 2, bias, bias, nullptr, nullptr}; return gemm_swiglu(g, sw, split, 0); }
+#endif
             default: { EpiResid<0> r{C, rowmap_plain(N), bias, gate, 0, 0, 0, M, nullptr}; return gemm_resid(g, 1, r, split, 0, cfg); }
         }
     };

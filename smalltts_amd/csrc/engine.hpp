@@ -226,6 +226,7 @@ class Engine {
     size_t denoise_core_bytes(int B, int N) const;
     // runs one block; the result lives in *x on return (the fused mixer ping-pongs *x <-> *xalt)
     int ensure_qkvg_unpadded();   // packs DitBlockW::qkvg of every block on first use of an A/B attention path
+    bool qkvg_unpadded_ready_ = false;   // ... set only after EVERY block packed (a failure half-way unlinks what was built)
     int codec_stage_chain(hipStream_t st, const CodecStageW& sg, float** x, float** xalt, int B, int T, int C);
     int codec_block(hipStream_t st, const CodecBlockW& w, float** x, float** xalt, float* nbuf, bf16_t* n2hi, bf16_t* n2lo,
                     bf16_t* hhi, bf16_t* hlo, int B, int T, int C, size_t n2_elems /* capacity of n2hi (bf16 elements) */);
@@ -322,4 +323,5 @@ static constexpr int kConvK = 31, kConvG = 16, kConvCpg = 60, kConvPad = 15, kCo
 static constexpr int kCodecPad = 8;
 static constexpr long kFoldPerBlock = 4L * kHeads * 128 + 2L * kFF;   // LN-fold table columns of one block: padded QKVG rows | interleaved [w1 | w3] rows
 static constexpr long kFoldNF = kBlocks * kFoldPerBlock;              // 106752
+static constexpr long kFoldMaxRows = 1024;                            // LN-fold of the DiT blocks up to this many rows (above: unsplit GEMM + ln_modulate, as before)
 static constexpr int kLnGroups = kHidden / 32;                        // row partials per residual row

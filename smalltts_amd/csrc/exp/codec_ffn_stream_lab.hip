@@ -55,12 +55,31 @@ struct FfnStreamArgs {
 // ---------------------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ unsigned cvt_pk_bf16s(float a, float b) { return cvt_pk_bf16(a, b); }
 
+#ifdef FS_TIMELINE   // debug build (tools/ffn_stream_timeline.py): wave 0 of every workgroup stamps the shader clock through its first FS_TL_PASSES
+                     // passes — into LDS (a global store per stamp would join the counted vmcnt waits of the ring), dumped when the kernel ends
+#define FS_TL_PASSES 3
+#define FS_TL_N 160
+static __device__ unsigned long long fs_tl_buf[256 * FS_TL_PASSES * FS_TL_N];
+#define FS_STAMP(i) do { if (tid == 0 && p < FS_TL_PASSES) tl[p * FS_TL_N + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define FS_STAMPR(i) do { if (tid == 0 && p < FS_TL_PASSES) tl[p * FS_TL_N + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+extern "C" int smtts_debug_read_fs_timeline(unsigned long long* host, int n) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(fs_tl_buf), (size_t)n * 8);
+}
+extern "C" int smtts_debug_clear_fs_timeline(void) {
+    void* q = nullptr;
+    if (hipGetSymbolAddress(&q, HIP_SYMBOL(fs_tl_buf)) != hipSuccess) return 1;
+    return (int)hipMemset(q, 0, sizeof(unsigned long long) * 256 * FS_TL_PASSES * FS_TL_N);
+}
+#else
+#define FS_STAMP(i) do { } while (0)
+#define FS_STAMPR(i) do { } while (0)
+#endif
 
 // (Round 4 measured a variant that takes the first product's operand from the mixer — fp16 rows by LDS-DMA into a wave-private tile, one
 // pass ahead, no fp32 tile at the top of the pass: FFN 282 -> 268 us (C = 128) and 242 -> 222 us (C = 256), but the mixer that has to
 // write those rows 121 -> 163 and 73 -> 93 us — a net loss, and the per-pass timeline shows why the FFN gains so little: the wait only
 // moves to the residual re-read, which was an L2 hit behind the top-of-pass load and is a cold HBM read without it.  Commit aefe457,
-// profiles/r04k_*; the instrumented / elimination builds live in exp/codec_ffn_stream_lab.hip: make LAB=1, tools/ffn_stream_timeline.py.)
+// profiles/r04k_*; tools/ffn_stream_timeline.py + -DFS_TIMELINE is the instrumentation.)
 template <int C, int SPLIT, int NW, int S>
 __global__ __launch_bounds__(NW * 64) void codec_ffn_stream_kernel(FfnStreamArgs a) {
     constexpr int F = 4 * C;
@@ -97,6 +116,10 @@ __global__ __launch_bounds__(NW * 64) void codec_ffn_stream_kernel(FfnStreamArgs
     float* vb2 = vb1 + F;
     float* vga = vb2 + C;
     float* vnw = vga + C;
+#ifdef FS_TIMELINE
+    unsigned long long* tl = reinterpret_cast<unsigned long long*>(vnw + C);
+    for (int i = tid; i < FS_TL_PASSES * FS_TL_N; i += NW * 64) tl[i] = 0;
+#endif
     for (int i = tid; i < F; i += NW * 64) vb1[i] = a.b1[i];
     for (int i = tid; i < C; i += NW * 64) { vb2[i] = a.b2[i]; vga[i] = a.gamma[i]; vnw[i] = a.norm_w[i]; }
 
@@ -148,6 +171,13 @@ __global__ __launch_bounds__(NW * 64) void codec_ffn_stream_kernel(FfnStreamArgs
         }
     };
 
+#ifdef FS_PHASE_TICKS   // (A/B builds: with two 4-wave workgroups per CU, hold the second half of the grid back by this many 10-ns ticks so
+                        // that the two workgroups of a CU do their tile I/O at different times)
+    if (blockIdx.x >= gridDim.x / 2) {
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+        while (__builtin_amdgcn_s_memrealtime() - t0 < (unsigned long long)(FS_PHASE_TICKS)) __builtin_amdgcn_s_sleep(32);
+    }
+#endif
     const int npass_total = (a.M + NW * 32 - 1) / (NW * 32);
     const int my_passes = blockIdx.x < npass_total ? (npass_total - blockIdx.x + gridDim.x - 1) / gridDim.x : 0;
     const int total = my_passes * NSTEP;  // ring slots this workgroup will consume
@@ -171,8 +201,14 @@ __global__ __launch_bounds__(NW * 64) void codec_ffn_stream_kernel(FfnStreamArgs
         const float* xr = a.x + a.img.at(mm < a.M ? mm : a.M - 1);
 #pragma unroll
         for (int kk = 0; kk < KK1; ++kk) {
+#ifdef FS_ELIM_XIN   // (timing experiment: no global read of the tile)
+            const float f0 = (float)(lane + kk) * 0.01f + (float)(size_t)xr * 1e-30f;
+            xa[kk][0] = make_float4(f0, f0 + 1.f, f0 - 1.f, f0 * 0.5f);
+            xa[kk][1] = make_float4(-f0, f0 + 2.f, f0 - 2.f, f0 * 0.25f);
+#else
             xa[kk][0] = *reinterpret_cast<const float4*>(xr + 16 * kk + 8 * fh);
             xa[kk][1] = *reinterpret_cast<const float4*>(xr + 16 * kk + 8 * fh + 4);
+#endif
         }
     };
     // x I/O of a pass used to cost three exposed memory round trips (tile read at the top; residual re-read, then the drain of
@@ -186,9 +222,17 @@ __global__ __launch_bounds__(NW * 64) void codec_ffn_stream_kernel(FfnStreamArgs
     // 300.4; C = 256: 238.8 / 237.0 / 232.0 / 238.1 — far less than the 120 us the elimination builds promised: what a pass
     // waits for is not the latency of its own requests but the BURST — every workgroup of the launch reaches its write-back
     // within the same few microseconds (32 MB of stores, then 32 MB of reads, per round of passes), and nothing computes while
-    // HBM serves it.  Each width keeps the variant that helps it (the lab copy, exp/codec_ffn_stream_lab.hip, takes -DFS_XNEXT=0/1 -DFS_XO_EARLY=0/1 for A/B builds).
+    // HBM serves it.  Each width keeps the variant that helps it (-DFS_XNEXT=0/1 -DFS_XO_EARLY=0/1 force one for A/B builds).
+#ifdef FS_XNEXT
+    constexpr bool XNEXT = FS_XNEXT;
+#else
     constexpr bool XNEXT = C == 256;
+#endif
+#ifdef FS_XO_EARLY
+    constexpr bool XO_EARLY = FS_XO_EARLY;
+#else
     constexpr bool XO_EARLY = C == 128;
+#endif
     constexpr int XL = XO_EARLY ? 4 * NOT : 0;   // loads of the early re-read (per lane)
     static_assert((S - 2) * PW + XL <= 63, "vmcnt immediate");
     if (XNEXT && my_passes > 0) load_x(0);
@@ -196,6 +240,8 @@ __global__ __launch_bounds__(NW * 64) void codec_ffn_stream_kernel(FfnStreamArgs
     for (int p = 0; p < my_passes; ++p) {
         const int pass = blockIdx.x + p * gridDim.x;
         const int m_cur = (pass * NW + wave) * 32 + fr;
+        FS_STAMP(0);
+        FS_STAMPR(150);
         // ---- x -> RMSNorm -> split bf16 B fragments (lane = frame, channels 16 kk + 8 fh + e) -------------------
         bf16x8 nh[KK1], nl[KK1];
         {
@@ -230,6 +276,10 @@ __global__ __launch_bounds__(NW * 64) void codec_ffn_stream_kernel(FfnStreamArgs
         for (int ot = 0; ot < NOT; ++ot)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc2[ot][r] = 0.f;
+#ifdef FS_TIMELINE
+        asm volatile("s_nop 0" :: "v"(nh[KK1 - 1]));   // (the stamp stays behind the tile load + norm)
+#endif
+        FS_STAMP(1);   // tile loaded, normalised, converted
 
         struct Frags { bf16x8 h[2], l[2]; };  // B fragments (two k16 steps) of one activated hidden tile
         floatx16 H0, H1;
@@ -244,8 +294,13 @@ __global__ __launch_bounds__(NW * 64) void codec_ffn_stream_kernel(FfnStreamArgs
                 wait_vmcnt<(S - 2) * PW + YL>();
             else
                 wait_vmcnt<0>();
+            FS_STAMP(2 + 4 * ti);   // own DMA pieces of this step's slot landed
+#ifndef FS_NOBARRIER   // (timing experiment only: without the barrier the ring hand-over is a data race)
             __builtin_amdgcn_s_barrier();  // everybody's pieces of slot `it` landed; everybody left slot it-1 -> it is free
+#endif
+            FS_STAMP(3 + 4 * ti);   // barrier passed
             if (it + S - 1 < total) issue(it + S - 1);
+            FS_STAMP(4 + 4 * ti);   // next slot's DMAs issued
             const char* sl = smem + (it % S) * SLOT;
             ++it;
 
@@ -262,8 +317,12 @@ __global__ __launch_bounds__(NW * 64) void codec_ffn_stream_kernel(FfnStreamArgs
                 int lo;
                 if (g < NG1) { ad = sl + (w1_a0 ^ (((2 * g) & 15) << 4)) + ((2 * g) >> 4) * 256; lo = W1T; }
                 else { const int g2 = g - NG1; ad = sl + w2_off[g2 / NOT] + (g2 % NOT) * 32 * 64; lo = W2T; }
+#ifdef FS_ELIM_FRAG   // (timing experiments only, results are wrong: FS_ELIM_*)
+                wf[g % NB][0] = nh[g % KK1]; wf[g % NB][1] = nl[g % KK1]; (void)ad; (void)lo;
+#else
                 wf[g % NB][0] = *reinterpret_cast<const bf16x8*>(ad);
                 if (SPLIT == 3) wf[g % NB][1] = *reinterpret_cast<const bf16x8*>(ad + lo);
+#endif
             };
 #pragma unroll
             for (int g = 0; g < PFD; ++g)
@@ -427,7 +486,13 @@ __global__ __launch_bounds__(NW * 64) void codec_ffn_stream_kernel(FfnStreamArgs
                 for (int ps = 0; ps < NPASS; ++ps) {
                     const int c = g * NPASS + ps;
                     __builtin_amdgcn_sched_barrier(0);
+#ifdef FS_ELIM_MFMA
+                    asm volatile("" :: "v"(wf[g % NB][0]));
+                    if (g < NG1) { hw[g & 15] += 1.0f; } else { acc2[(g - NG1) % NOT][g & 15] += fr_.h[(g - NG1) / NOT][0] == (bf16_t)0.5f ? 1.f : 0.f; }
+                    if (false) {
+#else
                     if (g < NG1) {
+#endif
                         // pass order: the two cross terms first, hi . hi last
                         if (SPLIT == 3 && ps == 0) hw = mfma16<SPLIT>(wf[g % NB][1], nh[g < NG1 ? g : 0], hw);
                         else if (SPLIT == 3 && ps == 1) hw = mfma16<SPLIT>(wf[g % NB][0], nl[g < NG1 ? g : 0], hw);
@@ -438,14 +503,33 @@ __global__ __launch_bounds__(NW * 64) void codec_ffn_stream_kernel(FfnStreamArgs
                         else if (SPLIT == 3 && ps == 1) acc2[ot] = mfma16<SPLIT>(wf[g % NB][0], fr_.l[s2], acc2[ot]);
                         else acc2[ot] = mfma16<SPLIT>(wf[g % NB][0], fr_.h[s2], acc2[ot]);
                     }
+#ifdef FS_ELIM_GELU
+                    if (G && c < 2) {   // bare conversion of the tile (keeps the first product alive): 8 cvt + the lane swap
+                        const int s2 = c;
+                        unsigned hp[4], fhh[4];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) hp[j] = cvt_pk_f16_satpos(hr[8 * s2 + 2 * j], hr[8 * s2 + 2 * j + 1]);
+#pragma unroll
+                        for (int e = 0; e < 2; ++e) {
+                            auto rh = __builtin_amdgcn_permlane32_swap(hp[e], hp[2 + e], false, false);
+                            fhh[e] = rh[0]; fhh[2 + e] = rh[1];
+                        }
+                        fw.h[s2] = __builtin_bit_cast(bf16x8, *reinterpret_cast<uint4*>(fhh));
+                    }
+#else
                     if (G)
 #pragma unroll
                         for (int k = NTASK * c / NCH; k < NTASK * (c + 1) / NCH; ++k) {
                             if constexpr (PK16) task_pk(k); else if constexpr (PK) task_q5(k); else task(k);
                         }
+#endif
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
+#ifdef FS_TIMELINE
+            asm volatile("s_nop 0" :: "v"(acc2[0][0]), "v"(hw[0]));   // (the stamp stays behind the step's MFMAs)
+#endif
+            FS_STAMP(5 + 4 * ti);   // fragment reads + MFMAs + GELU tasks of the step issued
         };
         using T_ = std::true_type;
         using F_ = std::false_type;
@@ -474,9 +558,16 @@ __global__ __launch_bounds__(NW * 64) void codec_ffn_stream_kernel(FfnStreamArgs
         step(F_{}, F_{}, T_{}, NT1 + 1, H1, H0, F0, F1, std::integral_constant<int, (S > 2 ? XL : 0)>{});
 
         // ---- epilogue: x[frame][c] += gamma[c] (out + b2[c]); channel(r) = 32 ot + (r & 3) + 8 (r >> 2) + 4 fh ----------
+        FS_STAMP(140);   // ring steps of the pass done
         if (!XO_EARLY) load_xo();   // every re-read of the tile is issued before the first store: one round trip, not one per channel tile
+#ifndef FS_EPI_NOFENCE
         __builtin_amdgcn_sched_barrier(0);   // (keeps hipcc from sinking the loads back next to their stores)
+#endif
+#ifdef FS_ELIM_XOUT   // (timing experiment: the residual read-modify-write never happens, but the compiler cannot know)
+        if (m_cur < a.M && a.eps < 0.f) {
+#else
         if (m_cur < a.M) {
+#endif
 #pragma unroll
             for (int ot = 0; ot < NOT; ++ot) {
 #pragma unroll
@@ -489,7 +580,11 @@ __global__ __launch_bounds__(NW * 64) void codec_ffn_stream_kernel(FfnStreamArgs
                     o.y += gv.y * (acc2[ot][4 * q + 1] + bv.y);
                     o.z += gv.z * (acc2[ot][4 * q + 2] + bv.z);
                     o.w += gv.w * (acc2[ot][4 * q + 3] + bv.w);
+#ifdef FS_LIN_STORE   // (timing experiment, results wrong: the same bytes written as whole 1-KiB wave stores instead of 32-B pieces of 32 rows)
+                    *reinterpret_cast<float4*>(a.x + a.img.at(0) + ((((long)(pass * NW + wave) * NOT + ot) * 4 + q) * 64 + lane) * 4) = o;
+#else
                     *reinterpret_cast<float4*>(xr + c0) = o;
+#endif
                 }
             }
         }
@@ -500,15 +595,27 @@ __global__ __launch_bounds__(NW * 64) void codec_ffn_stream_kernel(FfnStreamArgs
         __builtin_amdgcn_sched_barrier(0);   // (the request stays BEHIND the stores: hoisted above them it would be live next to the accumulators)
         // (unconditional — behind the last pass it re-reads a clamped row: a conditional request would keep the OLD tile's 64-128
         // registers live through the whole pass on the not-taken path, and spills)
+        FS_STAMP(141);   // residual added, stores issued
         if (XNEXT) load_x(p + 1);
         wait_vmcnt<0>();
+        FS_STAMP(142);   // stores (and the next tile's request) drained
+        FS_STAMPR(151);
     }
+#ifdef FS_TIMELINE
+    __syncthreads();
+    if (blockIdx.x < 256)
+        for (int i = tid; i < FS_TL_PASSES * FS_TL_N; i += NW * 64) fs_tl_buf[blockIdx.x * FS_TL_PASSES * FS_TL_N + i] = tl[i];
+#endif
 }
 
 template <int C, int SPLIT, int NW, int S>
 static hipError_t ffn_stream_go(const FfnStreamArgs& a, hipStream_t st) {
     constexpr int NARR = SPLIT == 3 ? 2 : 1;
+#ifdef FS_TIMELINE
+    constexpr size_t lds = (size_t)S * NARR * 128 * C + (size_t)7 * C * 4 + FS_TL_PASSES * FS_TL_N * 8;
+#else
     constexpr size_t lds = (size_t)S * NARR * 128 * C + (size_t)7 * C * 4;
+#endif
     static_assert(lds <= 160 * 1024, "ring exceeds LDS");
     auto kern = codec_ffn_stream_kernel<C, SPLIT, NW, S>;
     static DevOnce once;

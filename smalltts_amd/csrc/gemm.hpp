@@ -39,12 +39,16 @@ __device__ __forceinline__ void split4(const float4& v, uint2& hi, uint2& lo) {
 }
 
 
-#ifdef G3_TIMELINE   // debug build (tools/gemm3_timeline.py): wave 0 of every workgroup stamps the shader clock; one buffer per translation unit
-static __device__ unsigned long long g3_tl_buf[1024 * 160];
-static __device__ int g3_tl_skip_k;   // 1: no per-k-tile stamps (an s_memtime costs the one-wave-per-SIMD loop of the 64x64 tile as much as the k-tile itself)
-#define EPI_STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x < 1024) g3_tl_buf[blockIdx.x * 160 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+// Timeline markers (G3_STAMP*, EPI_STAMP): empty statements in the shipped library; a lab build (exp/timeline.hpp) makes them stamps.
+#ifdef SMTTS_LAB
+#include "exp/timeline.hpp"
 #else
+#define G3_STAMPK(i) do { } while (0)
+#define G3_STAMP(i) do { } while (0)
+#define G3_STAMPR(i) do { } while (0)
+#define G3_STAMP_FENCE(v) do { } while (0)
 #define EPI_STAMP(i) do { } while (0)
+#define G3_TIMELINE_EXPORTS(suffix)
 #endif
 struct RowCtx;
 // Shared accumulator write-out for gemm_kernel / gemm3_kernel.  mw0 / nw0 = first row / column of this wave.

@@ -28,17 +28,6 @@ struct Gemm3Operands {
     int ksplit_tiles;  // > 0: blockIdx.z is a split-K index; this launch slice covers k-tiles [z*ksplit_tiles, +ksplit_tiles)
 };
 
-#ifdef G3_TIMELINE   // debug build (tools/gemm3_timeline.py): wave 0 of every workgroup stamps the shader clock around each k-tile's wait / barrier / MFMAs
-// (g3_tl_buf: gemm.hpp, one copy per translation unit — read through the unit's smtts_debug_read_timeline*)
-#define G3_STAMPK(i) do { if (tid == 0 && blockIdx.x < 1024 && (i) < 146 && !g3_tl_skip_k) g3_tl_buf[blockIdx.x * 160 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)   // k-tiles 0 .. 35
-#define G3_STAMP(i) do { if (tid == 0 && blockIdx.x < 1024 && (i) < 160) g3_tl_buf[blockIdx.x * 160 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
-#define G3_STAMPR(i) do { if (tid == 0 && blockIdx.x < 1024) g3_tl_buf[blockIdx.x * 160 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)   // constant 100 MHz: calibrates the shader clock
-#else
-#define G3_STAMPK(i) do { } while (0)
-#define G3_STAMPR(i) do { } while (0)
-#define G3_STAMP(i) do { } while (0)
-#endif
-
 template <int BM, int BN, int WM, int WN, int SPLIT, int S, class Epi>
 __global__ __launch_bounds__(WM* WN * 64) void gemm3_kernel(Gemm3Operands g, Epi epi) {
     constexpr int BK = 64;
@@ -326,9 +315,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm3_kernel(Gemm3Operands g, Epi
                     }
             }
         }
-#ifdef G3_TIMELINE
-        asm volatile("s_nop 0" :: "v"(acc[0][0][0]));   // (the stamp must not move above the MFMAs' issue)
-#endif
+        G3_STAMP_FENCE(acc[0][0][0]);   // (lab: the stamp must not move above the MFMAs' issue)
         G3_STAMPK(5 + 4 * kt);          // fragment reads + MFMAs of k-tile kt issued
     }
     G3_STAMP(150);
@@ -392,7 +379,16 @@ static inline bool gemm3_ok(const Gemm3Operands& g) {
     return g.K % 64 == 0 && g.K >= 64 && (g.amap.ld % 8) == 0 && (g.amap.off % 8) == 0 && (g.ldw % 8) == 0 &&
            (g.amap.bstride % 8) == 0;
 }
-#include "gemm4.hpp"
+// gemm4 (256 x 256 x 64 macro-tile on a phase-split schedule, round 5): bit-identical to gemm3 and 1.05 PFLOP/s on 4096^3, but no better
+// than gemm3 on any product this library runs (profiles/r05b-d, r05h) — it lives in exp/ and is compiled into lab builds only
+// (make LAB=1, cfg 7; tools/gemm4_check.py); the shipped library has no instantiation of it.
+#ifdef SMTTS_LAB
+#include "exp/gemm4.hpp"
+#else
+#include <type_traits>
+template <class Epi> struct gemm4_enabled : std::false_type {};
+static inline bool gemm4_ok(const Gemm3Operands&) { return false; }
+#endif
 
 static inline int gemm3_pick_cfg(int M, int N, bool paired, bool single = false /* one array per operand (fp16 / bf16) */) {
     extern int g_gemm3_w4_minm;   // single-array formats: 128x128 with four 64x64 waves from this M up (0 = never); split-bf16 falls back
@@ -479,9 +475,11 @@ static inline hipError_t gemm3_launch_split(const Gemm3Operands& g, const Epi& e
         }
     }
     switch (cfg) {
+#ifdef SMTTS_LAB
         case G4_256x256:
             if constexpr (SPLIT == PREC_BF16 || SPLIT == PREC_F16) return gemm4_launch_cfg<SPLIT, Epi>(g, epi, Z, st);
             break;
+#endif
         case G3_128x128:
             return gemm3_launch_cfg<128, 128, 4, 2, SPLIT, 2, Epi>(g, epi, Z, st);
         case G3_64x128:

@@ -29,7 +29,7 @@ hipError_t gemm3_qkv(const Gemm3Operands& g_in, const EpiQKV& p, int split, hipS
     extern int g_gemm3_nfast;
     Gemm3Operands g = g_in;
     g.nfast = g_gemm3_nfast && (long)g.M > (long)g.N;
-    static const int big_minm = getenv("SMTTS_QKV_BIG_MINM") ? atoi(getenv("SMTTS_QKV_BIG_MINM")) : 641;   // A/B: 128x128 tiles from this many rows up
+    static const int big_minm = lab_env("SMTTS_QKV_BIG_MINM") ? atoi(lab_env("SMTTS_QKV_BIG_MINM")) : 641;   // A/B: 128x128 tiles from this many rows up
     const bool big = g.M >= big_minm;
     const long tiles = (long)((g.M + (big ? 127 : 63)) / (big ? 128 : 64)) * (g.N / 128);
     const bool deep = g_gemm3_deep && split != PREC_BF16X3 && tiles <= 256;   // deep rings only while the grid is one resident round (gemm3_launch_split)

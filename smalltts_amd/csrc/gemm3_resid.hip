@@ -23,14 +23,4 @@ hipError_t gemm3_resid_ln(const Gemm3Operands& g, const EpiResidLN& p, int split
     return gemm3_launch(g, p, 1, split, st, cfg);
 }
 
-#ifdef G3_TIMELINE   // debug build only (tools/gemm3_timeline.py): the stamps of THIS translation unit's instantiations (the residual epilogues)
-extern "C" int smtts_debug_read_timeline_resid(unsigned long long* host, int n) {
-    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g3_tl_buf), (size_t)n * 8);
-}
-extern "C" int smtts_debug_timeline_resid_skip_k(int on) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(g3_tl_skip_k), &on, sizeof on); }
-extern "C" int smtts_debug_clear_timeline_resid(void) {
-    void* p = nullptr;
-    if (hipGetSymbolAddress(&p, HIP_SYMBOL(g3_tl_buf)) != hipSuccess) return 1;
-    return (int)hipMemset(p, 0, sizeof(unsigned long long) * 1024 * 160);
-}
-#endif
+G3_TIMELINE_EXPORTS(_resid)   // (lab builds with -DG3_TIMELINE only: tools/gemm3_resid_timeline.py)

@@ -22,18 +22,9 @@ hipError_t gemm3_store_x2(const Gemm3Operands& g, const EpiStore<ACT_NONE>& p, h
     return gemm3_launch_x2(g, p, 1, st, cfg);
 }
 
-#ifdef G3_TIMELINE   // debug build only (tools/gemm3_timeline.py): the k-tile stamps of this translation unit's gemm3 instantiations
-extern "C" int smtts_debug_read_timeline(unsigned long long* host, int n) {
-    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g3_tl_buf), (size_t)n * 8);
-}
-extern "C" int smtts_debug_clear_timeline(void) {
-    void* p = nullptr;
-    if (hipGetSymbolAddress(&p, HIP_SYMBOL(g3_tl_buf)) != hipSuccess) return 1;
-    return (int)hipMemset(p, 0, sizeof(unsigned long long) * 1024 * 160);
-}
-#endif
+G3_TIMELINE_EXPORTS()   // (lab builds with -DG3_TIMELINE only: tools/gemm3_timeline.py)
 
-#ifdef G4_TIMELINE   // debug build only (tools/gemm4_timeline.py): the phase stamps of this translation unit's gemm4 instantiations
+#if defined(SMTTS_LAB) && defined(G4_TIMELINE)   // tools/gemm4_timeline.py
 extern "C" int smtts_debug_read_timeline4(unsigned long long* host, int n) {
     return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g4_tl_buf), (size_t)n * 8);
 }

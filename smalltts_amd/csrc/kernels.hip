@@ -1332,9 +1332,9 @@ hipError_t launch_mixer_wide(const float* xin, float* xout, const float* norm_w,
         hipLaunchKernelGGL(kern, dim3((unsigned)(B * tiles)), dim3(256), lds, st, xin, xout, norm_w, w, bias, gamma, ffn_norm_w,   \
                            n2hi, n2lo, T, pad, eps, tiles);                                                                        \
     } while (0)
-    static const int tt512 = getenv("SMTTS_MW_TT512") ? atoi(getenv("SMTTS_MW_TT512")) : 8;
-    static const int tt1024 = getenv("SMTTS_MW_TT1024") ? atoi(getenv("SMTTS_MW_TT1024")) : 4;
-    static const int tt2048 = getenv("SMTTS_MW_TT2048") ? atoi(getenv("SMTTS_MW_TT2048")) : 4;
+    static const int tt512 = lab_env("SMTTS_MW_TT512") ? atoi(lab_env("SMTTS_MW_TT512")) : 8;
+    static const int tt1024 = lab_env("SMTTS_MW_TT1024") ? atoi(lab_env("SMTTS_MW_TT1024")) : 4;
+    static const int tt2048 = lab_env("SMTTS_MW_TT2048") ? atoi(lab_env("SMTTS_MW_TT2048")) : 4;
     if (C == 2048) { if (tt2048 == 4) MW_GO(2048, 4); else MW_GO(2048, 8); }
     else if (C == 1024) { if (tt1024 == 4) MW_GO(1024, 4); else if (tt1024 == 8) MW_GO(1024, 8); else MW_GO(1024, 16); }
     else { if (tt512 == 4) MW_GO(512, 4); else if (tt512 == 8) MW_GO(512, 8); else if (tt512 == 16) MW_GO(512, 16); else MW_GO(512, 32); }

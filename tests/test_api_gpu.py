@@ -368,6 +368,25 @@ def test_wrong_shaped_checkpoint_is_a_clean_error_naming_the_tensor(tmp_path):
     e.close()
 
 
+def test_stress_determinism_tool_half_a_minute_all_workloads():
+    """tools/stress_determinism.py in its short mode: repeated cond_encode and sampler calls under latency tuning
+    (dual-stream encoders, LN-fold epilogues), then the dmd4 / teacher-CFG / clone workloads with three batches in flight under
+    throughput tuning, each round compared bit for bit with the batches run alone.  This is the detector of the wrong-rows mode of
+    NOTEBOOK 13a (packed fp32 behind cross-lane reductions next to LDS-DMA / MFMA kernels): -fno-slp-vectorize is on every
+    translation unit since round 6 and this test would see a regression."""
+    import re
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, os.path.join(root, "tools", "stress_determinism.py"), "160"], capture_output=True, text=True,
+                       timeout=600, cwd=root)
+    assert p.returncode == 0, p.stderr[-2000:]
+    rows = re.findall(r"^(.*): (\d+) of (\d+) (?:repeats|rounds) differ", p.stdout, re.M)
+    assert len(rows) == 5, p.stdout
+    for what, bad, n in rows:
+        assert int(bad) == 0 and int(n) >= 40, (what, bad, n)
+
+
 def test_results_repeat_bit_for_bit_next_to_other_streams():
     """Bitwise repeatability with other HIP streams active — the two situations the product creates itself: the condition
     encoders on two streams (latency tuning) and three batches in flight on three streams (throughput tuning, bench.py's

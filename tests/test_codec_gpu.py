@@ -126,7 +126,7 @@ def test_alternative_paths_agree_with_the_default(tmp_path):
     assert np.array_equal(_decode_in_subprocess(tmp_path, "tp_no_chain", {"SMTTS_STAGE_CHAIN": "0"}, "throughput"), tp), "stage chain (tp)"
     assert np.array_equal(_decode_in_subprocess(tmp_path, "tp_chain_100", {"SMTTS_PERSIST_CUS": "100"}, "throughput"), tp), "stage chain, 100 workgroups"
     for tag, env in (("grid_all_cus", {"SMTTS_PERSIST_CUS": "0"}), ("grid_half", {"SMTTS_PERSIST_CUS": "128"}),
-                     ("tp_shallow", {"SMTTS_GEMM_DEEP_TP": "0"})):
+                     ("tp_shallow", {"SMTTS_GEMM_DEEP": "0"})):
         alt = _decode_in_subprocess(tmp_path, tag, env, "throughput")
         assert np.array_equal(alt, tp), tag
     # the two-kernel mixer sums the rows' squares in another order; at the default precision the normalised rows are then rounded to
@@ -134,5 +134,3 @@ def test_alternative_paths_agree_with_the_default(tmp_path):
     # (68.7 dB vs the oracle; measured 72 dB between them)
     two = _decode_in_subprocess(tmp_path, "two_kernel_mixer", {"SMTTS_MIXER_WIDE": "0"})
     assert snr_db(two, base) > 66.0
-    x2 = _decode_in_subprocess(tmp_path, "mixer_tiles", {"SMTTS_MW_TT512": "32", "SMTTS_MW_TT1024": "16", "SMTTS_MW_TT2048": "8"})
-    assert np.array_equal(x2, base)   # (the thread -> channel mapping and every reduction order are the same for every tile size)

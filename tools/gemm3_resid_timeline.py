@@ -1,5 +1,7 @@
-"""Where a launch of the DiT's N = 960 projections spends its time.  GPU box, debug build -DG3_TIMELINE loaded
-through SMTTS_LIB (tools/sessions/r06_timeline.sh): wave 0 of every workgroup stamps the shader clock (s_memtime, calibrated per
+"""Where a launch of the DiT's N = 960 projections spends its time.  GPU box, lab build
+    make -C smalltts_amd/csrc LAB=1 BUILD=build_tl LIB=../libsmalltts_hip_tl.so EXTRA="-DG3_TIMELINE -DG3_TL_NO_K"
+loaded through SMTTS_LIB (no per-k-tile stamps: one s_memtime per k-tile doubles the loop of this one-wave-per-SIMD tile; the loop's
+own cost comes from tools/gemm_kloop_probe.py on the un-instrumented library): wave 0 of every workgroup stamps the shader clock (s_memtime, calibrated per
 workgroup against s_memrealtime) at
    start | ring prologue issued | first k-tile landed | k-loop end | mask bytes landed | residual + vectors landed | stores issued | end
 and the 100 MHz real-time counter at start / end, which places every workgroup on ONE time axis: first workgroup's start -> last
@@ -13,8 +15,7 @@ from smalltts_amd.engine import HipEngine
 
 eng = HipEngine(0, "f16")
 lib = eng.lib
-for f in ("smtts_debug_read_timeline_resid", "smtts_debug_read_timeline"):
-    getattr(lib, f).argtypes = [C.c_void_p, C.c_int]
+lib.smtts_debug_read_timeline_resid.argtypes = [C.c_void_p, C.c_int]
 # name, M, N, K, epi, cfg (2 = 64x64, 8 = 64x32, 9 = 32x64), ring ("SMTTS_GEMM_DEEP" value)
 SH = [("out-proj resid_gate + mask, 64x64", 600, 960, 960, 8, 2), ("out-proj resid_ln + mask, 64x64", 600, 960, 960, 7, 2),
       ("FF2 resid_gate, 64x64", 600, 960, 2432, 3, 2), ("FF2 resid_ln, 64x64", 600, 960, 2432, 9, 2)]
@@ -30,16 +31,12 @@ for name, M, N, K, epi, cfg in SH:
         for _ in range(3):   # the un-stamped launch time: 50 launches back to back
             assert lib.smtts_bench_gemm(e2.h, M, N, K, epi, 2, cfg, 50, 3, C.byref(us)) == 0, lib.smtts_last_error(e2.h)
             best = min(best, us.value)
-        def stamped(skip_k):
-            assert lib.smtts_debug_timeline_resid_skip_k(skip_k) == 0 and lib.smtts_debug_clear_timeline_resid() == 0
-            assert lib.smtts_bench_gemm(e2.h, M, N, K, epi, 2, cfg, 1, 3, C.byref(us)) == 0, lib.smtts_last_error(e2.h)
-            buf = np.zeros(1024 * 160, np.uint64)
-            assert lib.smtts_debug_read_timeline_resid(buf.ctypes.data, buf.size) == 0
-            a = buf.reshape(1024, 160).astype(np.int64)
-            return a[a[:, 0] > 0]
-        tk = stamped(0)     # with the per-k-tile stamps (they slow the loop: used for the k-tile table only)
-        t = stamped(1)      # phase stamps only: start, prologue, loop end, epilogue phases, end
-        t[:, 2] = t[:, 1]   # (first-k-tile stamp absent in this pass)
+        assert lib.smtts_debug_clear_timeline_resid() == 0
+        assert lib.smtts_bench_gemm(e2.h, M, N, K, epi, 2, cfg, 1, 3, C.byref(us)) == 0, lib.smtts_last_error(e2.h)
+        buf = np.zeros(1024 * 160, np.uint64)
+        assert lib.smtts_debug_read_timeline_resid(buf.ctypes.data, buf.size) == 0
+        t = buf.reshape(1024, 160).astype(np.int64)
+        t = t[t[:, 0] > 0]
         tick = np.median((t[:, 153] - t[:, 152]) * 10.0 / np.maximum(t[:, 151] - t[:, 0], 1))   # ns per shader tick
         us_of = lambda a, b: (t[:, a] - t[:, b]) * tick / 1e3
         med = lambda a: float(np.median(a))
@@ -54,13 +51,4 @@ for name, M, N, K, epi, cfg in SH:
               f" | k-loop ({nk} k-tiles) +{med(us_of(150, 1)):.2f}"
               f" | mask bytes +{med(us_of(154, 150)):.2f} | residual + vectors +{med(us_of(155, 154)):.2f} | stores issued +{med(us_of(156, 155)):.2f}"
               f" | {'partials + ' if epi in (7, 9) else ''}drain +{med(us_of(151, 156)):.2f}")
-        nks = min(nk, 36)   # (k-tiles 0 .. 35 are stamped)
-        t = tk
-        own = np.stack([t[:, 2 + 4 * k] - (t[:, 5 + 4 * (k - 1)] if k else t[:, 1]) for k in range(nks)], 1) * tick / 1e3
-        bar = np.stack([t[:, 3 + 4 * k] - t[:, 2 + 4 * k] for k in range(nks)], 1) * tick / 1e3
-        iss = np.stack([t[:, 4 + 4 * k] - t[:, 3 + 4 * k] for k in range(nks)], 1) * tick / 1e3
-        mma = np.stack([t[:, 5 + 4 * k] - t[:, 4 + 4 * k] for k in range(nks)], 1) * tick / 1e3
-        print(f"  WITH per-k-tile stamps (each costs the loop ~0.07 us: shares, not times) per k-tile (median over workgroups, mean over k-tiles 1 .. {nks - 1}): wait own DMA {own[:, 1:].mean(1).mean():.3f} | barrier "
-              f"{np.median(bar[:, 1:], 0).mean():.3f} | fragment reads + next stage issue {np.median(iss[:, 1:], 0).mean():.3f} | MFMA issue "
-              f"{np.median(mma[:, 1:], 0).mean():.3f} us;  wait own DMA by k-tile: " + " ".join(f"{np.median(own[:, k]):.2f}" for k in range(min(nks, 16))))
         e2.close()

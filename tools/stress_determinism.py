@@ -25,6 +25,14 @@ for i in range(iters):
     bad += any(not torch.equal(a[k], b[k]) for k in a)
 print(f"cond_encode (dual-stream encoders): {bad} of {iters} repeats differ")
 
+# the fused sampler under latency tuning (round 6: LN-fold epilogues — cross-lane partial sums in the producer, fixed-order reduction in
+# the consumer — and the modulation / fold tables computed on the side stream)
+cache0 = eng.cond_encode(inp["ref"], inp["ref_len"], inp["ids"], inp["ph_mask"])
+x0 = eng.sample(cache0, inp["mask"], num_steps=4, seed=77).clone(); bad = 0
+for i in range(iters):
+    bad += not torch.equal(eng.sample(cache0, inp["mask"], num_steps=4, seed=77), x0)
+print(f"4-step sampler (latency tuning, LN-fold): {bad} of {iters} repeats differ")
+
 prev = eng.set_tuning("throughput")
 ref_audio = [bench.one_step(eng, inp, 100 + i).clone() for i in range(3)]
 streams = [torch.cuda.Stream(dev) for _ in range(3)]
