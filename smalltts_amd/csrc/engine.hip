@@ -61,8 +61,9 @@ Engine::Engine(int device) : device_(device) {
     const char* s = getenv("SMTTS_SINGLE_STREAM");
     if (s && *s == '1') dual_stream_ = false;
     if ((s = lab_env("SMTTS_BLOCK_WAVE"))) block_wave_ = atoi(s) != 0;
-    if ((s = getenv("SMTTS_STAGE_CHAIN"))) stage_chain_ = atoi(s) != 0;
+    if ((s = getenv("SMTTS_STAGE_CHAIN"))) { stage_chain_ = atoi(s) != 0; if (atoi(s) >= 2) chain_min_run_ = 0; }   // 2: the chain whatever the run length (tests)
     if ((s = lab_env("SMTTS_CHAIN_MIN"))) chain_min_blocks_ = atoi(s);
+    if ((s = lab_env("SMTTS_CHAIN_MIN_RUN"))) chain_min_run_ = atoi(s);
     if ((s = lab_env("SMTTS_SMALLM_SPLITK"))) g_small_m_splitk = atoi(s);
     if ((s = lab_env("SMTTS_CONVPOS_BY_GROUP"))) convpos_by_group_ = atoi(s) != 0;
     if ((s = getenv("SMTTS_ATTN_EPI"))) attn_epi_ = atoi(s) != 0;
@@ -1583,6 +1584,14 @@ int Engine::codec_stage_chain(hipStream_t st, const CodecStageW& sg, float** xp,
         if (b.w1.K != C || b.w2.K != F) return 0;
     }
     if (!codec_chain_wave_ok(C, F, cspec_.kernel, T, pf, nb)) return 0;
+    {
+        // Every wave of the chain walks ONE contiguous run of tiles plus a warm-up tile that is computed and not stored: with short runs
+        // (small decodes: one 10 s utterance is 3 tiles per wave) the warm-up is a third of the work.  Measured (ADVICE r5,
+        // profiles/r06q_chain_small_batch.txt, B x 10 s, chain vs one launch per block): B = 1 1.567 vs 1.554 ms, B = 4 (10 tiles per
+        // wave) 3.538 vs 3.517, B = 8 (20) 5.923 vs 5.994 -> the chain from 16 tiles per wave up.
+        const long waves = (long)(persist_cus_ > 0 ? persist_cus_ : num_cus_) * 12;
+        if (chain_min_run_ > 0 && (long)B * T / 32 < chain_min_run_ * waves) return 0;
+    }
     CodecChainBlock cb[3];
     for (int i = 0; i < nb; ++i) {
         const CodecBlockW& b = sg.blocks[i];

@@ -258,6 +258,7 @@ class Engine {
     int preset_ = kDefaultPrecision;   // set_precision(kDefaultPrecision) in the constructor fills prec_
     int prec_[SITE_COUNT] = {3, 3, 3, 3, 3, 3, 3, 3};
     bool fused_ffn_ = true;  // test hook: smtts_test_set_fused_ffn
+    int chain_min_run_ = 16;   // ... and decodes of at least this many tiles per wave of the chain's grid (codec_stage_chain)
     int chain_min_blocks_ = 2; // ... for stages of at least this many blocks (a single block gains nothing from the chain's contiguous walk; SMTTS_CHAIN_MIN=1: debugging)
     bool stage_chain_ = true; // codec stages with C = 32: all blocks of the stage in ONE launch (SMTTS_STAGE_CHAIN=0: one launch per block)
     bool block_wave_ = true;  // codec stages with C = 32 / 64: mixer + FFN in one kernel (SMTTS_BLOCK_WAVE=0: mixer_fused + codec_ffn_wave)
