@@ -13,7 +13,7 @@ TAG=${1:-r05}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 mkdir -p gpurun_out
 SHA=$(python -c 'import bench; print(bench.kernel_source_hash())')
-BASE="python bench.py --steps 5 --warmup 2 --min-seconds 0 --no-cpu-baseline"
+BASE="python bench.py --steps 5 --warmup 2 --min-seconds 0 --no-cpu-baseline --no-secondary"
 ONE="$BASE --no-roofline --in-flight 1 --no-sequential"
 $BASE > gpurun_out/${TAG}_plain_bench.json 2>/dev/null
 db() { ls gpurun_out/$1/*.db gpurun_out/$1/*/*.db 2>/dev/null | head -1; }
