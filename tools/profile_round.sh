@@ -15,7 +15,7 @@ mkdir -p gpurun_out
 SHA=$(python -c 'import bench; print(bench.kernel_source_hash())')
 BASE="python bench.py --steps 5 --warmup 2 --min-seconds 0 --no-cpu-baseline --no-secondary"
 ONE="$BASE --no-roofline --in-flight 1 --no-sequential"
-$BASE > gpurun_out/${TAG}_plain_bench.json 2>/dev/null
+python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-secondary > gpurun_out/${TAG}_plain_bench.json 2>/dev/null   # (the un-profiled time per batch: the driver's own steps / warm-up, >= 2 s timed)
 db() { ls gpurun_out/$1/*.db gpurun_out/$1/*/*.db 2>/dev/null | head -1; }
 cc() { find gpurun_out/$1 -name '*counter_collection.csv' | head -1; }
 for T in throughput latency; do
