@@ -89,6 +89,10 @@ def load():
         raise RuntimeError(
             f"{LIB_PATH} not found: the HIP extension is required (no CPU fallback). "
             "Build it with `make -C smalltts_amd/csrc` or `python -c 'import __graft_entry__ as g; g.build()'`.")
+    # PyTorch-ROCm first: it brings its own copy of the HIP runtime (torch/lib/libamdhip64.so), and this library must bind to THAT one —
+    # two HIP runtimes in one process do not both see the GPU.  Loaded the other way round (this library, then torch: what
+    # `python __graft_entry__.py smoke` does when build() runs in front of smoke()) smtts_create fails with "no ROCm-capable device".
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)
