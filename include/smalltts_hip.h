@@ -49,9 +49,9 @@ int smtts_create(int device_id, smtts_handle* out);
 int smtts_destroy(smtts_handle h);
 const char* smtts_last_error(smtts_handle h); /* h may be NULL: last creation error */
 const char* smtts_version(void);
-/* bumped on every signature / default change: 4 = round 4 (workspace queries take R and P, new handles default to preset 2,
+/* bumped on every signature / default change: 5 = round 6 (smtts_test_set_ln_fold; one side stream per caller stream); 4 = round 4 (workspace queries take R and P, new handles default to preset 2,
  * smtts_get_saturations) */
-#define SMTTS_ABI_VERSION 4
+#define SMTTS_ABI_VERSION 5
 int smtts_abi_version(void);
 
 /* ---- weights (replaces the ONNX initialisers; names/shapes = DiTModel.state_dict(),

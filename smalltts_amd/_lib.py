@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get("SMTTS_LIB") or os.path.join(_HERE, "libsmalltts_hip.s
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "smalltts_hip.h")
 
 _lib = None
-ABI_VERSION = 4   # include/smalltts_hip.h SMTTS_ABI_VERSION
+ABI_VERSION = 5   # include/smalltts_hip.h SMTTS_ABI_VERSION
 
 vp, i32, i64, u64, f32, sz = C.c_void_p, C.c_int, C.c_int64, C.c_uint64, C.c_float, C.c_size_t
 cstr = C.c_char_p

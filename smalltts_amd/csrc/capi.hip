@@ -20,7 +20,7 @@ static thread_local std::string g_create_err;
 
 extern "C" {
 
-const char* smtts_version(void) { return "smalltts-hip 0.4 (gfx950)"; }
+const char* smtts_version(void) { return "smalltts-hip 0.5 (gfx950)"; }
 int smtts_abi_version(void) { return SMTTS_ABI_VERSION; }
 
 int smtts_create(int device_id, smtts_handle* out) {

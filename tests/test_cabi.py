@@ -100,4 +100,4 @@ def test_abi_version_matches_the_header_and_the_host_side():
     with open(_lib.HEADER_PATH) as f:
         m = re.search(r"#define\s+SMTTS_ABI_VERSION\s+(\d+)", f.read())
     assert m and int(m.group(1)) == lib.smtts_abi_version() == _lib.ABI_VERSION
-    assert b"0.4" in lib.smtts_version()
+    assert b"0.5" in lib.smtts_version()

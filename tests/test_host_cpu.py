@@ -352,6 +352,9 @@ def test_bench_codec_bytes_follow_the_spec_and_profiler_names_map_back():
     for k, want in {
         "void gemm3_kernel<64, 64, 2, 2, 2, 4, EpiResid<1> >(Gemm3Operands, EpiResid<1>)": "gemm3<64x64,s2,resid_gate>",
         "void gemm4_kernel<2, EpiStore<2> >(Gemm3Operands, EpiStore<2>)": "gemm4<256x256,s2,store_gelu>",
+        "void gemm3_kernel<64, 64, 2, 2, 2, 4, EpiResidLN>(Gemm3Operands, EpiResidLN)": "gemm3<64x64,s2,resid_ln>",
+        "void gemm3_kernel<128, 128, 4, 2, 2, 4, EpiSwiGLUT<true> >(Gemm3Operands, EpiSwiGLUT<true>)": "gemm3<128x128,s2,swiglu>",
+        "void gemm3_kernel<64, 128, 2, 4, 2, 3, EpiQKVT<false> >(Gemm3Operands, EpiQKVT<false>)": "gemm3<64x128,s2,qkv_img>",
         "void codec_chain_wave_kernel<32, 2, 12, 3>(FfnChainArgs)": "codec_chain_wave<32>",
         "void codec_ffn_wave_kernel<64, 2, 8, true>(FfnWaveArgs)": "codec_block_wave<64>",
         "void codec_ffn_wave_kernel<32, 2, 8, false>(FfnWaveArgs)": "codec_ffn_wave<32>",

@@ -4,13 +4,14 @@ import re
 
 _EPI3 = {"EpiStore<0>": "store", "EpiStore<1>": "store_silu", "EpiStore<2>": "store_gelu", "EpiStore<3>": "store_mish",
          "EpiSwiGLU": "swiglu", "EpiResid<0>": "resid", "EpiResid<1>": "resid_gate", "EpiResid<2>": "resid_layerscale",
-         "EpiKV": "kv_scatter", "EpiQKV": "qkv_img", "EpiConvPos<0>": "convpos", "EpiConvPos<1>": "convpos_final"}
+         "EpiKV": "kv_scatter", "EpiQKV": "qkv_img", "EpiResidLN": "resid_ln",
+         "EpiSwiGLUT<false>": "swiglu", "EpiSwiGLUT<true>": "swiglu", "EpiQKVT<false>": "qkv_img", "EpiQKVT<true>": "qkv_img", "EpiConvPos<0>": "convpos", "EpiConvPos<1>": "convpos_final"}
 
 
 def prof_name(kernel: str):
     k = kernel.strip()
     k = k[5:] if k.startswith("void ") else k
-    m = re.match(r"gemm3_kernel<(\d+), (\d+), \d+, \d+, (\d), \d+, (Epi\w+(?:<\d>)?) ?>", k)
+    m = re.match(r"gemm3_kernel<(\d+), (\d+), \d+, \d+, (\d), \d+, (Epi\w+(?:<(?:\d|true|false)>)?) ?>", k)
     if m:
         return f"gemm3<{m.group(1)}x{m.group(2)},s{m.group(3)},{_EPI3.get(m.group(4), m.group(4))}>"
     m = re.match(r"gemm4_kernel<(\d), (Epi\w+(?:<\d>)?) ?>", k)
