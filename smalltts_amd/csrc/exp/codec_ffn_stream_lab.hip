@@ -1,3 +1,6 @@
+// LAB: copy of ../codec_ffn_stream.hip (make LAB=1 compiles THIS file instead): every timing-experiment branch (FS_ELIM_*, FS_LIN_STORE,
+// LAB: FS_NOBARRIER, ... — several give wrong results by design) and the FS_TIMELINE stamps.  The shipped file is this one with those switches
+// LAB: resolved as "not defined" (tools/strip_lab.py; tests/test_host_cpu.py checks that the two have not drifted apart).
 // Fused codec FFN for the stages whose weights do NOT fit in LDS (C = 128, 256), gfx950:
 //     x += ffn_gamma * ( W2 . gelu( W1 . RMSNorm(x; g, eps) + b1 ) + b2 )
 //
@@ -79,7 +82,7 @@ extern "C" int smtts_debug_clear_fs_timeline(void) {
 // pass ahead, no fp32 tile at the top of the pass: FFN 282 -> 268 us (C = 128) and 242 -> 222 us (C = 256), but the mixer that has to
 // write those rows 121 -> 163 and 73 -> 93 us — a net loss, and the per-pass timeline shows why the FFN gains so little: the wait only
 // moves to the residual re-read, which was an L2 hit behind the top-of-pass load and is a cold HBM read without it.  Commit aefe457,
-// profiles/r04k_*; tools/ffn_stream_timeline.py + -DFS_TIMELINE is the instrumentation.)
+// profiles/r04k_*; the instrumented / elimination builds live in exp/codec_ffn_stream_lab.hip: make LAB=1, tools/ffn_stream_timeline.py.)
 template <int C, int SPLIT, int NW, int S>
 __global__ __launch_bounds__(NW * 64) void codec_ffn_stream_kernel(FfnStreamArgs a) {
     constexpr int F = 4 * C;
@@ -222,7 +225,7 @@ __global__ __launch_bounds__(NW * 64) void codec_ffn_stream_kernel(FfnStreamArgs
     // 300.4; C = 256: 238.8 / 237.0 / 232.0 / 238.1 — far less than the 120 us the elimination builds promised: what a pass
     // waits for is not the latency of its own requests but the BURST — every workgroup of the launch reaches its write-back
     // within the same few microseconds (32 MB of stores, then 32 MB of reads, per round of passes), and nothing computes while
-    // HBM serves it.  Each width keeps the variant that helps it (-DFS_XNEXT=0/1 -DFS_XO_EARLY=0/1 force one for A/B builds).
+    // HBM serves it.  Each width keeps the variant that helps it (the lab copy, exp/codec_ffn_stream_lab.hip, takes -DFS_XNEXT=0/1 -DFS_XO_EARLY=0/1 for A/B builds).
 #ifdef FS_XNEXT
     constexpr bool XNEXT = FS_XNEXT;
 #else

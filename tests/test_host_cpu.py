@@ -383,4 +383,11 @@ def test_the_shipped_library_reads_exactly_the_ten_documented_environment_switch
     # no experiment branch or timeline stamp in the shipped streamed-FFN kernel: those live in the lab copy
     shipped = open(os.path.join(root, "smalltts_amd", "csrc", "codec_ffn_stream.hip")).read()
     assert not re.search(r"#\s*if(n?def)?\s+FS_(ELIM|LIN_STORE|NOBARRIER|TIMELINE|PHASE_TICKS|EPI_NOFENCE)", shipped) and "FS_STAMP" not in shipped
-    assert os.path.exists(os.path.join(root, "smalltts_amd", "csrc", "exp", "codec_ffn_stream_lab.hip"))
+    lab = os.path.join(root, "smalltts_amd", "csrc", "exp", "codec_ffn_stream_lab.hip")
+    assert os.path.exists(lab)
+    # ... and the shipped kernel IS the lab copy with the experiment switches resolved as "not defined": the two cannot drift apart
+    import sys
+    sys.path.insert(0, os.path.join(root, "tools"))
+    from strip_lab import STREAM_FFN, shipped as strip_to_shipped
+    with open(lab) as f:
+        assert "".join(strip_to_shipped(f.readlines(), STREAM_FFN)) == shipped

@@ -48,11 +48,29 @@ def strip(lines, undef, drop_calls):
     return out
 
 
-if __name__ == "__main__":
-    src, dst, syms = sys.argv[1], sys.argv[2], set(sys.argv[3:])
-    calls = [s[5:] for s in syms if s.startswith("CALL:")]
-    syms = {s for s in syms if not s.startswith("CALL:")}
+def _main():
+    src, dst, syms = sys.argv[1], sys.argv[2], (sys.argv[3:] or STREAM_FFN)
     with open(src) as f:
         lines = f.readlines()
     with open(dst, "w") as f:
-        f.writelines(strip(lines, syms, calls))
+        f.writelines(shipped(lines, syms))
+
+
+def shipped(lines, syms):
+    """syms: switch names, "CALL:<macro>" (statement lines calling it are dropped), "DEF:<macro>" (its #define lines are dropped)."""
+    syms = set(syms)
+    calls = [s[5:] for s in syms if s.startswith("CALL:")]
+    defs = [s[4:] for s in syms if s.startswith("DEF:")]
+    plain = {s for s in syms if ":" not in s}
+    while lines and lines[0].startswith("// LAB:"):   # the lab copy's own header
+        lines = lines[1:]
+    out = strip(lines, plain, calls)
+    return [ln for ln in out if not any(re.match(r"\s*#\s*define\s+%s\b" % d, ln) for d in defs)]
+
+
+STREAM_FFN = ["FS_TIMELINE", "FS_PHASE_TICKS", "FS_ELIM_XIN", "FS_NOBARRIER", "FS_ELIM_FRAG", "FS_ELIM_MFMA", "FS_ELIM_GELU", "FS_EPI_NOFENCE",
+              "FS_ELIM_XOUT", "FS_LIN_STORE", "FS_XNEXT", "FS_XO_EARLY", "CALL:FS_STAMP", "CALL:FS_STAMPR", "DEF:FS_STAMP", "DEF:FS_STAMPR"]
+
+
+if __name__ == "__main__":
+    _main()
