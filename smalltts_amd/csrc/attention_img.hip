@@ -70,7 +70,7 @@ __device__ __forceinline__ void pack_p2(float a, float b, unsigned& hi, unsigned
 }
 
 template <int DHP, int SPLIT>
-__global__ __launch_bounds__(256) void attention_img_kernel(AttnImg a, int nslots) {
+__global__ __launch_bounds__(256, 2) void attention_img_kernel(AttnImg a, int nslots) {   // (two workgroups per CU: <= 256 registers)
     constexpr int NARR = SPLIT == PREC_BF16X3 ? 2 : 1;
     constexpr int KC = 64, QT = 32;
     constexpr int PITCH = DHP * 2;              // bytes per row of the Q / K images
@@ -93,6 +93,20 @@ __global__ __launch_bounds__(256) void attention_img_kernel(AttnImg a, int nslot
     const int fr = lane & 31, fh = lane >> 5;
     const unsigned lds0 = (unsigned)(size_t)SM_LPTR(smem);
     const bool resident = nch <= nslots;        // (uniform) every chunk keeps its own slot for the whole workgroup
+    // The image / mask pointers as values in SGPRs.  Written as `cond ? a.kc : a.k` with a per-lane condition, hipcc selected the
+    // FIELD OFFSET per lane and loaded the pointer from the kernel-argument segment with a vector load — a dependent memory round trip
+    // (and an s_waitcnt vmcnt(0) that also drained the DMAs already in flight) in front of every DMA instruction of a chunk, four more in
+    // the key-mask chain: ~20 serialised round trips, most of this kernel's 12 us (round 6, found in the ISA).  An empty asm makes each
+    // pointer an opaque register value; the per-lane choice is then a v_cndmask.
+    auto pin = [](auto* p) { asm volatile("" : "+s"(p)); return p; };
+    const bf16_t* const pk[2] = {pin(a.k), NARR == 2 ? pin(a.k_lo) : nullptr};
+    const bf16_t* const pkc[2] = {pin(a.kc), NARR == 2 ? pin(a.kc_lo) : nullptr};
+    const bf16_t* const pvt[2] = {pin(a.vt), NARR == 2 ? pin(a.vt_lo) : nullptr};
+    const bf16_t* const pvtc[2] = {pin(a.vtc), NARR == 2 ? pin(a.vtc_lo) : nullptr};
+    const uint8_t* const pms = pin(a.mask_self);
+    const uint8_t* const pmr = pin(a.mask_ref);
+    const uint8_t* const pmt = pin(a.mask_text);
+    const int aR = a.R, aP = a.P;
 
     auto swz = [](int row, int c) { return PPR == 16 ? (c ^ (row & 15)) : (c ^ ((row >> 1) & 7)); };
 
@@ -122,11 +136,11 @@ __global__ __launch_bounds__(256) void attention_img_kernel(AttnImg a, int nslot
                 const bf16_t* src;
                 if (kp < Np || Cp == 0) {
                     const int n = kp < N ? kp : N - 1;            // pad rows: any readable row (masked out below)
-                    src = (ar ? a.k_lo : a.k) + (bh * N + n) * DHP;
+                    src = pk[ar] + (bh * N + n) * DHP;
                 } else {
                     int j = kp - Np;
                     j = j < Cp ? j : Cp - 1;
-                    src = (ar ? a.kc_lo : a.kc) + (bh * Cp + j) * DHP;
+                    src = pkc[ar] + (bh * Cp + j) * DHP;
                 }
                 dma16(src + swz(row, p) * 8, base + (unsigned)(ar * K_ARR + ii * 1024));
             }
@@ -137,30 +151,42 @@ __global__ __launch_bounds__(256) void attention_img_kernel(AttnImg a, int nslot
                 const int gp = c0 + ((p ^ ((dr >> 1) & 7)) << 3);    // first key position of this 8-key group
                 const bf16_t* src;
                 if (gp < Np) {
-                    src = (ar ? a.vt_lo : a.vt) + (bh * DHP + dr) * Np + gp;
+                    src = pvt[ar] + (bh * DHP + dr) * Np + gp;
                 } else if (gp < Kpos) {
-                    src = (ar ? a.vtc_lo : a.vtc) + (bh * DHP + dr) * Cp + (gp - Np);
+                    src = pvtc[ar] + (bh * DHP + dr) * Cp + (gp - Np);
                 } else {
-                    src = (ar ? a.vt_lo : a.vt) + (bh * DHP + dr) * Np;   // beyond the last key: finite data, P = 0 there
+                    src = pvt[ar] + (bh * DHP + dr) * Np;   // beyond the last key: finite data, P = 0 there
                 }
                 dma16(src, base + (unsigned)(NARR * K_ARR + ar * V_ARR + ii * 1024));
             }
         }
     };
-    // key validity of a chunk as a 64-bit mask (lane = key position), identical in every wave
-    auto chunk_mask = [&](int c0) -> unsigned long long {
-        bool kval = false;
+    // key validity of a chunk as a 64-bit mask (lane = key position), identical in every wave.  ONE byte load per lane: which mask
+    // array and which index is a per-lane select of register values, not three branch arms with a load and a wait each
+    auto chunk_byte = [&](int c0, bool& inr) -> int {
         const int kp = c0 + lane;
+        const uint8_t* mp;
+        long mi;
         if (kp < Np) {
-            kval = kp < N && (!a.mask_self || a.mask_self[b * N + kp]);
+            mp = pms; mi = (long)b * N + kp; inr = kp < N;
         } else if (kp < Np + Rp) {
             const int j = kp - Np;
-            kval = j < a.R && (!a.mask_ref || a.mask_ref[b * a.R + j]);
-        } else if (kp < Kpos) {
+            mp = pmr; mi = (long)b * aR + j; inr = j < aR;
+        } else {
             const int j = kp - Np - Rp;
-            kval = j < a.P && (!a.mask_text || a.mask_text[b * a.P + j]);
+            mp = pmt; mi = (long)b * aP + j; inr = kp < Kpos && j < aP;
         }
-        return __ballot(kval);
+        // unconditional load of a readable byte (an exec-masked `if (inr && mp)` put a wait at its join: four serial round trips for
+        // the four chunk masks); the value only counts where the key is in range and its mask exists
+        const bool use = inr && mp != nullptr;
+        const uint8_t* const sp = use ? mp + mi : reinterpret_cast<const uint8_t*>(pk[0]);
+        const int v = *sp;
+        return use ? v : 1;
+    };
+    auto chunk_mask = [&](int c0) -> unsigned long long {
+        bool inr;
+        const int v = chunk_byte(c0, inr);
+        return __ballot(inr && v != 0);
     };
 
     float m_run, l_run;   // per query (lane & 31); both lane halves keep identical copies
@@ -263,15 +289,37 @@ __global__ __launch_bounds__(256) void attention_img_kernel(AttnImg a, int nslot
     // ---- normalise, gate, store: lane = query fr, rows = dims 32 w + (r & 3) + 8 (r >> 2) + 4 fh -----------------------------
     // sigmoid(gate) of this lane's output elements: requested at the top of a tile, together with the DMAs, so that the
     // epilogue does not start with a dependent memory round trip
-    float4 g4[4];
+    // (RAW 16-bit words: the conversion waits for the data, so it happens in finish() — converting where the loads are issued put an
+    // s_waitcnt vmcnt(0) behind each of the four, i.e. four dependent round trips that also drained the tile's DMAs)
+    uint2 graw[4], glraw[4];
+    const bf16_t* const pg = pin(a.g);
+    const bf16_t* const pgl = SPLIT == PREC_BF16X3 ? pin(a.g_lo) : nullptr;
     auto load_gate = [&](int q0) {
         const int n = q0 + fr;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int d0 = 32 * w + 8 * q + 4 * fh;
-            g4[q] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (w < NDT && n < N && d0 < a.dh)
-                g4[q] = load_act4(a.g, a.g_lo, ((long)b * N + n) * ((long)a.H * a.dh) + h * a.dh + d0);
+            graw[q] = make_uint2(0u, 0u);
+            if (SPLIT == PREC_BF16X3) glraw[q] = make_uint2(0u, 0u);
+            if (w < NDT && n < N && d0 < a.dh) {
+                const long off = ((long)b * N + n) * ((long)a.H * a.dh) + h * a.dh + d0;
+                graw[q] = *reinterpret_cast<const uint2*>(pg + off);
+                if (SPLIT == PREC_BF16X3) glraw[q] = *reinterpret_cast<const uint2*>(pgl + off);
+            }
+        }
+    };
+    auto gate4 = [&](int q) -> float4 {   // what store_split4 wrote in the format of this instantiation
+        if constexpr (SPLIT == PREC_F16) {
+            const half2_t a0 = __builtin_bit_cast(half2_t, graw[q].x), a1 = __builtin_bit_cast(half2_t, graw[q].y);
+            return make_float4((float)a0[0], (float)a0[1], (float)a1[0], (float)a1[1]);
+        } else {
+            float4 r = make_float4(__uint_as_float(graw[q].x << 16), __uint_as_float(graw[q].x & 0xffff0000u),
+                                   __uint_as_float(graw[q].y << 16), __uint_as_float(graw[q].y & 0xffff0000u));
+            if constexpr (SPLIT == PREC_BF16X3) {
+                r.x += __uint_as_float(glraw[q].x << 16); r.y += __uint_as_float(glraw[q].x & 0xffff0000u);
+                r.z += __uint_as_float(glraw[q].y << 16); r.w += __uint_as_float(glraw[q].y & 0xffff0000u);
+            }
+            return r;
         }
     };
     auto finish = [&](int q0) {
@@ -279,9 +327,12 @@ __global__ __launch_bounds__(256) void attention_img_kernel(AttnImg a, int nslot
         if (w < NDT && n < N) {
             const float inv = l_run > 0.f ? 1.0f / l_run : 0.f;
             const long obase = ((long)b * N + n) * a.ors + h * a.dh;
+            float4 g4[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {   // the (conditional) gate loads are complete before the first store (gemm.hpp epi_settle)
-                asm volatile("" : "+v"(g4[q].x), "+v"(g4[q].y), "+v"(g4[q].z), "+v"(g4[q].w));
+                asm volatile("" : "+v"(graw[q].x), "+v"(graw[q].y));
+                if (SPLIT == PREC_BF16X3) asm volatile("" : "+v"(glraw[q].x), "+v"(glraw[q].y));
+                g4[q] = gate4(q);
             }
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
@@ -308,11 +359,16 @@ __global__ __launch_bounds__(256) void attention_img_kernel(AttnImg a, int nslot
     if (resident)
         for (int c = 0; c < nch; ++c) issue_chunk(c * KC, c);
     unsigned long long vm0 = 0, vm1 = 0, vm2 = 0, vm3 = 0;   // chunk masks, loaded once when there are at most four chunks
-    if (nch <= 4) {
-        vm0 = chunk_mask(0);
-        if (nch > 1) vm1 = chunk_mask(KC);
-        if (nch > 2) vm2 = chunk_mask(2 * KC);
-        if (nch > 3) vm3 = chunk_mask(3 * KC);
+    if (nch <= 4) {   // (all four byte loads go out before the first ballot looks at one)
+        bool i0 = false, i1 = false, i2 = false, i3 = false;
+        const int v0 = chunk_byte(0, i0);
+        const int v1 = chunk_byte(KC, i1);          // (chunks past the last: every key out of range, the load reads a dummy byte)
+        const int v2 = chunk_byte(2 * KC, i2);
+        const int v3 = chunk_byte(3 * KC, i3);
+        vm0 = __ballot(i0 && v0 != 0);
+        vm1 = __ballot(i1 && v1 != 0);
+        vm2 = __ballot(i2 && v2 != 0);
+        vm3 = __ballot(i3 && v3 != 0);
     }
     for (int it = 0; qt < ntiles; qt += gridDim.x, ++it) {
         if (!resident) {
