@@ -474,6 +474,13 @@ static inline hipError_t gemm3_launch_split(const Gemm3Operands& g, const Epi& e
             }
         }
     }
+    if constexpr (SPLIT == 3 && !Epi::PAIRED) {
+        // split-bf16 on the 64 x 64 tile: four arrays per stage, so the 2-stage ring has ONE k-tile in flight and every k-tile pays a
+        // whole memory round trip (the grouped conv pos-embed: 31 k-tiles, 1.26 us each).  A grid that is resident at once (<= 256
+        // workgroups, one per CU: 128 KiB of LDS) takes four stages (round 6)
+        const long tiles64 = ((g.M + 63) / 64) * ((g.N + 63) / 64) * (Z > 0 ? Z : 1);
+        if (g_gemm3_deep && cfg == G3_64x64 && tiles64 <= 256) return gemm3_launch_cfg<64, 64, 2, 2, 3, 4, Epi>(g, epi, Z, st);
+    }
     switch (cfg) {
 #ifdef SMTTS_LAB
         case G4_256x256:
