@@ -276,7 +276,10 @@ template <class Epi> struct gemm4_enabled : std::false_type {};
 template <int ACT> struct gemm4_enabled<EpiStore<ACT>> : std::true_type {};
 template <int G> struct gemm4_enabled<EpiResid<G>> : std::true_type {};
 
-static inline bool gemm4_ok(const Gemm3Operands& g) { return gemm3_ok(g) && (g.ksplit_tiles ? g.ksplit_tiles >= 2 : g.K >= 128); }
+// (a split-K launch whose tail slice has ONE k-tile has no pipeline to run: not ok -> gemm3_launch falls back to its 128 x 128 tile)
+static inline bool gemm4_ok(const Gemm3Operands& g) {
+    return gemm3_ok(g) && (g.ksplit_tiles ? (g.ksplit_tiles >= 2 && (g.K / 64) % g.ksplit_tiles != 1) : g.K >= 128);
+}
 
 template <int SPLIT, class Epi>
 static inline hipError_t gemm4_launch_cfg(const Gemm3Operands& g, const Epi& epi, int Z, hipStream_t st) {
@@ -284,7 +287,6 @@ static inline hipError_t gemm4_launch_cfg(const Gemm3Operands& g, const Epi& epi
         return hipErrorInvalidValue;
     } else {
         if (!gemm4_ok(g)) return hipErrorInvalidValue;
-        if (g.ksplit_tiles && (g.K / 64) % g.ksplit_tiles == 1) return hipErrorInvalidValue;   // (a 1-k-tile tail slice has no pipeline)
         constexpr size_t lds = 2 * (256 + 256) * 128;   // 128 KiB: one workgroup per CU
         dim3 grid(((g.N + 255) / 256) * ((g.M + 255) / 256), 1, Z);
         auto kern = gemm4_kernel<SPLIT, Epi>;
